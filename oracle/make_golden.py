@@ -1,0 +1,384 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (read-only import from
+/root/reference) on deterministic, name-seeded parameters and synthetic batches.
+
+Run in the build container only:  python oracle/make_golden.py
+The reference never travels to the GPU box; only the small .npz fixtures written here do.
+
+Reference code exercised (imported, not copied):
+  src/modeling/models/adapter.py        Adapter
+  src/modeling/adaptered_output.py      Adaptered_ViltOutput
+  src/modeling/vilt.py                  ViltEncoderWrapper, ViltContinualLearner
+  src/train/visionlanguage_tasks/task_trainer.py   TaskTrainer.train_step/create_optimizer, kl_loss
+  src/train/main.py                     get_average_net  (function source exec'd: the module itself
+                                        imports transformers.adapters, which does not exist here)
+around HuggingFace transformers' ViltModel(ViltConfig()) (random init replaced by seeded fill).
+Shims are the ones listed in SURVEY.md section 8c.
+"""
+import ast
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.nn as nn
+import transformers  # noqa: F401  (must be imported before the stubs below)
+import accelerate  # noqa: F401
+
+from oracle import feddat_oracle as O
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_shims():
+    class _LoraLinear(nn.Linear):
+        def __init__(self, i, o, r=0, **kw):
+            super().__init__(i, o)
+    _stub("loralib", Linear=_LoraLinear)
+    _stub("timm")
+    _stub("timm.models")
+    _stub("timm.models.vision_transformer", _cfg=lambda **k: {}, PatchEmbed=nn.Identity)
+    _stub("timm.models.registry", register_model=lambda f: f)
+    _stub("timm.models.layers", trunc_normal_=nn.init.trunc_normal_, DropPath=nn.Identity)
+    sys.path.insert(0, REF)
+    # bypass src/modeling/__init__.py (pulls in ALBEF -> HF 4.x internals)
+    for pkg, sub in (("src", "src"), ("src.modeling", "src/modeling"), ("src.modeling.models", "src/modeling/models"),
+                     ("src.train", "src/train"), ("src.train.visionlanguage_tasks", "src/train/visionlanguage_tasks"),
+                     ("src.utils", "src/utils")):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, sub)]
+        sys.modules[pkg] = m
+    # adapter.py:144 hard-codes .to('cuda'): send it to CPU
+    _orig_to = torch.Tensor.to
+
+    def _to(self, *a, **k):
+        if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+            a = ("cpu",) + tuple(a[1:])
+        return _orig_to(self, *a, **k)
+    torch.Tensor.to = _to
+
+
+install_shims()
+from src.modeling.models.adapter import Adapter  # noqa: E402
+from src.modeling.vilt import ViltEncoderWrapper, ViltContinualLearner  # noqa: E402
+from src.train.visionlanguage_tasks.task_trainer import TaskTrainer, kl_loss  # noqa: E402
+from transformers import ViltConfig, ViltModel  # noqa: E402
+
+
+def load_get_average_net():
+    src = open(os.path.join(REF, "src/train/main.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_average_net"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "main.py:get_average_net", "exec"), ns)
+    return ns["get_average_net"]
+
+
+def build_reference_model(d: O.ViltDims, tasks, bias_std):
+    cfg = ViltConfig(num_hidden_layers=d.layers, image_size=d.image_size)
+    vilt = ViltModel(cfg)
+    enc = ViltEncoderWrapper.__new__(ViltEncoderWrapper)  # its __init__ loads ./models/bert-base-uncased
+    nn.Module.__init__(enc)
+    enc.processor = None
+    enc.vilt = vilt
+    enc.device = torch.device("cpu")
+    enc.max_text_length = cfg.max_position_embeddings
+    enc.encoder_dim = cfg.hidden_size
+    enc.expand_modality_type_embeddings()           # vilt.py:102-113
+    enc.process_inputs = lambda images, texts: images  # pre-built tensor dict rides in `images`
+    task_cfg = {t: {"num_labels": d.num_labels, "num_images": 1, "model_type": "classification"} for t in tasks}
+    model = ViltContinualLearner(list(tasks), enc, cfg.hidden_size, task_cfg, torch.device("cpu"),
+                                 {"names": ["adapter_0", "adapter_1", "adapter_2"], "device": "cpu"})
+    for p in model.parameters():                    # main.py:138-139
+        p.requires_grad = False
+    # add_adapter() hard-codes range(12) (vilt.py:357); restate its body for d.layers
+    from src.modeling.adaptered_output import Adaptered_ViltOutput
+    for i in range(d.layers):
+        model.vilt_encoder.vilt.encoder.layer[i].output = Adaptered_ViltOutput(
+            model.vilt_encoder.vilt.encoder.layer[i].output, model.adapter_config)
+    for n, p in model.named_parameters():           # main.py:157-159, 248-250
+        if "adapter" in n or "task" in n:
+            p.requires_grad = True
+    model.comm_state_dict_names = [n for n in model.state_dict().keys() if "adapter_1" in n]
+    sd = model.state_dict()
+    shapes = O.param_shapes(d, tasks)
+    missing = [k for k in shapes if k not in sd]
+    assert not missing, missing[:5]
+    with torch.no_grad():
+        for k, shp in shapes.items():
+            assert tuple(sd[k].shape) == tuple(shp), (k, sd[k].shape, shp)
+            sd[k].copy_(O.seeded_value(k, shp, 0.02, bias_std))
+    extra = [k for k in sd if k not in shapes and "position_ids" not in k and "token_type_ids" not in k]
+    assert not extra, extra[:5]
+    model.eval()
+    return model
+
+
+class _Wrap:
+    def __init__(self, m):
+        self.module = m
+
+    def __call__(self, *a, **k):
+        return self.module(*a, **k)
+
+    def named_parameters(self):
+        return self.module.named_parameters()
+
+
+class _Acc:
+    device = torch.device("cpu")
+
+    @staticmethod
+    def backward(loss):
+        loss.backward()
+
+
+def make_trainer(task, lr, steps_per_epoch, num_epochs=15):
+    tr = TaskTrainer()
+    tr.accelerator = _Acc()
+    tr.device = torch.device("cpu")
+    tr.task_key = task
+    tr.args = types.SimpleNamespace(optimizer_mode="dat", encoder_name="vilt", debug=0)
+    tr.batch2inputs_converter = lambda batch: {"images": _enc_only(batch), "texts": None}
+    tr.loss_criterion = nn.BCEWithLogitsLoss(reduction="mean")
+    tr.lr, tr.adam_epsilon, tr.weight_decay = lr, 1e-8, 1e-2
+    tr.max_steps = steps_per_epoch * num_epochs
+    tr.warmup_ratio = 0.1
+    return tr
+
+
+def ref_local_update(model, task, batches, lr, num_epochs=15, capture=None):
+    """task_trainer.py:36-59 prologue + train_step loop, driven on the reference objects."""
+    from transformers import get_polynomial_decay_schedule_with_warmup
+    sd = model.state_dict()
+    for name in sd.keys():
+        if "adapter_1" in name:
+            sd[name.replace("adapter_1", "adapter_2")].data.copy_(sd[name].data.clone())
+    for n, p in model.named_parameters():
+        if "adapter_2" in n:
+            p.requires_grad = False
+    tr = make_trainer(task, lr, len(batches), num_epochs)
+    opt = tr.create_optimizer(model, "dat")
+    sch = get_polynomial_decay_schedule_with_warmup(opt, num_warmup_steps=int(tr.max_steps * tr.warmup_ratio),
+                                                    num_training_steps=tr.max_steps, lr_end=0, power=1)
+    model.zero_grad()
+    w = _Wrap(model)
+    losses = []
+    for step, b in enumerate(batches):
+        loss = tr.train_step(w, step, dict(b), opt, sch)
+        losses.append(float(loss))
+        if capture is not None:
+            capture(step, model)
+    return losses, opt
+
+
+def _enc_only(b):
+    return {k: v for k, v in b.items() if k != "target_scores"}
+
+
+def np_(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+SAMPLE_ABOVE = 40000
+N_SAMPLES = 2048
+
+
+def put(rec, key, t):
+    """Small tensors are stored whole; large ones as L2 norm + N_SAMPLES strided samples
+    (tests/golden_util.py:check reads both forms)."""
+    t = t.detach().float()
+    if t.numel() <= SAMPLE_ABOVE:
+        rec[key] = np_(t)
+    else:
+        flat = t.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, N_SAMPLES).long()
+        rec["samp::" + key] = np_(flat[idx])
+        rec["norm::" + key] = np_(flat.norm())
+
+
+def main():
+    out = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out, exist_ok=True)
+    torch.manual_seed(0)
+
+    # ---------------- G1: Adapter module (adapter.py:124-163) ----------------
+    ad = Adapter(["adapter_0", "adapter_1", "adapter_2"], "cpu")
+    g = torch.Generator().manual_seed(11)
+    T = 128
+    with torch.no_grad():
+        for n, p in ad.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if "weight" in n else 0.02))
+    x = torch.randn(2, T // 2, 768, generator=g)
+    dy = torch.randn(2, T // 2, 768, generator=g)
+    res = {"x": np_(x), "dy": np_(dy)}
+    for n, p in ad.named_parameters():
+        res["p." + n] = np_(p)
+    for mode in ("adapter_1", "gating"):
+        for p in ad.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        if mode == "gating":
+            ad.activate_gating()
+            ad.set_active_adapter("adapter_0")
+        else:
+            ad.deactivate_gating()
+            ad.set_active_adapter("adapter_1")
+        y = ad(xi, xi)
+        y.backward(dy)
+        res[f"{mode}.y"] = np_(y)
+        res[f"{mode}.dx"] = np_(xi.grad)
+        for n, p in ad.named_parameters():
+            if p.grad is not None:
+                res[f"{mode}.d.{n}"] = np_(p.grad)
+    np.savez_compressed(os.path.join(out, "g1_adapter.npz"), **res)
+
+    # ---------------- G2: loss (task_trainer.py:299-301,506-516) ----------------
+    logits = (torch.randn(8, 100, generator=g) * 2).requires_grad_(True)
+    teacher = torch.randn(8, 100, generator=g) * 2
+    target = O.synthetic_batch(8, 32, 5)["target_scores"]
+    bce = nn.BCEWithLogitsLoss(reduction="mean")(logits, target) * target.shape[1]
+    kl = kl_loss(logits, teacher.clone().detach())
+    L = (bce + kl) / 2
+    L.backward()
+    np.savez_compressed(os.path.join(out, "g2_loss.npz"), logits=np_(logits), teacher=np_(teacher),
+                        target=np_(target), bce=np_(bce), kl=np_(kl), L=np_(L), dlogits=np_(logits.grad))
+
+    # ---------------- G3: 2-layer ViLT, B=4, 224 and 384 (configs[0]) ----------------
+    gavg = load_get_average_net()
+    for res_px in (224, 384):
+        d = O.ViltDims(layers=2)
+        tasks = ["art", "gqa"]
+        model = build_reference_model(d, tasks, bias_std=0.02)
+        batches = [O.synthetic_batch(4, res_px, 1234 + s) for s in range(5)]
+        rec = {}
+        with torch.no_grad():
+            for mode in ("gating", "adapter_1", "adapter_0"):
+                if mode == "gating":
+                    model.activate_gating()
+                else:
+                    model.deactivate_gating()
+                    model.set_active_adapter(mode)
+                pooled, lg = model(task_key="art", images=_enc_only(batches[0]), texts=None)
+                rec[f"fwd.{mode}.pooled"] = np_(pooled)
+                rec[f"fwd.{mode}.logits"] = np_(lg)
+        # the forward captures above left the flags in the post-set_active_adapter('adapter_0')
+        # state; restore prepare_model's round-0 state (main.py:157-159): all adapters trainable
+        for n, p in model.named_parameters():
+            if "adapter" in n:
+                p.requires_grad = True
+        snaps = {}
+
+        def cap(step, m, snaps=snaps):
+            if step + 1 in (1, 2, 5):
+                sd = m.state_dict()
+                snaps[step + 1] = {k: v.detach().clone() for k, v in sd.items()
+                                   if ("adapter_0" in k or "adapter_1" in k or k.startswith("task_layer.art."))}
+        losses, opt = ref_local_update(model, "art", batches, lr=1e-4, capture=cap)
+        rec["losses"] = np.array(losses, np.float32)
+        for n_steps, s in snaps.items():
+            for k, v in s.items():
+                if "adapter" in k and ".layer.0." not in k and n_steps != 5:
+                    continue  # keep the fixture small: layer-0 adapters at 1,2; everything at 5
+                put(rec, f"after{n_steps}.{k}", v)
+        np.savez_compressed(os.path.join(out, f"g3_vilt2_{res_px}.npz"), **rec)
+        print("G3", res_px, "losses", losses)
+
+    # ---------------- G3q: optimizer membership follows requires_grad at train() time ----------
+    # After TaskTrainer.eval (task_trainer.py:236-244) the server model is left in the
+    # set_active_adapter('adapter_1') state, i.e. adapter_0.requires_grad == False; the next
+    # round's create_optimizer (task_trainer.py:477-504) then leaves adapter_0 out.
+    d = O.ViltDims(layers=2)
+    model = build_reference_model(d, ["art", "gqa"], bias_std=0.02)
+    model.deactivate_gating()
+    model.set_active_adapter("adapter_1")
+    batches = [O.synthetic_batch(4, 224, 1234 + s) for s in range(3)]
+    losses, opt = ref_local_update(model, "art", batches, lr=1e-4)
+    rec = {"losses": np.array(losses, np.float32)}
+    for k, v in model.state_dict().items():
+        if ".layer.1." in k and ("adapter_0" in k or "adapter_1" in k):
+            put(rec, "after3." + k, v)
+    np.savez_compressed(os.path.join(out, "g3q_flags.npz"), **rec)
+
+    # ---------------- G5: FedAvg (main.py:50-65) + one round, 2 clients x 3 steps ----------------
+    d = O.ViltDims(layers=2)
+    tasks = ["art", "gqa"]
+    server = build_reference_model(d, tasks, bias_std=0.02)
+    import copy
+    personal = {t: {n: v.clone() for n, v in server.state_dict().items()
+                    if any(pn in n for pn in ("task", "adapter_0", "adapter_2"))} for t in tasks}
+    c_models = []
+    rec = {}
+    for ci, t in enumerate(tasks):
+        tm = copy.deepcopy(server)
+        for n, v in personal[t].items():
+            tm.state_dict()[n].data.copy_(v)
+        batches = [O.synthetic_batch(4, 224, 777 + 10 * ci + s) for s in range(3)]
+        losses, _ = ref_local_update(tm, t, batches, lr=1e-4)
+        rec[f"losses.{t}"] = np.array(losses, np.float32)
+        c_models.append({n: tm.state_dict()[n].data.clone() for n in server.comm_state_dict_names})
+        for n, v in tm.state_dict().items():
+            if "adapter_0" in n and ".layer.1." in n:
+                rec[f"personal.{t}.{n}"] = np_(v)
+    server = gavg(server, c_models, [1, 1], tasks, torch.device("cpu"))
+    for n in server.comm_state_dict_names:
+        rec["server." + n] = np_(server.state_dict()[n])
+    np.savez_compressed(os.path.join(out, "g5_round.npz"), **rec)
+    # pure FedAvg, K=5 synthetic client dicts, non-uniform nums
+    K = 5
+    keys = [k for k in server.comm_state_dict_names if ".layer.0." in k]
+    cm = [{k: torch.randn(server.state_dict()[k].shape, generator=g) for k in keys} for _ in range(K)]
+    srv = types.SimpleNamespace(comm_state_dict_names=keys,
+                                state_dict=lambda sd={k: torch.zeros_like(cm[0][k]) for k in keys}: sd)
+    nums = [1, 2, 3, 4, 5]
+    gavg(srv, cm, nums, None, torch.device("cpu"))
+    rec = {f"c{i}.{k}": np_(cm[i][k]) for i in range(K) for k in keys}
+    rec.update({"avg." + k: np_(srv.state_dict()[k]) for k in keys})
+    rec["nums"] = np.array(nums, np.float32)
+    np.savez_compressed(os.path.join(out, "g5_fedavg.npz"), **rec)
+
+    # ---------------- G4: full 12-layer, B=4, 384: logits x3, loss, sampled adapter tensors after 4 steps
+    d = O.ViltDims(layers=12)
+    model = build_reference_model(d, ["art"], bias_std=0.02)
+    batches = [O.synthetic_batch(4, 384, 4321 + s) for s in range(4)]
+    rec = {}
+    with torch.no_grad():
+        for mode in ("gating", "adapter_1"):
+            if mode == "gating":
+                model.activate_gating()
+            else:
+                model.deactivate_gating()
+                model.set_active_adapter(mode)
+            pooled, lg = model(task_key="art", images=_enc_only(batches[0]), texts=None)
+            rec[f"fwd.{mode}.pooled"] = np_(pooled)
+            rec[f"fwd.{mode}.logits"] = np_(lg)
+    for n, p in model.named_parameters():   # back to prepare_model's round-0 flags
+        if "adapter" in n:
+            p.requires_grad = True
+    losses, _ = ref_local_update(model, "art", batches, lr=1e-4)
+    rec["losses"] = np.array(losses, np.float32)
+    for k, v in model.state_dict().items():
+        if "adapter_0" in k or "adapter_1" in k:
+            flat = v.flatten()
+            idx = torch.linspace(0, flat.numel() - 1, 256).long()
+            rec["norm::" + k] = np_(flat.norm())
+            rec["samp256::" + k] = np_(flat[idx])
+    np.savez_compressed(os.path.join(out, "g4_vilt12_384.npz"), **rec)
+    print("G4 losses", losses)
+    for f in sorted(os.listdir(out)):
+        print(f, os.path.getsize(os.path.join(out, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
