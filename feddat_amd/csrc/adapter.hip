@@ -1,0 +1,292 @@
+// K4: fused dual Pfeiffer adapter (DAT module), forward and backward.
+// Reference: src/modeling/models/adapter.py:124-163 (single: 125-131; gating: 133-146, get_agg_out 118-122),
+// called as adapter(h, h) from Adaptered_ViltOutput.forward (src/modeling/adaptered_output.py:77).
+//
+// One wave owns 16 tokens.  The token rows stream straight from HBM into MFMA operand registers
+// (fp32 -> bf16 in flight), the [16 x 48] bottleneck never leaves registers: the down-projection is
+// computed as Z^T[r, tok] so that its accumulator layout (lane: token = lane & 15, four consecutive r)
+// is already the operand layout of the up-projection (contraction slots are paired (g, j) <-> (g, j),
+// so the slot -> r permutation only has to be applied to the weight operand).  The up-projection is
+// computed as Y^T[c, tok]: every lane ends with 4 consecutive output columns of one token ->
+// 16-byte residual loads and stores.  Adapter weights (72 KiB per matrix, bf16) are read through L1/L2.
+// HBM-bound: 2 x T x 768 x 4 B algorithmic bytes per call.
+#include "common.hip.h"
+
+namespace {
+
+constexpr int H = 768, R = 48, NT = 3, KS = H / 32, CT = H / 16;
+
+struct AdapterLaunch {
+    feddat_adapter_seg seg[2];
+    int nseg;
+    int tiles0;  // number of 16-token tiles of segment 0
+};
+
+__device__ __forceinline__ bf16x8 load_x8(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    return cvt8(a, b);
+}
+
+// Z^T[a][nt] += Wd[a] (rows r) x X^T (cols tok), contraction over the 768 features.
+template <int NA>
+__device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const bf16* const* wd, int lane,
+                                          f32x4 (&z)[2][NT]) {
+    const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll 4
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 xf = load_x8(xrow + ks * 32 + g * 8);
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 wf =
+                    *reinterpret_cast<const bf16x8*>(wd[a] + (size_t)(nt * 16 + i16) * H + ks * 32 + g * 8);
+                z[a][nt] = mfma16x32(wf, xf, z[a][nt]);
+            }
+    }
+}
+
+// weight operand for the contraction over r = 48 with slots (g, j<4) -> r = 4g + j, (g, j>=4) -> r = 16 + 4g + j - 4
+// (first MFMA, K = 32) and (g, j) -> r = 32 + 4g + j (second MFMA, K = 16).  w is [rows, 48] bf16.
+__device__ __forceinline__ void load_w48(const bf16* w, int row, int g, bf16x8& w01, bf16x4& w2) {
+    const bf16* p = w + (size_t)row * R + 4 * g;
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 16);
+    w2 = *reinterpret_cast<const bf16x4*>(p + 32);
+    w01 = bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          AdapterLaunch L) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // this kernel instance serves the segments whose n_adapters == NA
+    int s, t;
+    if (tile < L.tiles0) { s = 0; t = tile; } else { s = 1; t = tile - L.tiles0; }
+    if (s >= L.nseg) return;
+    const feddat_adapter_seg& sg = L.seg[s];
+    if (sg.n_adapters != NA) return;
+    const int row0 = sg.row_begin + t * 16;
+    if (row0 >= sg.row_end) return;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int row = row0 + i16;
+    const bool valid = row < sg.row_end;
+    const float* xrow = x + (size_t)(valid ? row : sg.row_end - 1) * H;
+
+    const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
+    f32x4 z[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    down_proj<NA>(xrow, wd, lane, z);
+
+    bf16x8 zb01[NA];
+    bf16x4 zb2[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(z[a][nt][e] + b4[e], 0.f);
+        }
+        zb01[a] = cvt8(z[a][0], z[a][1]);
+        zb2[a] = cvt4(z[a][2]);
+    }
+
+#pragma unroll 2
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 16 + 4 * g;
+        f32x4 o = *reinterpret_cast<const f32x4*>(xrow + c);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            bf16x8 w01;
+            bf16x4 w2;
+            load_w48((const bf16*)sg.wu[a], ct * 16 + i16, g, w01, w2);
+            f32x4 y = mfma16x32(w01, zb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
+            y = mfma16x16(w2, zb2[a], y);
+            const f32x4 bu4 = *reinterpret_cast<const f32x4*>(sg.bu[a] + c);
+            const float sc = sg.scale[a];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += sc * (y[e] + bu4[e]);
+        }
+        if (valid) *reinterpret_cast<f32x4*>(out + (size_t)row * H + c) = o;
+    }
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, bf16* __restrict__ dx16,
+                                                          float* __restrict__ z_out, float* __restrict__ dz_out,
+                                                          AdapterLaunch L) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int s, t;
+    if (tile < L.tiles0) { s = 0; t = tile; } else { s = 1; t = tile - L.tiles0; }
+    if (s >= L.nseg) return;
+    const feddat_adapter_seg& sg = L.seg[s];
+    if (sg.n_adapters != NA) return;
+    const int row0 = sg.row_begin + t * 16;
+    if (row0 >= sg.row_end) return;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int row = row0 + i16;
+    const bool valid = row < sg.row_end;
+    const size_t rclamp = (size_t)(valid ? row : sg.row_end - 1);
+    const float* xrow = x + rclamp * H;
+    const float* dyrow = dy + rclamp * H;
+
+    // 1. recompute z = relu(Wd x + bd)
+    const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
+    f32x4 z[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    down_proj<NA>(xrow, wd, lane, z);
+    // 2. g = Wu^T dy  (same contraction over the 768 features, weight operand = WuT [48, 768])
+    const bf16* wuT[2] = {(const bf16*)sg.wuT[0], (const bf16*)sg.wuT[NA - 1]};
+    f32x4 gr[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    down_proj<NA>(dyrow, wuT, lane, gr);
+
+    // 3. dz = scale * g * (z > 0); export z*scale and dz of the trainable slot for the weight gradients
+    bf16x8 dzb01[NA];
+    bf16x4 dzb2[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const float sc = sg.scale[a];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
+            f32x4 zz, dz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                zz[e] = fmaxf(z[a][nt][e] + b4[e], 0.f);
+                dz[e] = zz[e] > 0.f ? sc * gr[a][nt][e] : 0.f;
+                zz[e] *= sc;
+            }
+            gr[a][nt] = dz;
+            if (a == sg.train_slot && valid && z_out) {
+                *reinterpret_cast<f32x4*>(z_out + (size_t)row * R + nt * 16 + 4 * g) = zz;
+                *reinterpret_cast<f32x4*>(dz_out + (size_t)row * R + nt * 16 + 4 * g) = dz;
+            }
+        }
+        dzb01[a] = cvt8(gr[a][0], gr[a][1]);
+        dzb2[a] = cvt4(gr[a][2]);
+    }
+
+    // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48])
+#pragma unroll 2
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 16 + 4 * g;
+        f32x4 o = *reinterpret_cast<const f32x4*>(dyrow + c);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            bf16x8 w01;
+            bf16x4 w2;
+            load_w48((const bf16*)sg.wdT[a], ct * 16 + i16, g, w01, w2);
+            f32x4 y = mfma16x32(w01, dzb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
+            y = mfma16x16(w2, dzb2[a], y);
+            o = o + y;
+        }
+        if (valid) {
+            *reinterpret_cast<f32x4*>(dx + (size_t)row * H + c) = o;
+            if (dx16) *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * H + c) = cvt4(o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
+                                                           bf16* __restrict__ wd16, bf16* __restrict__ wdT16,
+                                                           bf16* __restrict__ wu16, bf16* __restrict__ wuT16) {
+    // wd [R,H] -> wd16 [R,H], wdT16 [H,R];  wu [H,R] -> wu16 [H,R], wuT16 [R,H]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * H) return;
+    {
+        const int r = i / H, c = i - r * H;
+        const bf16 v = (bf16)wd[i];
+        wd16[i] = v;
+        wdT16[(size_t)c * R + r] = v;
+    }
+    {
+        const int c = i / R, r = i - c * R;
+        const bf16 v = (bf16)wu[i];
+        wu16[i] = v;
+        wuT16[(size_t)r * H + c] = v;
+    }
+}
+
+int prep_launch(const feddat_adapter_seg* segs, int nseg, int T, AdapterLaunch& L, int& tiles, bool bwd) {
+    if (!segs || nseg < 1 || nseg > 2) return FEDDAT_EINVAL;
+    L.nseg = nseg;
+    tiles = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const feddat_adapter_seg& sg = segs[s];
+        if (sg.row_begin < 0 || sg.row_end > T || sg.row_end < sg.row_begin) return FEDDAT_EINVAL;
+        if (sg.n_adapters != 1 && sg.n_adapters != 2) return FEDDAT_EINVAL;
+        for (int a = 0; a < sg.n_adapters; ++a) {
+            if (!sg.wd[a] || !sg.wu[a] || !sg.bd[a] || !sg.bu[a]) return FEDDAT_EINVAL;
+            if (bwd && (!sg.wdT[a] || !sg.wuT[a])) return FEDDAT_EINVAL;
+        }
+        L.seg[s] = sg;
+        const int t = (sg.row_end - sg.row_begin + 15) / 16;
+        if (s == 0) L.tiles0 = t;
+        tiles += t;
+    }
+    if (nseg == 1) L.seg[1] = L.seg[0];
+    return FEDDAT_OK;
+}
+
+}  // namespace
+
+extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int r, const feddat_adapter_seg* segs,
+                                  int nseg, hipStream_t stream) {
+    FD_CHECK_ARG(x && out && T > 0 && Hd == H && r == R);
+    AdapterLaunch L;
+    int tiles;
+    const int rc = prep_launch(segs, nseg, T, L, tiles, false);
+    if (rc) return rc;
+    if (tiles == 0) return FEDDAT_OK;
+    bool need[3] = {false, false, false};
+    for (int s = 0; s < nseg; ++s) need[segs[s].n_adapters] = true;
+    const dim3 grid((tiles + 3) / 4);
+    if (need[1]) hipLaunchKernelGGL(adapter_fwd_kernel<1>, grid, dim3(256), 0, stream, x, out, L);
+    if (need[2]) hipLaunchKernelGGL(adapter_fwd_kernel<2>, grid, dim3(256), 0, stream, x, out, L);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adapter_bwd(const float* x, const float* dy, float* dx, void* dx_bf16, float* z_out,
+                                  float* dz_out, int T, int Hd, int r, const feddat_adapter_seg* segs, int nseg,
+                                  hipStream_t stream) {
+    FD_CHECK_ARG(x && dy && dx && T > 0 && Hd == H && r == R);
+    FD_CHECK_ARG((z_out == nullptr) == (dz_out == nullptr));
+    AdapterLaunch L;
+    int tiles;
+    const int rc = prep_launch(segs, nseg, T, L, tiles, true);
+    if (rc) return rc;
+    if (tiles == 0) return FEDDAT_OK;
+    bool need[3] = {false, false, false};
+    for (int s = 0; s < nseg; ++s) need[segs[s].n_adapters] = true;
+    const dim3 grid((tiles + 3) / 4);
+    if (need[1])
+        hipLaunchKernelGGL(adapter_bwd_kernel<1>, grid, dim3(256), 0, stream, x, dy, dx, (bf16*)dx_bf16, z_out, dz_out,
+                           L);
+    if (need[2])
+        hipLaunchKernelGGL(adapter_bwd_kernel<2>, grid, dim3(256), 0, stream, x, dy, dx, (bf16*)dx_bf16, z_out, dz_out,
+                           L);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* wdT_bf16, void* wu_bf16,
+                                   void* wuT_bf16, int Hd, int r, hipStream_t stream) {
+    FD_CHECK_ARG(wd && wu && wd_bf16 && wdT_bf16 && wu_bf16 && wuT_bf16 && Hd == H && r == R);
+    hipLaunchKernelGGL(adapter_pack_kernel, dim3((R * H + 255) / 256), dim3(256), 0, stream, wd, wu, (bf16*)wd_bf16,
+                       (bf16*)wdT_bf16, (bf16*)wu_bf16, (bf16*)wuT_bf16);
+    FD_LAUNCH_RET();
+}

@@ -1,0 +1,360 @@
+// K2: fused self-attention forward / dX-only backward for the frozen ViLT layers
+// (HF ViltSelfAttention: softmax(Q K^T / sqrt(64) + mask) V; reference call site src/modeling/vilt.py:127,
+// backward = autograd through it from task_trainer.py:302,323).
+//
+// One workgroup (4 waves) per (sample, head).  S <= 256 so Q, K, V (and dO in the backward) of one head live in
+// LDS for the whole kernel (row-major [S_pad][64] bf16, 16-byte chunks XOR-swizzled by (row & 7) so that the
+// ds_read_b128 row-fragment reads are conflict-free).  No S x S matrix ever reaches HBM: scores stay in MFMA
+// accumulators; the only saved statistic is the per-row log-sum-exp.
+//
+// MFMA operand plumbing (see common.hip.h for the slot convention): a score tile is always produced in the
+// orientation whose accumulator layout (lane = one row/col index, 4 consecutive partner indices) IS the operand
+// layout of the next product, with the contraction slots permuted -- the partner operand is then fetched with the
+// same permutation: row fragments by ds_read_b128, "transposed" fragments (4 consecutive tokens for one feature)
+// by ds_read_b64_tr_b16.
+#include "common.hip.h"
+
+namespace {
+
+constexpr int D = 64;
+constexpr int ROWB = D * 2;  // 128 bytes per LDS row
+
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ bf16x8 row_frag(const char* m, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(m + sw_off(row, chunk));
+}
+
+// "transposed" fragment: for feature column (c0 + (lane & 15)) the 4 consecutive rows r0 .. r0+3, where r0 is
+// uniform within each 16-lane group.  Lane i of the group supplies the address of row r0 + i/4, columns
+// c0 + 4*(i%4) .. +3; ds_read_b64_tr_b16 hands lane i column i of that 4x16 block.
+__device__ __forceinline__ bf16x4 tr_frag(const char* m, int r0, int c0, int lane) {
+    const int i = lane & 15;
+    const int row = r0 + (i >> 2);
+    const int col = c0 + ((i & 3) << 2);
+    const char* p = m + sw_off(row, col >> 3) + ((col & 7) << 1);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ bf16x8 tr_frag8(const char* m, int r0a, int r0b, int c0, int lane) {
+    const bf16x4 a = tr_frag(m, r0a, c0, lane);
+    const bf16x4 b = tr_frag(m, r0b, c0, lane);
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// cooperative load of one head's [S][64] bf16 slice (row stride ld elements) into swizzled LDS, zero-padding to S_pad
+__device__ __forceinline__ void load_head(const bf16* __restrict__ src, long ld, int S, int S_pad, char* dst, int tid) {
+    for (int idx = tid; idx < S_pad * 8; idx += 256) {
+        const int row = idx >> 3, chunk = idx & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < S) v = *reinterpret_cast<const bf16x8*>(src + (size_t)row * ld + chunk * 8);
+        *reinterpret_cast<bf16x8*>(dst + sw_off(row, chunk)) = v;
+    }
+}
+
+template <int NKS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask,
+                                                       bf16* __restrict__ ctx, float* __restrict__ lse, int S,
+                                                       int heads) {
+    constexpr int S_pad = NKS * 32, NKT = NKS * 2, NQT = NKS * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Ks = Qs + S_pad * ROWB;
+    char* Vs = Ks + S_pad * ROWB;
+    float* mask_add = reinterpret_cast<float*>(Vs + S_pad * ROWB);  // 0 or -inf per key
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int H = heads * D;
+    const long ld = 3L * H;
+    const bf16* base = qkv + (size_t)b * S * ld + h * D;
+    load_head(base, ld, S, S_pad, Qs, tid);
+    load_head(base + H, ld, S, S_pad, Ks, tid);
+    load_head(base + 2 * H, ld, S, S_pad, Vs, tid);
+    for (int k = tid; k < S_pad; k += 256) {
+        const bool ok = k < S && (!kmask || kmask[(size_t)b * S + k]);
+        mask_add[k] = ok ? 0.f : -INFINITY;
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, i16 = lane & 15;
+    for (int qt = wave; qt < NQT; qt += 4) {
+        if (qt * 16 >= S) break;
+        bf16x8 qf[2];
+        qf[0] = row_frag(Qs, qt * 16 + i16, g);
+        qf[1] = row_frag(Qs, qt * 16 + i16, 4 + g);
+        // S^T tiles: rows = keys kt*16 + 4g + r, col = query i16
+        f32x4 s[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16x32(row_frag(Ks, kt * 16 + i16, g), qf[0], a);
+            a = mfma16x32(row_frag(Ks, kt * 16 + i16, 4 + g), qf[1], a);
+            const f32x4 ma = *reinterpret_cast<const f32x4*>(mask_add + kt * 16 + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = a[e] * 0.125f + ma[e];
+                mx = fmaxf(mx, a[e]);
+            }
+            s[kt] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[kt][e] = __expf(s[kt][e] - mx);
+                sum += s[kt][e];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NKS; ++st) {
+            const bf16x8 pb = cvt8(s[2 * st], s[2 * st + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vf = tr_frag8(Vs, st * 32 + 4 * g, st * 32 + 16 + 4 * g, dt * 16, lane);
+                o[dt] = mfma16x32(vf, pb, o[dt]);
+            }
+        }
+        const int q = qt * 16 + i16;
+        if (q < S) {
+            const float inv = 1.0f / sum;
+            bf16* out = ctx + ((size_t)b * S + q) * H + h * D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 v = o[dt];
+                v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+                *reinterpret_cast<bf16x4*>(out + dt * 16 + 4 * g) = cvt4(v);
+            }
+            if (g == 0 && lse) lse[((size_t)b * heads + h) * S + q] = mx + __logf(sum);
+        }
+    }
+}
+
+template <int NKS>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask,
+                                                       const bf16* __restrict__ ctx, const float* __restrict__ lse,
+                                                       const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int S,
+                                                       int heads) {
+    constexpr int S_pad = NKS * 32, NKT = NKS * 2, NQT = NKS * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Ks = Qs + S_pad * ROWB;
+    char* Vs = Ks + S_pad * ROWB;
+    char* Gs = Vs + S_pad * ROWB;  // dO
+    float* Dv = reinterpret_cast<float*>(Gs + S_pad * ROWB);
+    float* Ls = Dv + S_pad;
+    float* kvalid = Ls + S_pad;  // 1 / 0 per key
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int H = heads * D;
+    const long ld = 3L * H;
+    const bf16* base = qkv + (size_t)b * S * ld + h * D;
+    load_head(base, ld, S, S_pad, Qs, tid);
+    load_head(base + H, ld, S, S_pad, Ks, tid);
+    load_head(base + 2 * H, ld, S, S_pad, Vs, tid);
+    // dO into LDS, and Dv[q] = sum_d dO[q][d] * O[q][d]
+    {
+        const bf16* gO = ctx + (size_t)b * S * H + h * D;
+        const bf16* gG = dctx + (size_t)b * S * H + h * D;
+        for (int idx = tid; idx < S_pad * 8; idx += 256) {
+            const int row = idx >> 3, chunk = idx & 7;
+            bf16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
+            float part = 0.f;
+            if (row < S) {
+                gv = *reinterpret_cast<const bf16x8*>(gG + (size_t)row * H + chunk * 8);
+                const bf16x8 ov = *reinterpret_cast<const bf16x8*>(gO + (size_t)row * H + chunk * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += (float)gv[e] * (float)ov[e];
+            }
+            *reinterpret_cast<bf16x8*>(Gs + sw_off(row, chunk)) = gv;
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (chunk == 0) Dv[row] = part;
+        }
+        for (int k = tid; k < S_pad; k += 256) {
+            Ls[k] = k < S ? lse[((size_t)b * heads + h) * S + k] : 0.f;
+            kvalid[k] = (k < S && (!kmask || kmask[(size_t)b * S + k])) ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, i16 = lane & 15;
+    bf16* dq_base = dqkv + (size_t)b * S * ld + h * D;
+
+    // ---- phase 1: dK, dV.  wave owns key tiles; scores in [q rows, key col] orientation ----
+    for (int kt = wave; kt < NKT; kt += 4) {
+        if (kt * 16 >= S) break;
+        const int key = kt * 16 + i16;
+        const bf16x8 kf0 = row_frag(Ks, key, g), kf1 = row_frag(Ks, key, 4 + g);
+        const bf16x8 vf0 = row_frag(Vs, key, g), vf1 = row_frag(Vs, key, 4 + g);
+        const float kv = kvalid[key];
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int qs = 0; qs < NKS; ++qs) {
+            if (qs * 32 >= S) break;
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qrow = (2 * qs + t) * 16;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sc = mfma16x32(row_frag(Qs, qrow + i16, g), kf0, sc);
+                sc = mfma16x32(row_frag(Qs, qrow + i16, 4 + g), kf1, sc);
+                dp = mfma16x32(row_frag(Gs, qrow + i16, g), vf0, dp);
+                dp = mfma16x32(row_frag(Gs, qrow + i16, 4 + g), vf1, dp);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qrow + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + qrow + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = kv * __expf(sc[e] * 0.125f - l4[e]);
+                    p[t][e] = pe;
+                    ds[t][e] = pe * (dp[e] - d4[e]) * 0.125f;
+                }
+            }
+            const bf16x8 pb = cvt8(p[0], p[1]);
+            const bf16x8 dsb = cvt8(ds[0], ds[1]);
+            const int r0a = (2 * qs) * 16 + 4 * g, r0b = (2 * qs + 1) * 16 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = mfma16x32(tr_frag8(Gs, r0a, r0b, dt * 16, lane), pb, dv[dt]);
+                dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
+            }
+        }
+        if (key < S) {
+            bf16* ok = dq_base + (size_t)key * ld + H;
+            bf16* ov = dq_base + (size_t)key * ld + 2 * H;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<bf16x4*>(ok + dt * 16 + 4 * g) = cvt4(dk[dt]);
+                *reinterpret_cast<bf16x4*>(ov + dt * 16 + 4 * g) = cvt4(dv[dt]);
+            }
+        }
+    }
+
+    // ---- phase 2: dQ.  wave owns query tiles; scores in [key rows, q col] orientation ----
+    for (int qt = wave; qt < NQT; qt += 4) {
+        if (qt * 16 >= S) break;
+        const int q = qt * 16 + i16;
+        const bf16x8 qf0 = row_frag(Qs, q, g), qf1 = row_frag(Qs, q, 4 + g);
+        const bf16x8 gf0 = row_frag(Gs, q, g), gf1 = row_frag(Gs, q, 4 + g);
+        const float lq = Ls[q], dq_ = Dv[q];
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks * 32 >= S) break;
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int krow = (2 * ks + t) * 16;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sc = mfma16x32(row_frag(Ks, krow + i16, g), qf0, sc);
+                sc = mfma16x32(row_frag(Ks, krow + i16, 4 + g), qf1, sc);
+                dp = mfma16x32(row_frag(Vs, krow + i16, g), gf0, dp);
+                dp = mfma16x32(row_frag(Vs, krow + i16, 4 + g), gf1, dp);
+                const f32x4 kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = kv4[e] * __expf(sc[e] * 0.125f - lq);
+                    ds[t][e] = pe * (dp[e] - dq_) * 0.125f;
+                }
+            }
+            const bf16x8 dsb = cvt8(ds[0], ds[1]);
+            const int r0a = (2 * ks) * 16 + 4 * g, r0b = (2 * ks + 1) * 16 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
+        }
+        if (q < S) {
+            bf16* oq = dq_base + (size_t)q * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt]);
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kern, int bytes, bool& done) {
+    if (done) return 0;
+    done = true;
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? 0 : 1;
+}
+
+// hardware-semantics probe for tests: returns, per lane, tr_frag8(rows 4g.., rows 16+4g.., col block 16) of a
+// 64x64 bf16 matrix staged exactly like the attention operands.
+__global__ __launch_bounds__(256) void probe_tr16_kernel(const bf16* __restrict__ in, bf16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    load_head(in, 64, 64, 64, smem, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, g = lane >> 4;
+        const bf16x8 v = tr_frag8(smem, 4 * g, 16 + 4 * g, 16, lane);
+        *reinterpret_cast<bf16x8*>(out + lane * 8) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S,
+                               int heads, hipStream_t stream) {
+    FD_CHECK_ARG(qkv && ctx && B > 0 && S > 0 && S <= 256 && heads > 0);
+    const int nks = (S + 31) / 32;
+    const int lds = nks * 32 * ROWB * 3 + nks * 32 * 4;
+    static bool fdone[9] = {false};
+#define NKS_MAX_LDS_F(N) ((N) * 32 * ROWB * 3 + (N) * 32 * 4)
+#define ATTN_FWD(N)                                                                                           \
+    case N:                                                                                                   \
+        if (set_lds(attn_fwd_kernel<N>, NKS_MAX_LDS_F(N), fdone[N])) return FEDDAT_ELAUNCH;                                        \
+        hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * heads), dim3(256), lds, stream, (const bf16*)qkv,     \
+                           key_mask, (bf16*)ctx, lse, S, heads);                                              \
+        break;
+    switch (nks) {
+        ATTN_FWD(1) ATTN_FWD(2) ATTN_FWD(3) ATTN_FWD(4) ATTN_FWD(5) ATTN_FWD(6) ATTN_FWD(7) ATTN_FWD(8)
+        default: return FEDDAT_EINVAL;
+    }
+#undef ATTN_FWD
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse,
+                               const void* dctx, void* dqkv, int B, int S, int heads, hipStream_t stream) {
+    FD_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && B > 0 && S > 0 && S <= 256 && heads > 0);
+    const int nks = (S + 31) / 32;
+    const int lds = nks * 32 * ROWB * 4 + nks * 32 * 4 * 3;
+    static bool bdone[9] = {false};
+#define NKS_MAX_LDS_B(N) ((N) * 32 * ROWB * 4 + (N) * 32 * 4 * 3)
+#define ATTN_BWD(N)                                                                                           \
+    case N:                                                                                                   \
+        if (set_lds(attn_bwd_kernel<N>, NKS_MAX_LDS_B(N), bdone[N])) return FEDDAT_ELAUNCH;                                        \
+        hipLaunchKernelGGL(attn_bwd_kernel<N>, dim3(B * heads), dim3(256), lds, stream, (const bf16*)qkv,     \
+                           key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads);        \
+        break;
+    switch (nks) {
+        ATTN_BWD(1) ATTN_BWD(2) ATTN_BWD(3) ATTN_BWD(4) ATTN_BWD(5) ATTN_BWD(6) ATTN_BWD(7) ATTN_BWD(8)
+        default: return FEDDAT_EINVAL;
+    }
+#undef ATTN_BWD
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_probe_tr16(const void* in_bf16_64x64, void* out_bf16_64x8, hipStream_t stream) {
+    FD_CHECK_ARG(in_bf16_64x64 && out_bf16_64x8);
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(256), 64 * ROWB, stream, (const bf16*)in_bf16_64x64,
+                       (bf16*)out_bf16_64x8);
+    FD_LAUNCH_RET();
+}

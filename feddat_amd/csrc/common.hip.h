@@ -1,0 +1,77 @@
+// Shared device helpers for libfeddat_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/feddat_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define FD_WAVE 64
+
+#define FD_CHECK_ARG(cond)                 \
+    do {                                   \
+        if (!(cond)) return FEDDAT_EINVAL; \
+    } while (0)
+
+#define FD_LAUNCH_RET()                                        \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        return e__ == hipSuccess ? FEDDAT_OK : FEDDAT_ELAUNCH; \
+    } while (0)
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU and its derivative: HF ACT2FN["gelu"] / nn.GELU() (vilt.py:206).
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float u) {
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+
+__device__ __forceinline__ bf16x8 cvt8(const f32x4 a, const f32x4 b) {
+    bf16x8 r;
+    r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];
+    r[4] = (bf16)b[0]; r[5] = (bf16)b[1]; r[6] = (bf16)b[2]; r[7] = (bf16)b[3];
+    return r;
+}
+__device__ __forceinline__ bf16x4 cvt4(const f32x4 a) {
+    bf16x4 r;
+    r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];
+    return r;
+}
+
+// MFMA wrappers.  Operand convention used everywhere in this library (gfx950
+// v_mfma_f32_16x16x32_bf16): lane l supplies, for the non-contracted index (l & 15), the 8
+// contraction slots (g = l >> 4, j = 0..7); the hardware pairs slot (g, j) of A with slot (g, j) of B.
+// D: lane l holds D[row = 4 * (l >> 4) + r][col = l & 15], r = 0..3, rows indexed by A's
+// non-contracted index, cols by B's.
+__device__ __forceinline__ f32x4 mfma16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16x16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0,
+                                                     0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16x4_f32(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

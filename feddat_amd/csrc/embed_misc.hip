@@ -1,0 +1,271 @@
+// K8 embeddings (HF ViltEmbeddings.forward restated for full pixel masks, raster patch order; reference call
+// site src/modeling/vilt.py:127) and small element-wise helpers.  All HBM/latency-bound.
+#include "common.hip.h"
+
+namespace {
+
+// one wave per text token: LN(word[id] + type[tt] + pos[s]) + modality[0]
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ ids,
+                                                         const int64_t* __restrict__ tts,
+                                                         const float* __restrict__ word, const float* __restrict__ pos,
+                                                         const float* __restrict__ type, const float* __restrict__ ln_g,
+                                                         const float* __restrict__ ln_b, float eps,
+                                                         const float* __restrict__ mod0, float* __restrict__ h, int B,
+                                                         int Lt, int S, int H) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tok >= B * Lt) return;
+    const int b = tok / Lt, s = tok - b * Lt;
+    const float* w = word + (size_t)ids[tok] * H;
+    const float* ty = type + (size_t)tts[tok] * H;
+    const float* po = pos + (size_t)s * H;
+    const int nc = H >> 2;
+    f32x4 v[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(w + i * 4);
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(ty + i * 4);
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(po + i * 4);
+            v[c] = (a + t4) + p4;
+            sum += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[c][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    float* out = h + ((size_t)b * S + s) * H;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln_g + i * 4);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(ln_b + i * 4);
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mod0 + i * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g4[e] + b4[e] + m4[e];
+            *reinterpret_cast<f32x4*>(out + i * 4) = o;
+        }
+    }
+}
+
+// pixels [B,C,R,R] fp32 -> patches [B*gh*gw, C*P*P] bf16; one thread = 4 consecutive px of one patch row
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ px, bf16* __restrict__ out, int B,
+                                                     int C, int R, int P) {
+    const int gw = R / P;
+    const long total = (long)B * C * R * R / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long e = i * 4;              // linear index into pixels
+    const int x = (int)(e % R);
+    const int y = (int)((e / R) % R);
+    const int c = (int)((e / ((long)R * R)) % C);
+    const int b = (int)(e / ((long)R * R * C));
+    const f32x4 v = *reinterpret_cast<const f32x4*>(px + e);
+    const int py = y / P, iy = y - py * P, pxi = x / P, ix = x - pxi * P;
+    const size_t row = ((size_t)b * gw + py) * gw + pxi;
+    const size_t col = ((size_t)c * P + iy) * P + ix;
+    *reinterpret_cast<bf16x4*>(out + row * ((size_t)C * P * P) + col) = cvt4(v);
+}
+
+__global__ __launch_bounds__(256) void image_assemble_kernel(const float* __restrict__ proj,
+                                                             const float* __restrict__ cls,
+                                                             const float* __restrict__ pos0,
+                                                             const float* __restrict__ pos_img,
+                                                             const float* __restrict__ mod1, float* __restrict__ h,
+                                                             int B, int Lt, int np, int S, int H) {
+    const int nc = H >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * (np + 1) * nc;
+    if (i >= total) return;
+    const int c = (int)(i % nc);
+    const int t = (int)((i / nc) % (np + 1));
+    const int b = (int)(i / ((long)nc * (np + 1)));
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(mod1 + c * 4);
+    f32x4 o;
+    if (t == 0) {
+        o = (*reinterpret_cast<const f32x4*>(cls + c * 4) + *reinterpret_cast<const f32x4*>(pos0 + c * 4)) + m4;
+    } else {
+        const int p = t - 1;
+        o = (*reinterpret_cast<const f32x4*>(proj + ((size_t)b * np + p) * H + c * 4) +
+             *reinterpret_cast<const f32x4*>(pos_img + (size_t)p * H + c * 4)) + m4;
+    }
+    *reinterpret_cast<f32x4*>(h + ((size_t)b * S + Lt + t) * H + c * 4) = o;
+}
+
+// bilinear, align_corners=True: src = dst * (g - 1) / (gdst - 1)
+__global__ __launch_bounds__(256) void pos_resize_kernel(const float* __restrict__ grid, float* __restrict__ out,
+                                                         int g, int gh, int gw, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)gh * gw * H) return;
+    const int c = (int)(i % H);
+    const int x = (int)((i / H) % gw);
+    const int y = (int)(i / ((long)H * gw));
+    // torch area_pixel_compute_scale(align_corners=True): scale = (in - 1) / (out - 1); src = scale * dst
+    const float sy = gh > 1 ? ((float)(g - 1) / (float)(gh - 1)) * (float)y : 0.f;
+    const float sx = gw > 1 ? ((float)(g - 1) / (float)(gw - 1)) * (float)x : 0.f;
+    const int y0 = min((int)sy, g - 1), x0 = min((int)sx, g - 1);
+    const int y1 = min(y0 + 1, g - 1), x1 = min(x0 + 1, g - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float v00 = grid[((size_t)y0 * g + x0) * H + c], v01 = grid[((size_t)y0 * g + x1) * H + c];
+    const float v10 = grid[((size_t)y1 * g + x0) * H + c], v11 = grid[((size_t)y1 * g + x1) * H + c];
+    out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+__global__ __launch_bounds__(256) void cvt_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        *reinterpret_cast<bf16x4*>(out + i) = cvt4(*reinterpret_cast<const f32x4*>(in + i));
+    } else {
+        for (long k = i; k < n; ++k) out[k] = (bf16)in[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_cvt_kernel(const float* __restrict__ in, bf16* __restrict__ out,
+                                                            int R, int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * R + r] = (bf16)tile[tx][k];
+    }
+}
+
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(float* x, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* y, const float* dy, float* dx, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* x, float* y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = gelu_f(x[i]);
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* x, const float* dy, float* dx, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * gelu_grad_f(x[i]);
+}
+
+__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ rows, float* __restrict__ o32,
+                                                          bf16* __restrict__ o16, int B, int S, int H) {
+    const int nc = H >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * S * nc) return;
+    const int c = (int)(i % nc);
+    const long tok = i / nc;
+    const int s = (int)(tok % S);
+    const int b = (int)(tok / S);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s == 0) v = *reinterpret_cast<const f32x4*>(rows + (size_t)b * H + c * 4);
+    if (o32) *reinterpret_cast<f32x4*>(o32 + (size_t)tok * H + c * 4) = v;
+    if (o16) *reinterpret_cast<bf16x4*>(o16 + (size_t)tok * H + c * 4) = cvt4(v);
+}
+
+}  // namespace
+
+extern "C" int feddat_abi_version(void) { return FEDDAT_ABI_VERSION; }
+
+extern "C" int feddat_text_embed(const int64_t* input_ids, const int64_t* token_type_ids, const float* word,
+                                 const float* pos, const float* type, const float* ln_g, const float* ln_b, float eps,
+                                 const float* modality0, float* h, int B, int Lt, int S, int H, hipStream_t stream) {
+    FD_CHECK_ARG(input_ids && token_type_ids && word && pos && type && ln_g && ln_b && modality0 && h);
+    FD_CHECK_ARG(B > 0 && Lt > 0 && S >= Lt && H % 4 == 0 && H <= 2048);
+    hipLaunchKernelGGL(text_embed_kernel, dim3((B * Lt + 3) / 4), dim3(256), 0, stream, input_ids, token_type_ids,
+                       word, pos, type, ln_g, ln_b, eps, modality0, h, B, Lt, S, H);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C, int R, int P,
+                                     hipStream_t stream) {
+    FD_CHECK_ARG(pixels && patches_bf16 && B > 0 && C > 0 && R > 0 && P > 0 && R % P == 0 && P % 4 == 0);
+    const long total = (long)B * C * R * R / 4;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pixels,
+                       (bf16*)patches_bf16, B, C, R, P);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_image_embed_assemble(const float* proj, const float* cls, const float* pos0,
+                                           const float* pos_img, const float* modality1, float* h, int B, int Lt,
+                                           int np, int S, int H, hipStream_t stream) {
+    FD_CHECK_ARG(proj && cls && pos0 && pos_img && modality1 && h && B > 0 && np > 0 && S == Lt + 1 + np);
+    FD_CHECK_ARG(H % 4 == 0);
+    const long total = (long)B * (np + 1) * (H / 4);
+    hipLaunchKernelGGL(image_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, proj, cls,
+                       pos0, pos_img, modality1, h, B, Lt, np, S, H);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_pos_embed_resize(const float* pos_grid, float* out, int g, int gh, int gw, int H,
+                                       hipStream_t stream) {
+    FD_CHECK_ARG(pos_grid && out && g > 0 && gh > 0 && gw > 0 && H > 0);
+    const long total = (long)gh * gw * H;
+    hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pos_grid, out,
+                       g, gh, gw, H);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_cvt_f32_bf16(const float* in, void* out_bf16, long n, hipStream_t stream) {
+    FD_CHECK_ARG(in && out_bf16 && n > 0);
+    hipLaunchKernelGGL(cvt_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, stream, in, (bf16*)out_bf16,
+                       n);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_transpose_f32_bf16(const float* in, void* out_bf16, int R, int C, hipStream_t stream) {
+    FD_CHECK_ARG(in && out_bf16 && R > 0 && C > 0);
+    hipLaunchKernelGGL(transpose_cvt_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, in,
+                       (bf16*)out_bf16, R, C);
+    FD_LAUNCH_RET();
+}
+
+#define FD_EW(name, kern, ...)                                                                                   \
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, __VA_ARGS__);              \
+    FD_LAUNCH_RET();
+
+extern "C" int feddat_tanh_fwd(float* x, long n, hipStream_t stream) {
+    FD_CHECK_ARG(x && n > 0);
+    FD_EW(tanh, tanh_fwd_kernel, x, n)
+}
+extern "C" int feddat_tanh_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream) {
+    FD_CHECK_ARG(y && dy && dx && n > 0);
+    FD_EW(tanhb, tanh_bwd_kernel, y, dy, dx, n)
+}
+extern "C" int feddat_gelu_fwd(const float* x, float* y, long n, hipStream_t stream) {
+    FD_CHECK_ARG(x && y && n > 0);
+    FD_EW(gelu, gelu_fwd_kernel, x, y, n)
+}
+extern "C" int feddat_gelu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t stream) {
+    FD_CHECK_ARG(x && dy && dx && n > 0);
+    FD_EW(gelub, gelu_bwd_kernel, x, dy, dx, n)
+}
+
+extern "C" int feddat_scatter_cls_rows(const float* rows, float* out_f32, void* out_bf16, int B, int S, int H,
+                                       hipStream_t stream) {
+    FD_CHECK_ARG(rows && (out_f32 || out_bf16) && B > 0 && S > 0 && H % 4 == 0);
+    const long n = (long)B * S * (H / 4);
+    hipLaunchKernelGGL(scatter_cls_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rows, out_f32,
+                       (bf16*)out_bf16, B, S, H);
+    FD_LAUNCH_RET();
+}

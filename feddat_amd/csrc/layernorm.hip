@@ -1,0 +1,184 @@
+// K3: LayerNorm forward / dX-only backward (frozen affine) / full backward (trainable affine).
+// One 64-lane wave per row, the row lives in registers (H <= 2048), float4 I/O.  HBM-bound.
+#include "common.hip.h"
+
+namespace {
+
+// MAXC = float4 chunks per lane (H <= 256 * MAXC); instantiated for 3 (H=768), 6 (H=1536), 8 (H<=2048)
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long x_stride,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, int rows, int H, bf16* __restrict__ y16,
+                                                     float* __restrict__ y32, float* __restrict__ stats) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nc = H >> 2;
+    const float* xr = x + (size_t)row * x_stride;
+    f32x4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            v[c] = *reinterpret_cast<const f32x4*>(xr + i * 4);
+            s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[c][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    if (stats && lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + i * 4);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + i * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g4[e] + b4[e];
+            if (y16) *reinterpret_cast<bf16x4*>(y16 + (size_t)row * H + i * 4) = cvt4(o);
+            if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * H + i * 4) = o;
+        }
+    }
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__ dy16, const float* __restrict__ dy32,
+                                                        long dy_stride, const float* __restrict__ x, long x_stride,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                        long dres_stride, int rows, int H, float* __restrict__ out32,
+                                                        long out_stride, bf16* __restrict__ out16) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nc = H >> 2;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    f32x4 xh[MAXC], gg[MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * x_stride + i * 4);
+            f32x4 d;
+            if (dy16) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(dy16 + (size_t)row * dy_stride + i * 4);
+                d = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            } else {
+                d = *reinterpret_cast<const f32x4*>(dy32 + (size_t)row * dy_stride + i * 4);
+            }
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[c][e] = (xv[e] - mean) * rstd;
+                gg[c][e] = d[e] * g4[e];
+                s1 += gg[c][e];
+                s2 += gg[c][e] * xh[c][e];
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)H;
+    const float m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[c][e] - m1 - xh[c][e] * m2);
+            if (dres) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(dres + (size_t)row * dres_stride + i * 4);
+                o = o + r4;
+            }
+            if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)row * out_stride + i * 4) = o;
+            if (out16) *reinterpret_cast<bf16x4*>(out16 + (size_t)row * H + i * 4) = cvt4(o);
+        }
+    }
+}
+
+// trainable-affine backward for the task head's clf_norm0 (rows <= 1024): one block per 64 columns,
+// lanes over columns for dgamma/dbeta; dx by the wave-per-row kernel above with fp32 dy.
+__global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stats, int rows, int H,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    float ag = 0.f, ab = 0.f;
+    if (col < H) {
+        for (int r = part; r < rows; r += 4) {
+            const float d = dy[(size_t)r * H + col];
+            const float xh = (x[(size_t)r * H + col] - stats[2 * r]) * stats[2 * r + 1];
+            ag += d * xh;
+            ab += d;
+        }
+    }
+    sg[part][threadIdx.x & 63] = ag;
+    sb[part][threadIdx.x & 63] = ab;
+    __syncthreads();
+    if (part == 0 && col < H) {
+        const int l = threadIdx.x;
+        dgamma[col] = (sg[0][l] + sg[1][l]) + (sg[2][l] + sg[3][l]);
+        dbeta[col] = (sb[0][l] + sb[1][l]) + (sb[2][l] + sb[3][l]);
+    }
+}
+
+}  // namespace
+
+extern "C" int feddat_layernorm_fwd(const float* x, long x_stride, const float* gamma, const float* beta, float eps,
+                                    int rows, int H, void* y_bf16, float* y_f32, float* stats, hipStream_t stream) {
+    FD_CHECK_ARG(x && gamma && beta && rows > 0 && H > 0 && H % 4 == 0 && H <= 2048 && x_stride % 4 == 0);
+    FD_CHECK_ARG(y_bf16 || y_f32);
+#define LN_FWD(MC)                                                                                              \
+    hipLaunchKernelGGL(ln_fwd_kernel<MC>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, x_stride, gamma, beta, eps, \
+                       rows, H, (bf16*)y_bf16, y_f32, stats)
+    if (H <= 768) LN_FWD(3); else if (H <= 1536) LN_FWD(6); else LN_FWD(8);
+#undef LN_FWD
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_layernorm_bwd_dx(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x,
+                                       long x_stride, const float* stats, const float* gamma, const float* dres,
+                                       long dres_stride, int rows, int H, float* out_f32, long out_stride,
+                                       void* out_bf16, hipStream_t stream) {
+    FD_CHECK_ARG((dy_bf16 != nullptr) != (dy_f32 != nullptr));
+    FD_CHECK_ARG(x && stats && gamma && rows > 0 && H > 0 && H % 4 == 0 && H <= 2048);
+    FD_CHECK_ARG(dy_stride % 4 == 0 && x_stride % 4 == 0 && (!dres || dres_stride % 4 == 0));
+    FD_CHECK_ARG((out_f32 && out_stride % 4 == 0) || out_bf16);
+#define LN_BWD(MC)                                                                                                \
+    hipLaunchKernelGGL(ln_bwd_dx_kernel<MC>, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)dy_bf16, dy_f32, \
+                       dy_stride, x, x_stride, stats, gamma, dres, dres_stride, rows, H, out_f32, out_stride,          \
+                       (bf16*)out_bf16)
+    if (H <= 768) LN_BWD(3); else if (H <= 1536) LN_BWD(6); else LN_BWD(8);
+#undef LN_BWD
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_layernorm_bwd_full(const float* dy, const float* x, const float* stats, const float* gamma,
+                                         int rows, int H, float* dx, float* dgamma, float* dbeta,
+                                         hipStream_t stream) {
+    FD_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta && rows > 0 && rows <= 1024);
+    FD_CHECK_ARG(H > 0 && H % 4 == 0 && H <= 2048);
+    hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, dy, x, stats, rows, H, dgamma,
+                       dbeta);
+    return feddat_layernorm_bwd_dx(nullptr, dy, (long)H, x, (long)H, stats, gamma, nullptr, 0L, rows, H, dx, (long)H,
+                                   nullptr, stream);
+}

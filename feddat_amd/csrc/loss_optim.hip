@@ -1,0 +1,158 @@
+// K5 (DAT loss forward + dlogits), K6 (flat multi-tensor AdamW + device-side LR schedule), K7 (FedAvg
+// accumulate).  All fp32, HBM/latency-bound, tiny.
+#include "common.hip.h"
+
+namespace {
+
+// One wave per sample row.  L = (mean_bce * C + T^2 * KL_batchmean) / 2
+// (src/train/visionlanguage_tasks/task_trainer.py:299-301, 506-516).
+__global__ __launch_bounds__(64) void dat_loss_kernel(const float* __restrict__ logits,
+                                                      const float* __restrict__ teacher,
+                                                      const float* __restrict__ target, int B, int C, float temp,
+                                                      float* __restrict__ dlogits, float* __restrict__ row_terms) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* x = logits + (size_t)b * C;
+    const float* t = teacher + (size_t)b * C;
+    const float* y = target + (size_t)b * C;
+    const float it = 1.0f / temp;
+    float mx = -INFINITY, mt = -INFINITY;
+    for (int j = lane; j < C; j += 64) {
+        mx = fmaxf(mx, x[j] * it);
+        mt = fmaxf(mt, t[j] * it);
+    }
+    mx = wave_max(mx);
+    mt = wave_max(mt);
+    float sx = 0.f, st = 0.f;
+    for (int j = lane; j < C; j += 64) {
+        sx += expf(x[j] * it - mx);
+        st += expf(t[j] * it - mt);
+    }
+    sx = wave_sum(sx);
+    st = wave_sum(st);
+    const float lsx = mx + logf(sx), lst = mt + logf(st);
+    float bce = 0.f, kl = 0.f;
+    for (int j = lane; j < C; j += 64) {
+        const float xv = x[j];
+        // BCEWithLogits: max(x,0) - x*y + log(1 + exp(-|x|))
+        bce += fmaxf(xv, 0.f) - xv * y[j] + log1pf(expf(-fabsf(xv)));
+        const float logp = xv * it - lsx;
+        const float logq = t[j] * it - lst;
+        const float q = expf(logq);
+        kl += q * (logq - logp);
+        const float sig = 1.0f / (1.0f + expf(-xv));
+        dlogits[(size_t)b * C + j] = 0.5f / (float)B * ((sig - y[j]) + temp * (expf(logp) - q));
+    }
+    bce = wave_sum(bce);
+    kl = wave_sum(kl);
+    if (lane == 0) {
+        row_terms[2 * b] = bce;
+        row_terms[2 * b + 1] = kl;
+    }
+}
+
+__global__ __launch_bounds__(64) void dat_loss_finish(const float* __restrict__ row_terms, int B, float temp,
+                                                      float* __restrict__ scalars) {
+    float bce = 0.f, kl = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        bce += row_terms[2 * b];
+        kl += row_terms[2 * b + 1];
+    }
+    bce = wave_sum(bce);
+    kl = wave_sum(kl);
+    if (threadIdx.x == 0) {
+        const float l_bce = bce / (float)B;               // mean over B*C, times C
+        const float l_kl = kl / (float)B * temp * temp;   // batchmean * T^2
+        scalars[0] = l_bce;
+        scalars[1] = l_kl;
+        scalars[2] = 0.5f * (l_bce + l_kl);
+    }
+}
+
+// HF get_polynomial_decay_schedule_with_warmup(lr_end=0, power=1) multiplier (task_trainer.py:53-59).
+__device__ __forceinline__ float poly_lambda(int t, int warmup, int total) {
+    if (t < warmup) return (float)t / (float)max(1, warmup);
+    if (t > total) return 0.f;
+    return 1.0f - (float)(t - warmup) / (float)(total - warmup);
+}
+
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, long n,
+                                                         const long* __restrict__ seg_off,
+                                                         const float* __restrict__ seg_wd, int nseg,
+                                                         const int* __restrict__ state, float base_lr, int warmup,
+                                                         int total, float beta1, float beta2, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int sched_t = state[0];
+    const int t = state[1] + 1;
+    const float lr = base_lr * poly_lambda(sched_t, warmup, total);
+    // per-tensor weight decay: binary search of the segment table
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const float wd = seg_wd[lo];
+    const float bc1 = 1.0f - powf(beta1, (float)t);
+    const float bc2 = 1.0f - powf(beta2, (float)t);
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);   // lerp_(grad, 1 - beta1)
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+}
+
+__global__ void step_tick_kernel(int* state, int d_sched, int d_adam) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        state[0] += d_sched;
+        state[1] += d_adam;
+    }
+}
+
+__global__ __launch_bounds__(256) void fedavg_acc_kernel(float* __restrict__ acc, const float* __restrict__ x, long n,
+                                                         float num, float total, int first) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float term = x[i] * num / total;   // main.py:62: net[key] * num / total_num_train
+    acc[i] = first ? (0.0f + term) : (acc[i] + term);
+}
+
+}  // namespace
+
+extern "C" int feddat_dat_loss_fwd_bwd(const float* logits, const float* teacher, const float* target, int B, int C,
+                                       float temp, float* dlogits, float* scalars, hipStream_t stream) {
+    FD_CHECK_ARG(logits && teacher && target && dlogits && scalars && B > 0 && B <= 4096 && C > 0 && temp > 0.f);
+    // row_terms live behind the 3 scalars: scalars must hold 4 + 2*B floats
+    float* row_terms = scalars + 4;
+    hipLaunchKernelGGL(dat_loss_kernel, dim3(B), dim3(64), 0, stream, logits, teacher, target, B, C, temp, dlogits,
+                       row_terms);
+    hipLaunchKernelGGL(dat_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, B, temp, scalars);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adamw_flat(float* p, const float* g, float* m, float* v, long n, const long* seg_off,
+                                 const float* seg_wd, int nseg, const int* state, float base_lr, int warmup, int total,
+                                 float beta1, float beta2, float eps, hipStream_t stream) {
+    FD_CHECK_ARG(p && g && m && v && n > 0 && seg_off && seg_wd && nseg > 0 && state && total > warmup);
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n,
+                       seg_off, seg_wd, nseg, state, base_lr, warmup, total, beta1, beta2, eps);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_step_tick(int* state, int d_sched, int d_adam, hipStream_t stream) {
+    FD_CHECK_ARG(state);
+    hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, stream, state, d_sched, d_adam);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_fedavg_accumulate(float* acc, const float* x, long n, float num, float total, int first,
+                                        hipStream_t stream) {
+    FD_CHECK_ARG(acc && x && n > 0 && total > 0.f);
+    hipLaunchKernelGGL(fedavg_acc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc, x, n, num,
+                       total, first);
+    FD_LAUNCH_RET();
+}

@@ -1,0 +1,296 @@
+"""ctypes binding of libfeddat_hip.so (include/feddat_hip.h).
+
+The HIP library is THE product path: if it cannot be loaded this module raises -- there is no eager /
+PyTorch / CPU fallback anywhere in feddat_amd.  torch is used only as plumbing: device allocations
+(tensor.data_ptr()), the current HIP stream, and torch.distributed for the one RCCL all-reduce per round.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch  # imported first on purpose: libfeddat_hip.so must bind to the HIP runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfeddat_hip.so")
+
+EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class AdapterSeg(C.Structure):
+    _fields_ = [("row_begin", i32), ("row_end", i32), ("n_adapters", i32), ("train_slot", i32),
+                ("scale", f32 * 2), ("wd", vp * 2), ("wdT", vp * 2), ("wu", vp * 2), ("wuT", vp * 2),
+                ("bd", vp * 2), ("bu", vp * 2)]
+
+
+_SIGS = {
+    "feddat_abi_version": [],
+    "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
+    "feddat_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "feddat_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "feddat_layernorm_fwd": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp],
+    "feddat_layernorm_bwd_dx": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp],
+    "feddat_layernorm_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
+    "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
+    "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
+    "feddat_adapter_pack": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, vp],
+    "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
+    "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
+    "feddat_adamw_flat": [vp, vp, vp, vp, i64, vp, vp, i32, vp, f32, i32, i32, f32, f32, f32, vp],
+    "feddat_step_tick": [vp, i32, i32, vp],
+    "feddat_text_embed": [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, vp],
+    "feddat_im2col_patches": [vp, vp, i32, i32, i32, i32, vp],
+    "feddat_image_embed_assemble": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "feddat_pos_embed_resize": [vp, vp, i32, i32, i32, i32, vp],
+    "feddat_cvt_f32_bf16": [vp, vp, i64, vp],
+    "feddat_transpose_f32_bf16": [vp, vp, i32, i32, vp],
+    "feddat_tanh_fwd": [vp, i64, vp],
+    "feddat_tanh_bwd": [vp, vp, vp, i64, vp],
+    "feddat_gelu_fwd": [vp, vp, i64, vp],
+    "feddat_gelu_bwd": [vp, vp, vp, i64, vp],
+    "feddat_scatter_cls_rows": [vp, vp, vp, i32, i32, i32, vp],
+    "feddat_fedavg_accumulate": [vp, vp, i64, f32, f32, i32, vp],
+    "feddat_probe_tr16": [vp, vp, vp],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+
+class FeddatHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libfeddat_hip.so; raise loudly if it is missing (build it with `python -m feddat_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FeddatHipError(
+            f"{LIB_PATH} not found: the HIP library is the only implementation of this path "
+            "(no CPU/PyTorch fallback). Build it with `python __graft_entry__.py` or `python -m feddat_amd.build`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    if lib.feddat_abi_version() != 1:
+        raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise FeddatHipError(f"{what} failed with code {rc} ({'EINVAL' if rc == 1 else 'ELAUNCH'})")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise FeddatHipError("feddat_amd ops need device (HIP) tensors; there is no CPU path")
+
+
+# ---------------------------------------------------------------------------------------------------
+# thin typed wrappers (tensors in, tensors out; no arithmetic happens on the Python side)
+# ---------------------------------------------------------------------------------------------------
+def gemm_bf16_nt(A, B, epi, *, bias=None, resid=None, aux=None, out_f32=None, out_bf16=None, out2_bf16=None,
+                 M=None):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+ epilogue).  A, B bf16 2-D (row stride taken from the tensors)."""
+    _dev(A, B)
+    M = A.shape[0] if M is None else M
+    K = A.shape[1]
+    N = B.shape[0]
+
+    def ld(t):
+        return 0 if t is None else t.stride(0)
+    rc = load().feddat_gemm_bf16_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, epi, _p(bias), _p(resid),
+                                    ld(resid), _p(aux), ld(aux), _p(out_f32), ld(out_f32), _p(out_bf16),
+                                    ld(out_bf16), _p(out2_bf16), ld(out2_bf16), _stream())
+    _chk(rc, "feddat_gemm_bf16_nt")
+
+
+def attn_fwd(qkv, ctx, lse, B, S, heads, key_mask=None):
+    _dev(qkv, ctx)
+    _chk(load().feddat_attn_fwd(_p(qkv), _p(key_mask), _p(ctx), _p(lse), B, S, heads, _stream()), "feddat_attn_fwd")
+
+
+def attn_bwd(qkv, ctx, lse, dctx, dqkv, B, S, heads, key_mask=None):
+    _dev(qkv, ctx, dctx, dqkv)
+    _chk(load().feddat_attn_bwd(_p(qkv), _p(key_mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), B, S, heads, _stream()),
+         "feddat_attn_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, eps, rows, H, *, x_stride=None, y_bf16=None, y_f32=None, stats=None):
+    _dev(x)
+    _chk(load().feddat_layernorm_fwd(_p(x), H if x_stride is None else x_stride, _p(gamma), _p(beta), eps, rows, H,
+                                     _p(y_bf16), _p(y_f32), _p(stats), _stream()), "feddat_layernorm_fwd")
+
+
+def layernorm_bwd_dx(x, stats, gamma, rows, H, *, dy_bf16=None, dy_f32=None, dy_stride=None, x_stride=None,
+                     dres=None, dres_stride=None, out_f32=None, out_stride=None, out_bf16=None):
+    _dev(x)
+    _chk(load().feddat_layernorm_bwd_dx(_p(dy_bf16), _p(dy_f32), H if dy_stride is None else dy_stride, _p(x),
+                                        H if x_stride is None else x_stride, _p(stats), _p(gamma), _p(dres),
+                                        H if dres_stride is None else dres_stride, rows, H, _p(out_f32),
+                                        H if out_stride is None else out_stride, _p(out_bf16), _stream()),
+         "feddat_layernorm_bwd_dx")
+
+
+def layernorm_bwd_full(dy, x, stats, gamma, rows, H, dx, dgamma, dbeta):
+    _dev(dy, x)
+    _chk(load().feddat_layernorm_bwd_full(_p(dy), _p(x), _p(stats), _p(gamma), rows, H, _p(dx), _p(dgamma),
+                                          _p(dbeta), _stream()), "feddat_layernorm_bwd_full")
+
+
+def make_segs(segs: Sequence[dict]):
+    arr = (AdapterSeg * len(segs))()
+    for s, d in zip(arr, segs):
+        s.row_begin, s.row_end = d["row_begin"], d["row_end"]
+        ads = d["adapters"]  # list of dicts with wd, wdT, wu, wuT (bf16), bd, bu (fp32), scale
+        s.n_adapters = len(ads)
+        s.train_slot = d.get("train_slot", -1)
+        for a, ad in enumerate(ads):
+            s.scale[a] = ad["scale"]
+            s.wd[a] = ad["wd"].data_ptr()
+            s.wu[a] = ad["wu"].data_ptr()
+            s.wdT[a] = ad["wdT"].data_ptr() if ad.get("wdT") is not None else None
+            s.wuT[a] = ad["wuT"].data_ptr() if ad.get("wuT") is not None else None
+            s.bd[a] = ad["bd"].data_ptr()
+            s.bu[a] = ad["bu"].data_ptr()
+    return arr
+
+
+def adapter_fwd(x, out, segs_arr, T, H=768, r=48):
+    _dev(x, out)
+    _chk(load().feddat_adapter_fwd(_p(x), _p(out), T, H, r, segs_arr, len(segs_arr), _stream()), "feddat_adapter_fwd")
+
+
+def adapter_bwd(x, dy, dx, segs_arr, T, *, dx_bf16=None, z_out=None, dz_out=None, H=768, r=48):
+    _dev(x, dy, dx)
+    _chk(load().feddat_adapter_bwd(_p(x), _p(dy), _p(dx), _p(dx_bf16), _p(z_out), _p(dz_out), T, H, r, segs_arr,
+                                   len(segs_arr), _stream()), "feddat_adapter_bwd")
+
+
+def adapter_pack(wd, wu, wd16, wdT16, wu16, wuT16, H=768, r=48):
+    _dev(wd, wu)
+    _chk(load().feddat_adapter_pack(_p(wd), _p(wu), _p(wd16), _p(wdT16), _p(wu16), _p(wuT16), H, r, _stream()),
+         "feddat_adapter_pack")
+
+
+def sgemm_f32(A, sa_i, sa_k, B, sb_k, sb_j, I, J, K, out, *, ldo=None, ksplit=1, alpha=1.0, bias_j=None,
+              out_split_stride=0, colsum=None):
+    _dev(A, B, out)
+    _chk(load().feddat_sgemm_f32(_p(A), sa_i, sa_k, _p(B), sb_k, sb_j, I, J, K, ksplit, alpha, _p(bias_j), _p(out),
+                                 J if ldo is None else ldo, out_split_stride, _p(colsum), _stream()),
+         "feddat_sgemm_f32")
+
+
+def reduce_partials(inp, stride, nsplit, n, out):
+    _dev(inp, out)
+    _chk(load().feddat_reduce_partials(_p(inp), stride, nsplit, n, _p(out), _stream()), "feddat_reduce_partials")
+
+
+def dat_loss_fwd_bwd(logits, teacher, target, dlogits, scalars, temp=3.0):
+    _dev(logits, teacher, target)
+    B, Cn = logits.shape
+    assert scalars.numel() >= 4 + 2 * B
+    _chk(load().feddat_dat_loss_fwd_bwd(_p(logits), _p(teacher), _p(target), B, Cn, temp, _p(dlogits), _p(scalars),
+                                        _stream()), "feddat_dat_loss_fwd_bwd")
+
+
+def adamw_flat(p, g, m, v, seg_off, seg_wd, state, base_lr, warmup, total, beta1=0.9, beta2=0.98, eps=1e-8):
+    _dev(p, g, m, v)
+    _chk(load().feddat_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_off), _p(seg_wd), seg_wd.numel(),
+                                  _p(state), base_lr, warmup, total, beta1, beta2, eps, _stream()),
+         "feddat_adamw_flat")
+
+
+def step_tick(state, d_sched, d_adam):
+    _chk(load().feddat_step_tick(_p(state), d_sched, d_adam, _stream()), "feddat_step_tick")
+
+
+def text_embed(ids, tts, word, pos, typ, ln_g, ln_b, eps, mod0, h, B, Lt, S, H):
+    _dev(ids, h)
+    _chk(load().feddat_text_embed(_p(ids), _p(tts), _p(word), _p(pos), _p(typ), _p(ln_g), _p(ln_b), eps, _p(mod0),
+                                  _p(h), B, Lt, S, H, _stream()), "feddat_text_embed")
+
+
+def im2col_patches(pixels, patches, B, Cc, R, P):
+    _dev(pixels, patches)
+    _chk(load().feddat_im2col_patches(_p(pixels), _p(patches), B, Cc, R, P, _stream()), "feddat_im2col_patches")
+
+
+def image_embed_assemble(proj, cls, pos0, pos_img, mod1, h, B, Lt, npatch, S, H):
+    _dev(proj, h)
+    _chk(load().feddat_image_embed_assemble(_p(proj), _p(cls), _p(pos0), _p(pos_img), _p(mod1), _p(h), B, Lt, npatch,
+                                            S, H, _stream()), "feddat_image_embed_assemble")
+
+
+def pos_embed_resize(grid, out, g, gh, gw, H):
+    _dev(grid, out)
+    _chk(load().feddat_pos_embed_resize(_p(grid), _p(out), g, gh, gw, H, _stream()), "feddat_pos_embed_resize")
+
+
+def cvt_f32_bf16(x, out):
+    _dev(x, out)
+    _chk(load().feddat_cvt_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "feddat_cvt_f32_bf16")
+
+
+def transpose_f32_bf16(x, out, R, Cc):
+    _dev(x, out)
+    _chk(load().feddat_transpose_f32_bf16(_p(x), _p(out), R, Cc, _stream()), "feddat_transpose_f32_bf16")
+
+
+def tanh_fwd(x):
+    _dev(x)
+    _chk(load().feddat_tanh_fwd(_p(x), x.numel(), _stream()), "feddat_tanh_fwd")
+
+
+def tanh_bwd(y, dy, dx):
+    _dev(y, dy, dx)
+    _chk(load().feddat_tanh_bwd(_p(y), _p(dy), _p(dx), y.numel(), _stream()), "feddat_tanh_bwd")
+
+
+def gelu_fwd(x, y):
+    _dev(x, y)
+    _chk(load().feddat_gelu_fwd(_p(x), _p(y), x.numel(), _stream()), "feddat_gelu_fwd")
+
+
+def gelu_bwd(x, dy, dx):
+    _dev(x, dy, dx)
+    _chk(load().feddat_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "feddat_gelu_bwd")
+
+
+def scatter_cls_rows(rows, out_f32, out_bf16, B, S, H):
+    _dev(rows)
+    _chk(load().feddat_scatter_cls_rows(_p(rows), _p(out_f32), _p(out_bf16), B, S, H, _stream()),
+         "feddat_scatter_cls_rows")
+
+
+def fedavg_accumulate(acc, x, num, total, first):
+    _dev(acc, x)
+    _chk(load().feddat_fedavg_accumulate(_p(acc), _p(x), acc.numel(), float(num), float(total), int(first),
+                                         _stream()), "feddat_fedavg_accumulate")
+
+
+def probe_tr16(inp, out):
+    _dev(inp, out)
+    _chk(load().feddat_probe_tr16(_p(inp), _p(out), _stream()), "feddat_probe_tr16")

@@ -1,0 +1,195 @@
+/* libfeddat_hip.so -- C ABI of the MI355X-native FedDAT hot path (gfx950 only).
+ *
+ * The reference (HaokunChen245/FedDAT) has no FFI: its boundary for this path is the Python module API
+ * (SURVEY.md section 8b).  These entry points are what a binding for that API calls; each one cites the
+ * reference code whose arithmetic it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; the library never allocates or frees;
+ *   - all launches are asynchronous on `stream`; functions are re-entrant per stream, no global state;
+ *   - return value: FEDDAT_OK (0), FEDDAT_EINVAL (bad shape / alignment / null), FEDDAT_ELAUNCH (HIP launch error);
+ *   - "bf16" buffers are passed as void* (raw bfloat16, 2 bytes per element); fp32 as float*;
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
+ */
+#ifndef FEDDAT_HIP_H
+#define FEDDAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define FEDDAT_OK 0
+#define FEDDAT_EINVAL 1
+#define FEDDAT_ELAUNCH 2
+
+#define FEDDAT_ABI_VERSION 1
+int feddat_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  bf16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T  (+ fused epilogue)
+ * Replaces the frozen nn.Linear calls inside HF ViltLayer (reference call site src/modeling/vilt.py:127;
+ * FFN-out dense+residual: src/modeling/adaptered_output.py:74-76) and, with B = W^T, their dX-only
+ * backward (autograd through frozen weights, src/train/visionlanguage_tasks/task_trainer.py:302,323).
+ * Requirements: N % 128 == 0, K % 64 == 0, lda/ldb % 8 == 0.
+ * ------------------------------------------------------------------------------------------- */
+#define FEDDAT_EPI_BF16 0       /* out_bf16 = acc + bias                                    */
+#define FEDDAT_EPI_RESID_F32 1  /* out_f32  = acc + bias + resid(fp32)                      */
+#define FEDDAT_EPI_GELU 2       /* out2_bf16 = u = acc + bias (optional); out_bf16 = gelu(u) */
+#define FEDDAT_EPI_MUL_DGELU 3  /* out_bf16 = (acc) * gelu'(aux_bf16)                        */
+#define FEDDAT_EPI_F32 4        /* out_f32  = acc + bias                                    */
+int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
+                        const float* bias, const float* resid, int ldr, const void* aux, int ldaux, float* out_f32,
+                        int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  fused self-attention for one ViLT layer (HF ViltSelfAttention: softmax(QK^T/8 + mask) V).
+ * qkv: bf16 [B*S, 3*H] rows = tokens, columns = [Q | K | V], head h at columns h*64.. of each part.
+ * key_mask: optional uint8 [B,S] (1 = attend, 0 = masked; text padding, vilt.py:98) or NULL.
+ * ctx: bf16 [B*S, H]; lse: fp32 [B, heads, S] (log-sum-exp of the scaled scores, saved for backward).
+ * Requirements: head_dim == 64, S <= 256.
+ * ------------------------------------------------------------------------------------------- */
+int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
+                    hipStream_t stream);
+/* dX-only backward: dqkv (bf16 [B*S, 3*H]) from dctx (bf16 [B*S,H]), qkv, ctx, lse. */
+int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* dctx,
+                    void* dqkv, int B, int S, int heads, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  LayerNorm over the last dim (H <= 2048, H % 4 == 0), fp32 in.
+ * fwd: y = (x - mean) * rstd * gamma + beta; x row r at x + r * x_stride (elements); writes y as bf16
+ *      (y_bf16, ld = H) and/or fp32 (y_f32, ld = H); stats[2*r] = mean, stats[2*r+1] = rstd (optional).
+ * bwd (frozen gamma: dX only): dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)),
+ *      out_f32[r] = dx + (dres ? dres[r] : 0); optional bf16 copy.  dy is bf16 or fp32 (one non-null).
+ * Replaces nn.LayerNorm(768, eps=1e-12) in HF ViltLayer / ViltModel.layernorm (vilt.py:127).
+ * ------------------------------------------------------------------------------------------- */
+int feddat_layernorm_fwd(const float* x, long x_stride, const float* gamma, const float* beta, float eps, int rows,
+                         int H, void* y_bf16, float* y_f32, float* stats, hipStream_t stream);
+int feddat_layernorm_bwd_dx(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x, long x_stride,
+                            const float* stats, const float* gamma, const float* dres, long dres_stride, int rows,
+                            int H, float* out_f32, long out_stride, void* out_bf16, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  fused dual Pfeiffer adapter (the DAT module), src/modeling/models/adapter.py:124-163.
+ * One launch handles up to two row segments of x (fp32 [T,768]); segment s covers rows
+ * [row_begin, row_end) and applies n_adapters (1 = adapter.py:125-131, 2 = gating 133-146):
+ *     out = x + sum_a scale[a] * (W_up[a] * relu(W_down[a] * x + b_down[a]) + b_up[a])
+ * Weights are bf16 copies of the fp32 masters (feddat_adapter_pack): wd [r,H], wu [H,r] (+ the
+ * transposed copies wdT [H,r], wuT [r,H] for the backward); biases fp32.  H = 768, r = 48.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int row_begin, row_end;
+    int n_adapters;   /* 1 or 2 */
+    int train_slot;   /* backward: which adapter slot (0/1) gets weight grads, -1 = none */
+    float scale[2];
+    const void* wd[2];   /* bf16 [r,H]  */
+    const void* wdT[2];  /* bf16 [H,r]  (backward) */
+    const void* wu[2];   /* bf16 [H,r]  */
+    const void* wuT[2];  /* bf16 [r,H]  (backward) */
+    const float* bd[2];  /* fp32 [r]    */
+    const float* bu[2];  /* fp32 [H]    */
+} feddat_adapter_seg;
+
+int feddat_adapter_fwd(const float* x, float* out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg,
+                       hipStream_t stream);
+/* backward: dx = dy + sum_a W_down[a]^T (relu' .* (scale[a] * W_up[a]^T dy)); optional bf16 copy of dx.
+ * For the segment's train_slot the kernel also writes z = relu(.) and dz (fp32 [T,r] each, rows of that
+ * segment) that feddat_sgemm_f32 turns into dW_up = dy^T (scale*z), dW_down = dz^T x. */
+int feddat_adapter_bwd(const float* x, const float* dy, float* dx, void* dx_bf16, float* z_out, float* dz_out, int T,
+                       int H, int r, const feddat_adapter_seg* segs, int nseg, hipStream_t stream);
+/* fp32 master [wd(r*H), bd(r), wu(H*r), bu(H)] -> bf16 wd, wdT, wu, wuT. */
+int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* wdT_bf16, void* wu_bf16,
+                        void* wuT_bf16, int H, int r, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 with arbitrary strides and split-K partial sums:
+ *   for split s: D_s[i][j] = alpha * sum_{k in chunk s} A[i*sa_i + k*sa_k] * B[k*sb_k + j*sb_j]
+ *   out[s*out_split_stride + i*ldo + j] = D_s[i][j] (+ bias_j[j] if s == 0 and bias_j) .
+ * Used for the task head (vilt.py:202-209) forward/backward, the ViLT pooler, and the adapter
+ * weight gradients (contraction over tokens).  colsum: optional fp32 [ksplit, I] receiving
+ * alpha * sum_k A[i][k] for the i-tiles (used for bias gradients), or NULL.
+ * ------------------------------------------------------------------------------------------- */
+int feddat_sgemm_f32(const float* A, long sa_i, long sa_k, const float* B, long sb_k, long sb_j, int I, int J, int K,
+                     int ksplit, float alpha, const float* bias_j, float* out, long ldo, long out_split_stride,
+                     float* colsum, hipStream_t stream);
+/* out[i] = sum_s in[s*stride + i], i < n   (deterministic reduction of split-K partials). */
+int feddat_reduce_partials(const float* in, long stride, int nsplit, long n, float* out, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  loss.  L = (BCEWithLogits_mean(logits,target) * C + 9 * KL_batchmean(log_softmax(logits/3) ||
+ * softmax(teacher/3))) / 2   (task_trainer.py:299-301,506-516; train_vqa_crossvqa.py:237).
+ * logits/teacher/target: fp32 [B,C] (C <= 1024); dlogits: fp32 [B,C] = dL/dlogits;
+ * scalars: fp32 device buffer of at least 4 + 2*B floats; scalars[0..2] = {bce*C, kl, L}, the rest is scratch.
+ * ------------------------------------------------------------------------------------------- */
+int feddat_dat_loss_fwd_bwd(const float* logits, const float* teacher, const float* target, int B, int C, float temp,
+                            float* dlogits, float* scalars, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6  fused multi-tensor AdamW over one flat fp32 parameter buffer (torch.optim.AdamW semantics,
+ * task_trainer.py:477-504) with the HF polynomial-decay-with-warmup multiplier evaluated on device
+ * (task_trainer.py:53-59).  state (device, int32[2]) = {sched_t, adam_t}: lr = base_lr * lambda(sched_t);
+ * bias corrections use adam_t + 1.  The kernel does not modify state; feddat_step_tick does.
+ * seg_off (device int64 [nseg+1]) / seg_wd (device fp32 [nseg]) give per-tensor weight decay.
+ * ------------------------------------------------------------------------------------------- */
+int feddat_adamw_flat(float* p, const float* g, float* m, float* v, long n, const long* seg_off, const float* seg_wd,
+                      int nseg, const int* state, float base_lr, int warmup, int total, float beta1, float beta2,
+                      float eps, hipStream_t stream);
+int feddat_step_tick(int* state, int d_sched, int d_adam, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  embeddings (HF ViltEmbeddings.forward for full pixel masks, raster patch order).
+ * ------------------------------------------------------------------------------------------- */
+/* text rows: h[b, s, :] = LN(word[ids] + type[tt] + pos[s]) + modality[0];  h is fp32 [B, S, H], s < Lt */
+int feddat_text_embed(const int64_t* input_ids, const int64_t* token_type_ids, const float* word, const float* pos,
+                      const float* type, const float* ln_g, const float* ln_b, float eps, const float* modality0,
+                      float* h, int B, int Lt, int S, int H, hipStream_t stream);
+/* pixels fp32 [B,3,R,R] -> bf16 patches [B*gh*gw, 3*P*P] (k = c*P*P + py*P + px, Conv2d weight order) */
+int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C, int R, int P, hipStream_t stream);
+/* image rows: h[b, Lt, :] = cls + pos[0] + modality[1]; h[b, Lt+1+p, :] = proj[b*np+p] + pos_img[p] + modality[1] */
+int feddat_image_embed_assemble(const float* proj, const float* cls, const float* pos0, const float* pos_img,
+                                const float* modality1, float* h, int B, int Lt, int np, int S, int H,
+                                hipStream_t stream);
+/* bilinear(align_corners=True) resize of the [g,g,H] position grid to [gh,gw,H] (HF visual_embed) */
+int feddat_pos_embed_resize(const float* pos_grid, float* out, int g, int gh, int gw, int H, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * misc element-wise helpers
+ * ------------------------------------------------------------------------------------------- */
+int feddat_cvt_f32_bf16(const float* in, void* out_bf16, long n, hipStream_t stream);
+/* in fp32 [R,C] -> out bf16 [C,R] */
+int feddat_transpose_f32_bf16(const float* in, void* out_bf16, int R, int C, hipStream_t stream);
+/* y = tanh(x) in place (fwd), dx = dy * (1 - y^2) (bwd) -- ViltPooler activation */
+int feddat_tanh_fwd(float* x, long n, hipStream_t stream);
+int feddat_tanh_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream);
+/* y = gelu(x); dx = dy * gelu'(x) -- task head clf_actv0 (vilt.py:206) */
+int feddat_gelu_fwd(const float* x, float* y, long n, hipStream_t stream);
+int feddat_gelu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t stream);
+/* LayerNorm backward WITH affine gradients (task head clf_norm0, trainable): rows <= 1024 */
+int feddat_layernorm_bwd_full(const float* dy, const float* x, const float* stats, const float* gamma, int rows, int H,
+                              float* dx, float* dgamma, float* dbeta, hipStream_t stream);
+/* scatter B rows into a zero-filled [B*S, H] fp32 buffer at token 0 of each sample (+ bf16 copy) */
+int feddat_scatter_cls_rows(const float* rows, float* out_f32, void* out_bf16, int B, int S, int H,
+                            hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  FedAvg helpers (src/train/main.py:50-65).  acc += x * num / total in the reference's operation order
+ * (x * num, then / total); first=1 overwrites acc.  The cross-GPU sum itself is one RCCL all-reduce
+ * issued by the host binding (torch.distributed, backend "nccl" == RCCL) on the same flat buffer.
+ * ------------------------------------------------------------------------------------------- */
+int feddat_fedavg_accumulate(float* acc, const float* x, long n, float num, float total, int first,
+                             hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * hardware-semantics probes used by tests/ (MFMA operand pairing, ds_read_b64_tr_b16 layout)
+ * ------------------------------------------------------------------------------------------- */
+int feddat_probe_tr16(const void* in_bf16_64x64, void* out_bf16_64x8, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEDDAT_HIP_H */

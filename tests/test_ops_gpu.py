@@ -1,0 +1,443 @@
+"""Op-level parity of the HIP kernels (through the C ABI / ctypes) against the CPU oracle, the golden
+fixtures captured from the reference, and plain fp32 PyTorch restatements of the same op.
+
+Tolerances: the kernels compute in bf16 with fp32 accumulation (north_star: bf16 MFMA); references are fp32 on
+bf16-rounded inputs where the kernel rounds its inputs, so the stated tolerances cover output rounding
+(bf16 eps = 2^-8 relative) and accumulation-order differences only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import feddat_oracle as O
+from tests.golden_util import load
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import lib
+    lib.load()
+    return lib
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+# ------------------------------------------------------------------ hardware semantics
+def test_probe_tr16_layout(L):
+    x = torch.arange(64 * 64, dtype=torch.float32, device=DEV).reshape(64, 64)
+    x = bf(x % 251 + (x // 64) * 0.0)  # small exact integers
+    x = bf(torch.arange(64 * 64, device=DEV).reshape(64, 64).float() % 509)
+    out = torch.zeros(64, 8, dtype=torch.bfloat16, device=DEV)
+    L.probe_tr16(x, out)
+    torch.cuda.synchronize()
+    exp = torch.zeros(64, 8, dtype=torch.bfloat16, device=DEV)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for j in range(4):
+            exp[lane, j] = x[4 * g + j, 16 + i]
+            exp[lane, 4 + j] = x[16 + 4 * g + j, 16 + i]
+    assert torch.equal(out, exp), (out[:20], exp[:20])
+
+
+# ------------------------------------------------------------------ K1 GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (5920, 768, 3072), (11840, 2304, 768)])
+def test_gemm_epilogues(L, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    B = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    aux = bf(torch.randn(M, N, generator=g)).to(DEV)
+    ref = A.float() @ B.float().t()
+    tol = 1.5e-2
+
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm_bf16_nt(A, B, L.EPI_BF16, bias=bias, out_bf16=o16)
+    assert rel_err(o16, ref + bias) < tol
+
+    o32 = torch.empty(M, N, device=DEV)
+    L.gemm_bf16_nt(A, B, L.EPI_RESID_F32, bias=bias, resid=resid, out_f32=o32)
+    assert rel_err(o32, ref + bias + resid) < 2e-3
+
+    u16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm_bf16_nt(A, B, L.EPI_GELU, bias=bias, out_bf16=o16, out2_bf16=u16)
+    assert rel_err(u16, ref + bias) < tol
+    assert rel_err(o16, F.gelu(ref + bias)) < tol
+
+    L.gemm_bf16_nt(A, B, L.EPI_MUL_DGELU, aux=aux, out_bf16=o16)
+    a32 = aux.float().requires_grad_(True)
+    F.gelu(a32).sum().backward()
+    assert rel_err(o16, ref * a32.grad) < tol
+
+    L.gemm_bf16_nt(A, B, L.EPI_F32, bias=bias, out_f32=o32)
+    assert rel_err(o32, ref + bias) < 2e-3
+    torch.cuda.synchronize()
+
+
+def test_gemm_rejects_bad_shapes(L):
+    A = torch.zeros(8, 60, dtype=torch.bfloat16, device=DEV)
+    B = torch.zeros(100, 60, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.FeddatHipError):
+        L.gemm_bf16_nt(A, B, L.EPI_BF16, out_bf16=o)
+
+
+# ------------------------------------------------------------------ K3 LayerNorm
+@pytest.mark.parametrize("rows,H", [(37, 768), (5920, 768), (64, 1536)])
+def test_layernorm_fwd_bwd(L, rows, H):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, H, generator=g) * 2 + 0.3).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(H, generator=g)).to(DEV)
+    y32 = torch.empty(rows, H, device=DEV)
+    y16 = torch.empty(rows, H, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(rows, 2, device=DEV)
+    eps = 1e-12 if H == 768 else 1e-5
+    L.layernorm_fwd(x, gamma, beta, eps, rows, H, y_bf16=y16, y_f32=y32, stats=stats)
+    ref = F.layer_norm(x, (H,), gamma, beta, eps)
+    assert (y32 - ref).abs().max() < 2e-5
+    assert rel_err(y16, ref) < 1e-2
+    # dX-only backward with residual add
+    dy = torch.randn(rows, H, generator=g).to(DEV)
+    dres = torch.randn(rows, H, generator=g).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr, (H,), gamma, beta, eps).backward(dy)
+    out = torch.empty(rows, H, device=DEV)
+    L.layernorm_bwd_dx(x, stats, gamma, rows, H, dy_f32=dy, dres=dres, out_f32=out)
+    assert (out - (xr.grad + dres)).abs().max() < 5e-5
+    dy16 = bf(dy)
+    o16 = torch.empty(rows, H, dtype=torch.bfloat16, device=DEV)
+    L.layernorm_bwd_dx(x, stats, gamma, rows, H, dy_bf16=dy16, out_f32=out, out_bf16=o16)
+    xr.grad = None
+    F.layer_norm(xr, (H,), gamma, beta, eps).backward(dy16.float())
+    assert (out - xr.grad).abs().max() < 5e-5
+    assert rel_err(o16, xr.grad) < 1e-2
+    if rows <= 1024:
+        gr = gamma.clone().requires_grad_(True)
+        br = beta.clone().requires_grad_(True)
+        xr.grad = None
+        F.layer_norm(xr, (H,), gr, br, eps).backward(dy)
+        dx = torch.empty(rows, H, device=DEV)
+        dg = torch.empty(H, device=DEV)
+        db = torch.empty(H, device=DEV)
+        L.layernorm_bwd_full(dy, x, stats, gamma, rows, H, dx, dg, db)
+        assert (dx - xr.grad).abs().max() < 5e-5
+        assert (dg - gr.grad).abs().max() < 1e-4 * max(1.0, float(gr.grad.abs().max()))
+        assert (db - br.grad).abs().max() < 1e-4 * max(1.0, float(br.grad.abs().max()))
+
+
+# ------------------------------------------------------------------ K4 adapter
+def _pack(L, wd, wu):
+    r, H = wd.shape
+    w = [torch.empty(r, H, dtype=torch.bfloat16, device=DEV), torch.empty(H, r, dtype=torch.bfloat16, device=DEV),
+         torch.empty(H, r, dtype=torch.bfloat16, device=DEV), torch.empty(r, H, dtype=torch.bfloat16, device=DEV)]
+    L.adapter_pack(wd, wu, *w)
+    return w
+
+
+def _golden_adapter(L, golden_dir):
+    g = load(golden_dir, "g1_adapter.npz")
+    par = {}
+    for a in range(3):
+        wd = torch.from_numpy(g[f"p.adapter_{a}_down.weight"]).to(DEV)
+        wu = torch.from_numpy(g[f"p.adapter_{a}_up.weight"]).to(DEV)
+        wd16, wdT16, wu16, wuT16 = _pack(L, wd, wu)
+        par[a] = dict(wd=wd16, wdT=wdT16, wu=wu16, wuT=wuT16, wd32=wd, wu32=wu,
+                      bd=torch.from_numpy(g[f"p.adapter_{a}_down.bias"]).to(DEV),
+                      bu=torch.from_numpy(g[f"p.adapter_{a}_up.bias"]).to(DEV))
+    return g, par
+
+
+def test_adapter_pack(L, golden_dir):
+    g, par = _golden_adapter(L, golden_dir)
+    assert torch.equal(par[0]["wd"], bf(par[0]["wd32"]))
+    assert torch.equal(par[0]["wdT"], bf(par[0]["wd32"]).t().contiguous())
+    assert torch.equal(par[0]["wu"], bf(par[0]["wu32"]))
+    assert torch.equal(par[0]["wuT"], bf(par[0]["wu32"]).t().contiguous())
+
+
+def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
+    """G1: outputs and gradients of the reference's own Adapter module (adapter.py:124-163)."""
+    g, par = _golden_adapter(L, golden_dir)
+    x = torch.from_numpy(g["x"]).reshape(-1, 768).to(DEV)
+    dy = torch.from_numpy(g["dy"]).reshape(-1, 768).to(DEV)
+    T = x.shape[0]
+    # one launch, two segments: rows [0,T/2) gated (adapter_0 + adapter_2), rows [T/2,T) single adapter_1
+    h = T // 2
+    segs = L.make_segs([
+        dict(row_begin=0, row_end=h, train_slot=0,
+             adapters=[dict(par[0], scale=0.5), dict(par[2], scale=0.5)]),
+        dict(row_begin=h, row_end=T, train_slot=0, adapters=[dict(par[1], scale=1.0)]),
+    ])
+    out = torch.zeros_like(x)
+    L.adapter_fwd(x, out, segs, T)
+    yg = torch.from_numpy(g["gating.y"]).reshape(-1, 768).to(DEV)
+    ys = torch.from_numpy(g["adapter_1.y"]).reshape(-1, 768).to(DEV)
+    # the adapter delta is O(0.1): bf16 operands -> abs error ~ 1e-3 on the delta, fp32 residual exact
+    assert (out[:h] - yg[:h]).abs().max() < 4e-3
+    assert (out[h:] - ys[h:]).abs().max() < 4e-3
+
+    dx = torch.zeros_like(x)
+    dx16 = torch.zeros(T, 768, dtype=torch.bfloat16, device=DEV)
+    z = torch.zeros(T, 48, device=DEV)
+    dz = torch.zeros(T, 48, device=DEV)
+    L.adapter_bwd(x, dy, dx, segs, T, dx_bf16=dx16, z_out=z, dz_out=dz)
+    dxg = torch.from_numpy(g["gating.dx"]).reshape(-1, 768).to(DEV)
+    dxs = torch.from_numpy(g["adapter_1.dx"]).reshape(-1, 768).to(DEV)
+    assert (dx[:h] - dxg[:h]).abs().max() < 2e-2   # |dx - dy| ~ 1, bf16 operands
+    assert (dx[h:] - dxs[h:]).abs().max() < 2e-2
+    assert rel_err(dx16, dx) < 1e-2
+    # weight gradients from (z, dz) with the exact-fp32 MFMA GEMM; compare with an fp32 restatement on the SAME
+    # rows (the golden weight grads cover all T rows, ours half of them per mode)
+    for (lo, hi, a, sc, x_, dy_) in ((0, h, 0, 0.5, x[:h], dy[:h]), (h, T, 1, 1.0, x[h:], dy[h:])):
+        wd32, wu32, bd, bu = par[a]["wd32"], par[a]["wu32"], par[a]["bd"], par[a]["bu"]
+        zz = F.relu(F.linear(x_, wd32, bd))
+        gg = (dy_ @ wu32) * sc
+        dzz = gg * (zz > 0)
+        n = hi - lo
+        dWu = torch.empty(768, 48, device=DEV)
+        dbu = torch.empty(768, device=DEV)
+        L.sgemm_f32(dy[lo:], 1, 768, z[lo:], 48, 1, 768, 48, n, dWu, colsum=dbu)
+        dWd = torch.empty(48, 768, device=DEV)
+        dbd = torch.empty(48, device=DEV)
+        L.sgemm_f32(dz[lo:], 1, 48, x[lo:], 768, 1, 48, 768, n, dWd, colsum=dbd)
+        ref_dWu = dy_.t() @ (zz * sc)
+        ref_dWd = dzz.t() @ x_
+        assert rel_err(z[lo:hi], zz * sc) < 1e-2
+        assert rel_err(dz[lo:hi], dzz) < 2e-2
+        assert rel_err(dWu, ref_dWu) < 1e-2
+        assert rel_err(dWd, ref_dWd) < 2e-2
+        assert rel_err(dbu, dy_.sum(0) * 1.0) < 1e-5   # colsum of A = dy (scale folded into z)
+        assert rel_err(dbd, dzz.sum(0)) < 2e-2
+
+
+def test_adapter_full_size_and_ragged_rows(L):
+    """T = 5920 x 2 rows (configs[1]) and a segment length that is not a multiple of 16."""
+    g = torch.Generator().manual_seed(3)
+    T = 5920 * 2 + 7
+    x = torch.randn(T, 768, generator=g).to(DEV)
+    ads = []
+    for a in range(3):
+        wd = (torch.randn(48, 768, generator=g) * 0.03).to(DEV)
+        wu = (torch.randn(768, 48, generator=g) * 0.03).to(DEV)
+        wd16, wdT16, wu16, wuT16 = _pack(L, wd, wu)
+        ads.append(dict(wd=wd16, wdT=wdT16, wu=wu16, wuT=wuT16, wd32=wd, wu32=wu,
+                        bd=(torch.randn(48, generator=g) * 0.02).to(DEV),
+                        bu=(torch.randn(768, generator=g) * 0.02).to(DEV)))
+    h = 5920 + 7
+    segs = L.make_segs([
+        dict(row_begin=0, row_end=h, adapters=[dict(ads[0], scale=0.5), dict(ads[2], scale=0.5)]),
+        dict(row_begin=h, row_end=T, adapters=[dict(ads[1], scale=1.0)]),
+    ])
+    out = torch.full_like(x, float("nan"))
+    L.adapter_fwd(x, out, segs, T)
+
+    def ref_ad(xx, a):
+        wd, wu = bf(a["wd32"]).float(), bf(a["wu32"]).float()
+        z = F.relu(bf(xx).float() @ wd.t() + a["bd"])
+        return bf(z).float() @ wu.t() + a["bu"]
+    ref0 = x[:h] + 0.5 * ref_ad(x[:h], ads[0]) + 0.5 * ref_ad(x[:h], ads[2])
+    ref1 = x[h:] + ref_ad(x[h:], ads[1])
+    assert (out[:h] - ref0).abs().max() < 2e-3
+    assert (out[h:] - ref1).abs().max() < 2e-3
+
+
+# ------------------------------------------------------------------ exact fp32 small GEMM
+@pytest.mark.parametrize("I,J,K,ksplit", [(64, 1536, 768, 1), (100, 48, 5921, 16), (17, 5, 3, 2)])
+def test_sgemm_f32(L, I, J, K, ksplit):
+    g = torch.Generator().manual_seed(I * J)
+    A = torch.randn(I, K, generator=g).to(DEV)
+    Bm = torch.randn(K, J, generator=g).to(DEV)
+    bias = torch.randn(J, generator=g).to(DEV)
+    out = torch.empty(ksplit, I, J, device=DEV)
+    cs = torch.empty(ksplit, I, device=DEV)
+    L.sgemm_f32(A, K, 1, Bm, J, 1, I, J, K, out, ksplit=ksplit, alpha=0.5, bias_j=bias,
+                out_split_stride=I * J, colsum=cs)
+    res = torch.empty(I, J, device=DEV)
+    L.reduce_partials(out, I * J, ksplit, I * J, res)
+    ref = 0.5 * (A.double() @ Bm.double()) + bias.double()
+    assert (res.double() - ref).abs().max() < 2e-5 * math.sqrt(K) * 4
+    assert (cs.sum(0).double() - 0.5 * A.double().sum(1)).abs().max() < 1e-4 * math.sqrt(K)
+    # transposed access patterns: D = A^T-view
+    At = A.t().contiguous()  # [K, I]
+    out2 = torch.empty(I, J, device=DEV)
+    L.sgemm_f32(At, 1, I, Bm, J, 1, I, J, K, out2)
+    assert (out2.double() - A.double() @ Bm.double()).abs().max() < 2e-5 * math.sqrt(K) * 4
+
+
+# ------------------------------------------------------------------ K5 loss
+def test_loss_vs_reference_golden(L, golden_dir):
+    g = load(golden_dir, "g2_loss.npz")
+    lg = torch.from_numpy(g["logits"]).to(DEV)
+    te = torch.from_numpy(g["teacher"]).to(DEV)
+    ta = torch.from_numpy(g["target"]).to(DEV)
+    dl = torch.empty_like(lg)
+    sc = torch.empty(4 + 2 * lg.shape[0], device=DEV)
+    L.dat_loss_fwd_bwd(lg, te, ta, dl, sc)
+    assert abs(float(sc[0]) - float(g["bce"])) < 1e-4
+    assert abs(float(sc[1]) - float(g["kl"])) < 1e-5
+    assert abs(float(sc[2]) - float(g["L"])) < 1e-4
+    assert (dl.cpu() - torch.from_numpy(g["dlogits"])).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------ K6 AdamW + schedule
+def test_adamw_flat_vs_oracle(L):
+    g = torch.Generator().manual_seed(5)
+    names = ["w.weight", "w.bias", "clf_norm0.weight", "x.LayerNorm.weight"]
+    shapes = [(48, 768), (48,), (1536,), (768,)]
+    P = {n: torch.randn(s, generator=g) * 0.05 for n, s in zip(names, shapes)}
+    offs = np.cumsum([0] + [int(np.prod(s)) for s in shapes])
+    flat = torch.cat([P[n].flatten() for n in names]).to(DEV)
+    m = torch.zeros_like(flat)
+    v = torch.zeros_like(flat)
+    seg_off = torch.tensor(offs, dtype=torch.int64, device=DEV)
+    seg_wd = torch.tensor([0.0 if O.is_no_decay(n) else 0.01 for n in names], device=DEV)
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    opt = O.AdamWState(names, 1e-4)
+    warm, total = 3, 40
+    for t in range(6):
+        grads = {n: torch.randn(s, generator=g) * (10.0 ** -t) for n, s in zip(names, shapes)}
+        gflat = torch.cat([grads[n].flatten() for n in names]).to(DEV)
+        L.adamw_flat(flat, gflat, m, v, seg_off, seg_wd, state, 1e-4, warm, total)
+        L.step_tick(state, 1, 1)
+        opt.step(P, grads, 1e-4 * O.poly_lr_lambda(t, warm, total))
+    ref = torch.cat([P[n].flatten() for n in names])
+    assert (flat.cpu() - ref).abs().max() < 2e-7
+    assert state.tolist() == [6, 6]
+
+
+# ------------------------------------------------------------------ K2 attention
+def _attn_ref(qkv, B, S, heads, mask=None):
+    H = heads * 64
+    q, k, v = (qkv[:, i * H:(i + 1) * H].float().reshape(B, S, heads, 64).transpose(1, 2) for i in range(3))
+    sc = q @ k.transpose(-1, -2) / 8.0
+    if mask is not None:
+        sc = sc.masked_fill(~mask[:, None, None, :].bool(), float("-inf"))
+    p = torch.softmax(sc, -1)
+    ctx = (p @ v).transpose(1, 2).reshape(B * S, H)
+    return ctx, torch.logsumexp(sc, -1)
+
+
+@pytest.mark.parametrize("B,S,heads,masked", [(2, 185, 12, False), (3, 90, 12, True), (1, 33, 2, True),
+                                              (64, 185, 12, False)])
+def test_attention_fwd_bwd(L, B, S, heads, masked):
+    g = torch.Generator().manual_seed(S)
+    H = heads * 64
+    qkv = bf(torch.randn(B * S, 3 * H, generator=g)).to(DEV)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.uint8)
+        for b in range(B):
+            mask[b, 20 + 3 * b: 20 + 3 * b + 7] = 0
+        mask = mask.to(DEV)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, S, device=DEV)
+    L.attn_fwd(qkv, ctx, lse, B, S, heads, key_mask=mask)
+    qr = qkv.float().requires_grad_(True)
+    cref, lref = _attn_ref(qr, B, S, heads, mask)
+    assert rel_err(ctx, cref) < 1.5e-2
+    assert (lse - lref).abs().max() < 2e-3
+    dctx = bf(torch.randn(B * S, H, generator=g)).to(DEV)
+    cref.backward(dctx.float())
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.attn_bwd(qkv, ctx, lse, dctx, dqkv, B, S, heads, key_mask=mask)
+    for part, name in enumerate("QKV"):
+        a = dqkv[:, part * H:(part + 1) * H]
+        r = qr.grad[:, part * H:(part + 1) * H]
+        assert torch.isfinite(a.float()).all(), name
+        assert rel_err(a, r) < 3e-2, (name, rel_err(a, r))
+
+
+# ------------------------------------------------------------------ K8 embeddings
+@pytest.mark.parametrize("res", [224, 384])
+def test_embeddings_vs_oracle(L, res):
+    d = O.ViltDims(layers=1)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    batch = O.synthetic_batch(3, res, 99)
+    ref = O.vilt_embed(P, d, batch)            # [B,S,H] fp32, CPU oracle
+    B, S, H = ref.shape
+    e = O.ENC + "embeddings."
+    dev = {k: v.to(DEV) for k, v in P.items() if k.startswith(e)}
+    h = torch.full((B, S, H), float("nan"), device=DEV)
+    tok = dev[e + "token_type_embeddings.weight"]
+    L.text_embed(batch["input_ids"].to(DEV), batch["token_type_ids"].to(DEV),
+                 dev[e + "text_embeddings.word_embeddings.weight"],
+                 dev[e + "text_embeddings.position_embeddings.weight"],
+                 dev[e + "text_embeddings.token_type_embeddings.weight"],
+                 dev[e + "text_embeddings.LayerNorm.weight"], dev[e + "text_embeddings.LayerNorm.bias"], d.ln_eps,
+                 tok[0].contiguous(), h, B, 40, S, H)
+    gsz = res // 32
+    npatch = gsz * gsz
+    patches = torch.empty(B * npatch, 3072, dtype=torch.bfloat16, device=DEV)
+    L.im2col_patches(batch["pixel_values"].to(DEV), patches, B, 3, res, 32)
+    ref_patches = F.unfold(batch["pixel_values"], 32, stride=32).transpose(1, 2).reshape(B * npatch, 3072)
+    assert torch.equal(patches.cpu(), bf(ref_patches))
+    wp = bf(dev[e + "patch_embeddings.projection.weight"].reshape(768, 3072))
+    proj = torch.empty(B * npatch, 768, device=DEV)
+    L.gemm_bf16_nt(patches, wp, L.EPI_F32, bias=dev[e + "patch_embeddings.projection.bias"], out_f32=proj)
+    pos = dev[e + "position_embeddings"][0]
+    pos_img = torch.empty(npatch, 768, device=DEV)
+    L.pos_embed_resize(pos[1:].contiguous(), pos_img, 12, gsz, gsz, 768)
+    ref_pos = O.interp_pos_embed(P, d, gsz, gsz)[0]
+    assert (pos_img.cpu() - ref_pos).abs().max() < 1e-6
+    L.image_embed_assemble(proj, dev[e + "cls_token"].reshape(768), pos[0].contiguous(), pos_img,
+                           tok[1].contiguous(), h, B, 40, npatch, S, H)
+    torch.cuda.synchronize()
+    assert (h[:, :41].cpu() - ref[:, :41]).abs().max() < 2e-5          # text rows + CLS: fp32 exact path
+    assert (h[:, 41:].cpu() - ref[:, 41:]).abs().max() < 2e-2          # bf16 patch projection (K = 3072)
+
+
+# ------------------------------------------------------------------ misc
+def test_misc_elementwise_and_fedavg(L, golden_dir):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, generator=g).to(DEV)
+    y = x.clone()
+    L.tanh_fwd(y)
+    assert (y - torch.tanh(x)).abs().max() < 1e-6
+    dy = torch.randn(1000, generator=g).to(DEV)
+    dx = torch.empty_like(x)
+    L.tanh_bwd(y, dy, dx)
+    assert (dx - dy * (1 - torch.tanh(x) ** 2)).abs().max() < 1e-5
+    L.gelu_fwd(x, y)
+    assert (y - F.gelu(x)).abs().max() < 1e-6
+    xr = x.clone().requires_grad_(True)
+    F.gelu(xr).backward(dy)
+    L.gelu_bwd(x, dy, dx)
+    assert (dx - xr.grad).abs().max() < 1e-5
+    w = torch.randn(70, 130, generator=g).to(DEV)
+    o = torch.empty(130, 70, dtype=torch.bfloat16, device=DEV)
+    L.transpose_f32_bf16(w, o, 70, 130)
+    assert torch.equal(o, bf(w).t().contiguous())
+    o2 = torch.empty(70 * 130, dtype=torch.bfloat16, device=DEV)
+    L.cvt_f32_bf16(w, o2)
+    assert torch.equal(o2, bf(w).flatten())
+    rows = torch.randn(3, 768, generator=g).to(DEV)
+    o32 = torch.full((3 * 5, 768), float("nan"), device=DEV)
+    o16 = torch.full((3 * 5, 768), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.scatter_cls_rows(rows, o32, o16, 3, 5, 768)
+    exp = torch.zeros(3, 5, 768, device=DEV)
+    exp[:, 0] = rows
+    assert torch.equal(o32, exp.reshape(15, 768)) and torch.equal(o16, bf(exp.reshape(15, 768)))
+    # FedAvg accumulate: bit-exact with the reference's get_average_net (main.py:50-65) golden
+    gd = load(golden_dir, "g5_fedavg.npz")
+    keys = [k[4:] for k in gd if k.startswith("avg.")]
+    nums = list(gd["nums"])
+    for k in keys[:4]:
+        acc = torch.empty(gd["avg." + k].shape, device=DEV)
+        for i in range(5):
+            L.fedavg_accumulate(acc, torch.from_numpy(gd[f"c{i}.{k}"]).to(DEV), nums[i], sum(nums), i == 0)
+        assert torch.equal(acc.cpu(), torch.from_numpy(gd["avg." + k])), k
