@@ -48,13 +48,20 @@ __device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const 
 }
 
 // weight operand for the contraction over r = 48 with slots (g, j<4) -> r = 4g + j, (g, j>=4) -> r = 16 + 4g + j - 4
-// (first MFMA, K = 32) and (g, j) -> r = 32 + 4g + j (second MFMA, K = 16).  w is [rows, 48] bf16.
-__device__ __forceinline__ void load_w48(const bf16* w, int row, int g, bf16x8& w01, bf16x4& w2) {
+// (first MFMA) and (g, j<4) -> r = 32 + 4g + j, (g, j>=4) -> zero padding (second MFMA).  w is [rows, 48] bf16.
+// Both products use the K=32 instruction: chaining v_mfma_f32_16x16x32_bf16 -> v_mfma_f32_16x16x16_bf16 on one
+// accumulator returned stale values in accumulator registers 0-1 on gfx950 / ROCm 7.2 (measured), so the K=16
+// form is not used anywhere.
+__device__ __forceinline__ void load_w48(const bf16* w, int row, int g, bf16x8& w01, bf16x8& w2) {
     const bf16* p = w + (size_t)row * R + 4 * g;
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
     const bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 16);
-    w2 = *reinterpret_cast<const bf16x4*>(p + 32);
+    const bf16x4 c = *reinterpret_cast<const bf16x4*>(p + 32);
     w01 = bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    w2 = bf16x8{c[0], c[1], c[2], c[3], 0, 0, 0, 0};
+}
+__device__ __forceinline__ bf16x8 pad8(const f32x4 a) {
+    return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], 0, 0, 0, 0};
 }
 
 template <int NA>
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restric
     down_proj<NA>(xrow, wd, lane, z);
 
     bf16x8 zb01[NA];
-    bf16x4 zb2[NA];
+    bf16x8 zb2[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restric
             for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(z[a][nt][e] + b4[e], 0.f);
         }
         zb01[a] = cvt8(z[a][0], z[a][1]);
-        zb2[a] = cvt4(z[a][2]);
+        zb2[a] = pad8(z[a][2]);
     }
 
 #pragma unroll 2
@@ -103,11 +110,10 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restric
         f32x4 o = *reinterpret_cast<const f32x4*>(xrow + c);
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            bf16x8 w01;
-            bf16x4 w2;
+            bf16x8 w01, w2;
             load_w48((const bf16*)sg.wu[a], ct * 16 + i16, g, w01, w2);
             f32x4 y = mfma16x32(w01, zb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
-            y = mfma16x16(w2, zb2[a], y);
+            y = mfma16x32(w2, zb2[a], y);
             const f32x4 bu4 = *reinterpret_cast<const f32x4*>(sg.bu[a] + c);
             const float sc = sg.scale[a];
 #pragma unroll
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
 
     // 3. dz = scale * g * (z > 0); export z*scale and dz of the trainable slot for the weight gradients
     bf16x8 dzb01[NA];
-    bf16x4 dzb2[NA];
+    bf16x8 dzb2[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         const float sc = sg.scale[a];
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
             }
         }
         dzb01[a] = cvt8(gr[a][0], gr[a][1]);
-        dzb2[a] = cvt4(gr[a][2]);
+        dzb2[a] = pad8(gr[a][2]);
     }
 
     // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48])
@@ -188,11 +194,10 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
         f32x4 o = *reinterpret_cast<const f32x4*>(dyrow + c);
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            bf16x8 w01;
-            bf16x4 w2;
+            bf16x8 w01, w2;
             load_w48((const bf16*)sg.wdT[a], ct * 16 + i16, g, w01, w2);
             f32x4 y = mfma16x32(w01, dzb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
-            y = mfma16x16(w2, dzb2[a], y);
+            y = mfma16x32(w2, dzb2[a], y);
             o = o + y;
         }
         if (valid) {

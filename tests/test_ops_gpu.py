@@ -187,9 +187,10 @@ def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
     L.adapter_fwd(x, out, segs, T)
     yg = torch.from_numpy(g["gating.y"]).reshape(-1, 768).to(DEV)
     ys = torch.from_numpy(g["adapter_1.y"]).reshape(-1, 768).to(DEV)
-    # the adapter delta is O(0.1): bf16 operands -> abs error ~ 1e-3 on the delta, fp32 residual exact
-    assert (out[:h] - yg[:h]).abs().max() < 4e-3
-    assert (out[h:] - ys[h:]).abs().max() < 4e-3
+    # the adapter delta here is O(1) (golden weights have std 0.05): bf16 operands (2^-8 relative) on a 768- and a
+    # 48-term contraction -> abs error <~ 1e-2 on the delta; the fp32 residual path is exact
+    assert (out[:h] - yg[:h]).abs().max() < 1.2e-2
+    assert (out[h:] - ys[h:]).abs().max() < 1.2e-2
 
     dx = torch.zeros_like(x)
     dx16 = torch.zeros(T, 768, dtype=torch.bfloat16, device=DEV)
