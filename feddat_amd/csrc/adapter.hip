@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restric
     const int g = lane >> 4, i16 = lane & 15;
     const int row = row0 + i16;
     const bool valid = row < sg.row_end;
-    const float* xrow = x + (size_t)(valid ? row : sg.row_end - 1) * H;
+    const float* xrow = x + (size_t)((valid ? row : sg.row_end - 1) + sg.x_row_delta) * H;
 
     const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
     f32x4 z[2][NT];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
     const int row = row0 + i16;
     const bool valid = row < sg.row_end;
     const size_t rclamp = (size_t)(valid ? row : sg.row_end - 1);
-    const float* xrow = x + rclamp * H;
+    const float* xrow = x + (rclamp + sg.x_row_delta) * H;
     const float* dyrow = dy + rclamp * H;
 
     // 1. recompute z = relu(Wd x + bd)
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
         for (int nt = 0; nt < NT; ++nt) gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     down_proj<NA>(dyrow, wuT, lane, gr);
 
-    // 3. dz = scale * g * (z > 0); export z*scale and dz of the trainable slot for the weight gradients
+    // 3. dz = scale * g * (z > 0); export z and dz of the trainable slot for the weight gradients
     bf16x8 dzb01[NA];
     bf16x8 dzb2[NA];
 #pragma unroll
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
             for (int e = 0; e < 4; ++e) {
                 zz[e] = fmaxf(z[a][nt][e] + b4[e], 0.f);
                 dz[e] = zz[e] > 0.f ? sc * gr[a][nt][e] : 0.f;
-                zz[e] *= sc;
             }
             gr[a][nt] = dz;
             if (a == sg.train_slot && valid && z_out) {
@@ -188,6 +187,7 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
     }
 
     // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48])
+    if (!dx) return;
 #pragma unroll 2
     for (int ct = 0; ct < CT; ++ct) {
         const int c = ct * 16 + 4 * g;
@@ -234,6 +234,7 @@ int prep_launch(const feddat_adapter_seg* segs, int nseg, int T, AdapterLaunch& 
     for (int s = 0; s < nseg; ++s) {
         const feddat_adapter_seg& sg = segs[s];
         if (sg.row_begin < 0 || sg.row_end > T || sg.row_end < sg.row_begin) return FEDDAT_EINVAL;
+        if (sg.row_begin + sg.x_row_delta < 0 || sg.row_end + sg.x_row_delta > T) return FEDDAT_EINVAL;
         if (sg.n_adapters != 1 && sg.n_adapters != 2) return FEDDAT_EINVAL;
         for (int a = 0; a < sg.n_adapters; ++a) {
             if (!sg.wd[a] || !sg.wu[a] || !sg.bd[a] || !sg.bu[a]) return FEDDAT_EINVAL;
@@ -269,7 +270,7 @@ extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int
 extern "C" int feddat_adapter_bwd(const float* x, const float* dy, float* dx, void* dx_bf16, float* z_out,
                                   float* dz_out, int T, int Hd, int r, const feddat_adapter_seg* segs, int nseg,
                                   hipStream_t stream) {
-    FD_CHECK_ARG(x && dy && dx && T > 0 && Hd == H && r == R);
+    FD_CHECK_ARG(x && dy && (dx || z_out) && T > 0 && Hd == H && r == R);
     FD_CHECK_ARG((z_out == nullptr) == (dz_out == nullptr));
     AdapterLaunch L;
     int tiles;

@@ -16,7 +16,7 @@ struct SgemmArgs {
     const float* bias_j;
     float* out;
     float* colsum;
-    long sa_i, sa_k, sb_k, sb_j, ldo, out_split_stride;
+    long sa_i, sa_k, sb_k, sb_j, ldo, out_split_stride, colsum_split_stride;
     int I, J, K, ksplit, kchunk, jgroups;
     float alpha;
 };
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs p) {
     if (p.colsum && jgrp == 0) {
         asum += __shfl_xor(asum, 16, 64);
         asum += __shfl_xor(asum, 32, 64);
-        if (g == 0 && iv) p.colsum[(size_t)split * p.I + i] = p.alpha * asum;
+        if (g == 0 && iv) p.colsum[(size_t)split * p.colsum_split_stride + i] = p.alpha * asum;
     }
 }
 
@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 extern "C" int feddat_sgemm_f32(const float* A, long sa_i, long sa_k, const float* B, long sb_k, long sb_j, int I,
                                 int J, int K, int ksplit, float alpha, const float* bias_j, float* out, long ldo,
-                                long out_split_stride, float* colsum, hipStream_t stream) {
+                                long out_split_stride, float* colsum, long colsum_split_stride, hipStream_t stream) {
     FD_CHECK_ARG(A && B && out && I > 0 && J > 0 && K > 0 && ksplit > 0 && ksplit <= 65535);
     FD_CHECK_ARG(ldo >= J && (ksplit == 1 || out_split_stride >= (long)I * ldo));
     SgemmArgs p;
     p.A = A; p.B = B; p.bias_j = bias_j; p.out = out; p.colsum = colsum;
     p.sa_i = sa_i; p.sa_k = sa_k; p.sb_k = sb_k; p.sb_j = sb_j; p.ldo = ldo; p.out_split_stride = out_split_stride;
+    p.colsum_split_stride = colsum_split_stride;
     p.I = I; p.J = J; p.K = K; p.ksplit = ksplit; p.alpha = alpha;
     int kchunk = (K + ksplit - 1) / ksplit;
     kchunk = (kchunk + 3) / 4 * 4;

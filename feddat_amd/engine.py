@@ -1,0 +1,545 @@
+"""ViLT-B/32 dual-adapter (DAT) local-update engine on MI355X.
+
+Host-side sequencing of the HIP kernels in libfeddat_hip.so for the reference's hot path
+(src/train/visionlanguage_tasks/task_trainer.py:266-330 around src/modeling/vilt.py:244-264 and
+src/modeling/models/adapter.py:124-163).  No arithmetic happens in Python/PyTorch here: torch only owns the
+device buffers and the stream; every launch goes through the C ABI, on static buffers, so a whole train_step
+can be captured into one hipGraph (torch.cuda.CUDAGraph stream capture) and replayed.
+
+Restructuring relative to the reference (same results, fewer FLOPs -- DESIGN.md "step algebra"):
+  * P0 (no-grad gated forward) and P2 (gated forward with grad) see identical backbone inputs and identical
+    adapter_0/adapter_2 weights (P1 only updates adapter_1 and the task head), so the gated backbone forward is
+    run ONCE and its pooled output feeds both the P0 logits (old head) and the P2 logits (updated head).
+  * Embeddings and the body of layer 0 (everything below the first adapter) are shared by the gated and the
+    adapter_1 pass; from the layer-0 adapter on, the two passes ride in ONE batch of 2*B*S rows through the
+    frozen GEMMs / attention (rows [0,R) gated, rows [R,2R) adapter_1).
+  * Nothing trainable lies below the layer-0 adapter, so the backward stops there.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+
+ENC = "vilt_encoder.vilt."
+ADAPTER_TENSORS = ("down.weight", "down.bias", "up.weight", "up.bias")
+HEAD_TENSORS = ("clf_fc0.weight", "clf_fc0.bias", "clf_norm0.weight", "clf_norm0.bias", "clf_fc1.weight",
+                "clf_fc1.bias")
+
+
+def _no_decay(name: str) -> bool:  # task_trainer.py:478
+    return ("bias" in name) or ("LayerNorm.weight" in name)
+
+
+class FlatGroup:
+    """A set of named fp32 tensors living back-to-back in one flat device buffer (+ grad, Adam m/v, segment table)."""
+
+    def __init__(self, names_shapes: Sequence, device, with_opt: bool):
+        self.names = [n for n, _ in names_shapes]
+        self.shapes = {n: tuple(s) for n, s in names_shapes}
+        self.offsets = {}
+        off = 0
+        for n, s in names_shapes:
+            self.offsets[n] = off
+            off += int(math.prod(s))
+        self.numel = off
+        self.p = torch.zeros(off, device=device)
+        if with_opt:
+            self.g = torch.zeros(off, device=device)
+            self.m = torch.zeros(off, device=device)
+            self.v = torch.zeros(off, device=device)
+            offs = [self.offsets[n] for n in self.names] + [off]
+            self.seg_off = torch.tensor(offs, dtype=torch.int64, device=device)
+            self.seg_wd = torch.tensor([0.0 if _no_decay(n) else 1.0 for n in self.names], device=device)
+            self.state = torch.zeros(2, dtype=torch.int32, device=device)  # {sched_t, adam_t}
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        buf = self.p if buf is None else buf
+        o = self.offsets[name]
+        return buf[o:o + int(math.prod(self.shapes[name]))].view(self.shapes[name])
+
+
+class ViltDatEngine:
+    def __init__(self, params: Dict[str, torch.Tensor], tasks: Sequence[str], device, batch: int, res: int,
+                 text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
+                 weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16):
+        L.load()
+        self.dev = torch.device(device)
+        self.tasks = list(tasks)
+        self.B, self.res, self.Lt, self.nl = batch, res, text_len, layers
+        self.H, self.I, self.heads, self.r, self.C = 768, 3072, 12, 48, num_labels
+        self.P = 32
+        self.grid = res // self.P
+        self.np = self.grid * self.grid
+        self.S = text_len + 1 + self.np
+        self.R = batch * self.S
+        self.lr, self.wd, self.eps = lr, weight_decay, adam_eps
+        self.ksplit = wgrad_splits
+        self.ln_eps = 1e-12
+        dev = self.dev
+        H, I = self.H, self.I
+
+        def P(name):
+            return params[name].to(dev, torch.float32).contiguous()
+
+        def bf16_of(w):
+            out = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
+            L.cvt_f32_bf16(w, out)
+            return out
+
+        def bf16_T(w):  # [R,C] fp32 -> [C,R] bf16
+            out = torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev)
+            L.transpose_f32_bf16(w, out, w.shape[0], w.shape[1])
+            return out
+
+        # ---------------- frozen backbone (bf16 weights + their transposes for the dX products) --------------
+        e = ENC + "embeddings."
+        self.emb = {k: P(e + k) for k in (
+            "text_embeddings.word_embeddings.weight", "text_embeddings.position_embeddings.weight",
+            "text_embeddings.token_type_embeddings.weight", "text_embeddings.LayerNorm.weight",
+            "text_embeddings.LayerNorm.bias", "patch_embeddings.projection.bias")}
+        tok = P(e + "token_type_embeddings.weight")
+        self.mod0, self.mod1 = tok[0].contiguous(), tok[1].contiguous()
+        self.cls = P(e + "cls_token").reshape(H).contiguous()
+        pos = P(e + "position_embeddings")[0]
+        self.pos0 = pos[0].contiguous()
+        self.pos_img = torch.empty(self.np, H, device=dev)
+        g0 = int(round(math.sqrt(pos.shape[0] - 1)))
+        L.pos_embed_resize(pos[1:].contiguous(), self.pos_img, g0, self.grid, self.grid, H)
+        self.w_patch = bf16_of(P(e + "patch_embeddings.projection.weight").reshape(H, 3 * self.P * self.P))
+        self.layers: List[dict] = []
+        for i in range(layers):
+            Lp = ENC + f"encoder.layer.{i}."
+            wq, wk, wv = (P(Lp + f"attention.attention.{n}.weight") for n in ("query", "key", "value"))
+            wqkv = torch.cat([wq, wk, wv], 0).contiguous()
+            bqkv = torch.cat([P(Lp + f"attention.attention.{n}.bias") for n in ("query", "key", "value")]).contiguous()
+            wo, w1, w2 = P(Lp + "attention.output.dense.weight"), P(Lp + "intermediate.dense.weight"), \
+                P(Lp + "output.layer.dense.weight")
+            self.layers.append(dict(
+                wqkv=bf16_of(wqkv), wqkvT=bf16_T(wqkv), bqkv=bqkv,
+                wo=bf16_of(wo), woT=bf16_T(wo), bo=P(Lp + "attention.output.dense.bias"),
+                w1=bf16_of(w1), w1T=bf16_T(w1), b1=P(Lp + "intermediate.dense.bias"),
+                w2=bf16_of(w2), w2T=bf16_T(w2), b2=P(Lp + "output.layer.dense.bias"),
+                ln1g=P(Lp + "layernorm_before.weight"), ln1b=P(Lp + "layernorm_before.bias"),
+                ln2g=P(Lp + "layernorm_after.weight"), ln2b=P(Lp + "layernorm_after.bias")))
+        self.lnf_g, self.lnf_b = P(ENC + "layernorm.weight"), P(ENC + "layernorm.bias")
+        self.pool_w, self.pool_b = P(ENC + "pooler.dense.weight"), P(ENC + "pooler.dense.bias")
+
+        # ---------------- trainable state: three adapters (flat per adapter) and one head per task ----------
+        def adapter_names(a):
+            return [(ENC + f"encoder.layer.{i}.output.adapter.adapter_{a}_{t}",
+                     {"down.weight": (self.r, H), "down.bias": (self.r,), "up.weight": (H, self.r),
+                      "up.bias": (H,)}[t]) for i in range(layers) for t in ADAPTER_TENSORS]
+        self.ad = [FlatGroup(adapter_names(a), dev, with_opt=(a != 2)) for a in range(3)]
+        self.ad_layer_numel = self.r * H + self.r + H * self.r + H
+        head_shapes = {"clf_fc0.weight": (2 * H, H), "clf_fc0.bias": (2 * H,), "clf_norm0.weight": (2 * H,),
+                       "clf_norm0.bias": (2 * H,), "clf_fc1.weight": (num_labels, 2 * H), "clf_fc1.bias": (num_labels,)}
+        self.head = {t: FlatGroup([(f"task_layer.{t}.{n}", head_shapes[n]) for n in HEAD_TENSORS], dev, True)
+                     for t in self.tasks}
+        for grp in self.ad + list(self.head.values()):
+            for n in grp.names:
+                grp.view(n).copy_(params[n].to(dev, torch.float32))
+        # bf16 operand copies of the adapters: [a][layer] -> dict(wd, wdT, wu, wuT, bd, bu)
+        self.ad16 = [[self._alloc_pack(a, i) for i in range(layers)] for a in range(3)]
+        for a in range(3):
+            self.repack_adapter(a)
+
+        # ---------------- workspace (static: a whole step is graph-capturable) ----------------
+        R, R2, B = self.R, 2 * self.R, batch
+
+        def f32(*s):
+            return torch.empty(*s, device=dev)
+
+        def b16(*s):
+            return torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        self.inp = dict(pixel_values=f32(B, 3, res, res), input_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
+                        token_type_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
+                        target=f32(B, num_labels), key_mask=torch.ones(B, self.S, dtype=torch.uint8, device=dev))
+        self.use_mask = False
+        self.key_mask2 = torch.ones(2 * B, self.S, dtype=torch.uint8, device=dev)
+        self.patches = b16(B * self.np, 3 * self.P * self.P)
+        self.proj = f32(B * self.np, H)
+        self.h0 = f32(R, H)
+        self.x16 = b16(R2, H)          # LN output (GEMM operand), transient
+        self.f16 = b16(R2, I)          # gelu(u), transient
+        # layer 0 (shared body, R rows): only h3 is kept
+        self.l0 = dict(qkv=b16(R, 3 * H), ctx=b16(R, H), lse=f32(B, self.heads, self.S), h2=f32(R, H), h3=f32(R, H))
+        self.act = [None] + [dict(h_in=f32(R2, H), st1=f32(R2, 2), qkv=b16(R2, 3 * H), ctx=b16(R2, H),
+                                  lse=f32(2 * B, self.heads, self.S), h2=f32(R2, H), st2=f32(R2, 2),
+                                  u=b16(R2, I), h3=f32(R2, H)) for _ in range(1, layers)]
+        self.h_out = f32(R2, H)        # output of the last adapter
+        self.st0 = f32(R, 2)
+        # head / pooler
+        self.cls_ln = f32(2 * B, H)
+        self.cls_st = f32(2 * B, 2)
+        self.pooled = f32(2 * B, H)
+        self.hd = {k: dict(a0=f32(B, 2 * H), n0=f32(B, 2 * H), st=f32(B, 2), g0=f32(B, 2 * H),
+                           logits=f32(B, num_labels)) for k in ("all", "p1", "p2")}
+        self.dlogits = f32(B, num_labels)
+        self.loss_buf = {k: f32(4 + 2 * B) for k in ("p1", "p2")}
+        self.dg0, self.dn0, self.da0 = f32(B, 2 * H), f32(B, 2 * H), f32(B, 2 * H)
+        self.dpooled = f32(2 * B, H)
+        self.dpre = f32(2 * B, H)
+        self.dcls_ln = f32(2 * B, H)
+        self.dcls = f32(2 * B, H)
+        # backward streams
+        self.dh = [f32(R2, H), f32(R2, H)]       # ping-pong residual-gradient stream
+        self.dh16 = b16(R2, H)
+        self.dU = b16(R2, I)
+        self.dx16 = b16(R2, H)
+        self.dctx = b16(R2, H)
+        self.dqkv = b16(R2, 3 * H)
+        self.z = f32(R2, self.r)
+        self.dz = f32(R2, self.r)
+        self.wpart = f32(self.ksplit, self.ad_layer_numel)
+        self._segs_cache: Dict = {}
+        self.graph = None
+        self.sched = dict(warmup=1, total=2)
+        self.opt_adapters = (0, 1)
+        self.task = self.tasks[0]
+
+    # ------------------------------------------------------------------------------------------ adapters
+    def _alloc_pack(self, a, i):
+        H, r, dev = self.H, self.r, self.dev
+        base = ENC + f"encoder.layer.{i}.output.adapter.adapter_{a}_"
+
+        def b16(*s):
+            return torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        return dict(wd=b16(r, H), wdT=b16(H, r), wu=b16(H, r), wuT=b16(r, H),
+                    bd=self.ad[a].view(base + "down.bias"), bu=self.ad[a].view(base + "up.bias"),
+                    wd32=self.ad[a].view(base + "down.weight"), wu32=self.ad[a].view(base + "up.weight"))
+
+    def repack_adapter(self, a: int):
+        """fp32 masters -> bf16 MFMA operand copies (after every optimizer step / load / FedAvg)."""
+        for p in self.ad16[a]:
+            L.adapter_pack(p["wd32"], p["wu32"], p["wd"], p["wdT"], p["wu"], p["wuT"])
+
+    def copy_global_to_teacher(self):
+        """adapter_1 -> adapter_2 at the start of every local update (task_trainer.py:36-41)."""
+        self.ad[2].p.copy_(self.ad[1].p)
+        self.repack_adapter(2)
+
+    def _segs(self, layer: int, first: bool, bwd: bool):
+        """Two-segment descriptor: rows [0,R) gated (adapter_0 + adapter_2, 0.5 each), rows [R,2R) adapter_1."""
+        key = (layer, first, bwd)
+        if key not in self._segs_cache:
+            a0, a1, a2 = (self.ad16[a][layer] for a in range(3))
+            R = self.R
+            self._segs_cache[key] = L.make_segs([
+                dict(row_begin=0, row_end=R, train_slot=0 if bwd else -1, x_row_delta=0,
+                     adapters=[dict(a0, scale=0.5), dict(a2, scale=0.5)]),
+                dict(row_begin=R, row_end=2 * R, train_slot=0 if bwd else -1, x_row_delta=-R if first else 0,
+                     adapters=[dict(a1, scale=1.0)]),
+            ])
+        return self._segs_cache[key]
+
+    def _single_segs(self, layer: int, mode: str, rows: int):
+        if mode == "gating":
+            ads = [dict(self.ad16[0][layer], scale=0.5), dict(self.ad16[2][layer], scale=0.5)]
+        else:
+            ads = [dict(self.ad16[int(mode.split("_")[1])][layer], scale=1.0)]
+        return L.make_segs([dict(row_begin=0, row_end=rows, adapters=ads)])
+
+    # ------------------------------------------------------------------------------------------ inputs
+    def set_batch(self, batch: Dict[str, torch.Tensor]):
+        """Copy one batch (reference schema: HF ViLT encodings + target_scores) into the static input buffers."""
+        px = batch["pixel_values"]
+        if tuple(px.shape) != tuple(self.inp["pixel_values"].shape):
+            raise L.FeddatHipError(f"engine built for pixel_values {tuple(self.inp['pixel_values'].shape)}, got "
+                                   f"{tuple(px.shape)}")
+        if "pixel_mask" in batch and not bool(batch["pixel_mask"].all()):
+            raise L.FeddatHipError("padded images (pixel_mask with zeros) are not supported yet")
+        self.inp["pixel_values"].copy_(px, non_blocking=True)
+        self.inp["input_ids"].copy_(batch["input_ids"], non_blocking=True)
+        self.inp["token_type_ids"].copy_(batch["token_type_ids"], non_blocking=True)
+        if "target_scores" in batch:
+            self.inp["target"].copy_(batch["target_scores"], non_blocking=True)
+        am = batch.get("attention_mask")
+        if am is not None and not bool(am.all()):
+            self.use_mask = True
+            self.inp["key_mask"][:, :self.Lt].copy_(am.to(torch.uint8))
+            self.key_mask2[:self.B].copy_(self.inp["key_mask"])
+            self.key_mask2[self.B:].copy_(self.inp["key_mask"])
+        elif self.use_mask:
+            self.use_mask = False
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _embed(self):
+        B, H, S, Lt = self.B, self.H, self.S, self.Lt
+        e = self.emb
+        L.text_embed(self.inp["input_ids"], self.inp["token_type_ids"], e["text_embeddings.word_embeddings.weight"],
+                     e["text_embeddings.position_embeddings.weight"], e["text_embeddings.token_type_embeddings.weight"],
+                     e["text_embeddings.LayerNorm.weight"], e["text_embeddings.LayerNorm.bias"], self.ln_eps,
+                     self.mod0, self.h0, B, Lt, S, H)
+        L.im2col_patches(self.inp["pixel_values"], self.patches, B, 3, self.res, self.P)
+        L.gemm_bf16_nt(self.patches, self.w_patch, L.EPI_F32, bias=e["patch_embeddings.projection.bias"],
+                       out_f32=self.proj)
+        L.image_embed_assemble(self.proj, self.cls, self.pos0, self.pos_img, self.mod1, self.h0, B, Lt, self.np, S, H)
+
+    def _layer_body(self, i: int, h_in, rows: int, nb: int, qkv, ctx, lse, h2, h3, st1=None, st2=None, u=None,
+                    mask=None):
+        """LN -> QKV -> attention -> out-proj(+res) -> LN -> FFN1(gelu) -> FFN2(+res): HF ViltLayer with the
+        Adaptered_ViltOutput dense+residual (adaptered_output.py:74-76); returns the adapter input in h3."""
+        W, H = self.layers[i], self.H
+        x16, f16 = self.x16[:rows], self.f16[:rows]
+        L.layernorm_fwd(h_in, W["ln1g"], W["ln1b"], self.ln_eps, rows, H, y_bf16=x16, stats=st1)
+        L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=qkv)
+        L.attn_fwd(qkv, ctx, lse, nb, self.S, self.heads, key_mask=mask)
+        L.gemm_bf16_nt(ctx, W["wo"], L.EPI_RESID_F32, bias=W["bo"], resid=h_in, out_f32=h2)
+        L.layernorm_fwd(h2, W["ln2g"], W["ln2b"], self.ln_eps, rows, H, y_bf16=x16, stats=st2)
+        L.gemm_bf16_nt(x16, W["w1"], L.EPI_GELU, bias=W["b1"], out_bf16=f16, out2_bf16=u)
+        L.gemm_bf16_nt(f16, W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=h2, out_f32=h3)
+
+    def _forward_dual(self):
+        """Shared embeddings + layer-0 body, then both passes (gated | adapter_1) batched through layers 1..L-1."""
+        R, R2, B = self.R, 2 * self.R, self.B
+        self._embed()
+        l0 = self.l0
+        m1 = self.inp["key_mask"] if self.use_mask else None
+        m2 = self.key_mask2 if self.use_mask else None
+        self._layer_body(0, self.h0, R, B, l0["qkv"], l0["ctx"], l0["lse"], l0["h2"], l0["h3"], st1=self.st0,
+                         st2=self.st0, mask=m1)
+        nxt = self.act[1]["h_in"] if self.nl > 1 else self.h_out
+        L.adapter_fwd(l0["h3"], nxt, self._segs(0, True, False), R2)
+        for i in range(1, self.nl):
+            a = self.act[i]
+            self._layer_body(i, a["h_in"], R2, 2 * B, a["qkv"], a["ctx"], a["lse"], a["h2"], a["h3"], st1=a["st1"],
+                             st2=a["st2"], u=a["u"], mask=m2)
+            nxt = self.act[i + 1]["h_in"] if i + 1 < self.nl else self.h_out
+            L.adapter_fwd(a["h3"], nxt, self._segs(i, False, False), R2)
+        self._pool(self.h_out, 2 * B)
+
+    def _pool(self, h_last, nb: int):
+        """ViltModel.layernorm on token 0 + ViltPooler (dense + tanh) -> self.pooled[:nb]."""
+        H = self.H
+        L.layernorm_fwd(h_last, self.lnf_g, self.lnf_b, self.ln_eps, nb, H, x_stride=self.S * H,
+                        y_f32=self.cls_ln, stats=self.cls_st)
+        L.sgemm_f32(self.cls_ln, H, 1, self.pool_w, 1, H, nb, H, H, self.pooled, bias_j=self.pool_b)
+        L.tanh_fwd(self.pooled[:nb])
+
+    def _head_fwd(self, pooled, slot: str, task: str):
+        """vilt.py:202-209: fc0 -> LayerNorm(1536, eps 1e-5) -> GELU -> fc1 on B rows."""
+        B, H, C = self.B, self.H, self.C
+        hp, s = self.head[task], self.hd[slot]
+        pre = f"task_layer.{task}."
+        L.sgemm_f32(pooled, H, 1, hp.view(pre + "clf_fc0.weight"), 1, H, B, 2 * H, H, s["a0"],
+                    bias_j=hp.view(pre + "clf_fc0.bias"))
+        L.layernorm_fwd(s["a0"], hp.view(pre + "clf_norm0.weight"), hp.view(pre + "clf_norm0.bias"), 1e-5, B, 2 * H,
+                        y_f32=s["n0"], stats=s["st"])
+        L.gelu_fwd(s["n0"], s["g0"])
+        L.sgemm_f32(s["g0"], 2 * H, 1, hp.view(pre + "clf_fc1.weight"), 1, 2 * H, B, C, 2 * H, s["logits"],
+                    bias_j=hp.view(pre + "clf_fc1.bias"))
+        return s["logits"]
+
+    def _head_bwd(self, pooled, slot: str, task: str, dpooled_out):
+        """Gradients of the task head (all six tensors, fp32) and d(pooled) for B rows."""
+        B, H, C = self.B, self.H, self.C
+        hp, s = self.head[task], self.hd[slot]
+        pre = f"task_layer.{task}."
+
+        def G(n):
+            return hp.view(pre + n, hp.g)
+        dl = self.dlogits
+        L.sgemm_f32(dl, 1, C, s["g0"], 2 * H, 1, C, 2 * H, B, G("clf_fc1.weight"), colsum=G("clf_fc1.bias"))
+        L.sgemm_f32(dl, C, 1, hp.view(pre + "clf_fc1.weight"), 2 * H, 1, B, 2 * H, C, self.dg0)
+        L.gelu_bwd(s["n0"], self.dg0, self.dn0)
+        L.layernorm_bwd_full(self.dn0, s["a0"], s["st"], hp.view(pre + "clf_norm0.weight"), B, 2 * H, self.da0,
+                             G("clf_norm0.weight"), G("clf_norm0.bias"))
+        L.sgemm_f32(self.da0, 1, 2 * H, pooled, H, 1, 2 * H, H, B, G("clf_fc0.weight"), colsum=G("clf_fc0.bias"))
+        L.sgemm_f32(self.da0, 2 * H, 1, hp.view(pre + "clf_fc0.weight"), H, 1, B, H, 2 * H, dpooled_out)
+
+    def _adamw(self, grp: FlatGroup):
+        L.adamw_flat(grp.p, grp.g, grp.m, grp.v, grp.seg_off, self._wd_vec(grp), grp.state, self.lr,
+                     self.sched["warmup"], self.sched["total"], 0.9, 0.98, self.eps)
+
+    def _wd_vec(self, grp: FlatGroup):
+        if not hasattr(grp, "_wdv") or grp._wdv_val != self.wd:
+            grp._wdv = grp.seg_wd * self.wd
+            grp._wdv_val = self.wd
+        return grp._wdv
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _backward_dual(self):
+        """dpooled [2B,H] -> adapter_0 grads (rows [0,R)) and adapter_1 grads (rows [R,2R))."""
+        R, R2, B, H = self.R, 2 * self.R, self.B, self.H
+        nb = 2 * B
+        L.tanh_bwd(self.pooled, self.dpooled, self.dpre)
+        L.sgemm_f32(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln)
+        L.layernorm_bwd_dx(self.h_out, self.cls_st, self.lnf_g, nb, H, dy_f32=self.dcls_ln, x_stride=self.S * H,
+                           out_f32=self.dcls)
+        cur, oth = self.dh
+        L.scatter_cls_rows(self.dcls, cur, None, nb, self.S, H)
+        m2 = self.key_mask2 if self.use_mask else None
+        for i in range(self.nl - 1, 0, -1):
+            a, W = self.act[i], self.layers[i]
+            # adapter: dh3 (fp32 in `oth`, bf16 copy in dh16), z/dz for the weight gradients
+            L.adapter_bwd(a["h3"], cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
+                          dz_out=self.dz)
+            self._adapter_wgrads(i, a["h3"], 0, cur)
+            # FFN2^T (+ gelu'), FFN1^T, LN2 backward (+ residual)
+            L.gemm_bf16_nt(self.dh16, W["w2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
+            L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
+            L.layernorm_bwd_dx(a["h2"], a["st2"], W["ln2g"], R2, H, dy_bf16=self.dx16, dres=oth, out_f32=cur,
+                               out_bf16=self.dh16)
+            # attention-out^T, attention backward, QKV^T, LN1 backward (+ residual)
+            L.gemm_bf16_nt(self.dh16, W["woT"], L.EPI_BF16, out_bf16=self.dctx)
+            L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=m2)
+            L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
+            L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
+            cur, oth = oth, cur
+        # layer 0: weight gradients only (nothing trainable below)
+        L.adapter_bwd(self.l0["h3"], cur, None, self._segs(0, True, True), R2, z_out=self.z, dz_out=self.dz)
+        self._adapter_wgrads(0, self.l0["h3"], -R, cur)
+
+    def _adapter_wgrads(self, layer: int, x, x_delta_s: int, dy):
+        """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146):
+        exact fp32 MFMA, split over tokens, deterministic reduction straight into the flat gradient buffers."""
+        R, H, r, ks = self.R, self.H, self.r, self.ksplit
+        n = self.ad_layer_numel
+        o_wd, o_bd, o_wu, o_bu = 0, r * H, r * H + r, r * H + r + H * r
+        part = self.wpart
+        for a, row0, xrow0, sc in ((0, 0, 0, 0.5), (1, R, R + x_delta_s, 1.0)):
+            if a not in self.opt_adapters:
+                continue
+            dy_s, z_s, dz_s, x_s = dy[row0:], self.z[row0:], self.dz[row0:], x[xrow0:]
+            L.sgemm_f32(dy_s, 1, H, z_s, r, 1, H, r, R, part[:, o_wu:], ldo=r, ksplit=ks, out_split_stride=n,
+                        alpha=sc, colsum=part[:, o_bu:], colsum_split_stride=n)
+            L.sgemm_f32(dz_s, 1, r, x_s, H, 1, r, H, R, part[:, o_wd:], ldo=H, ksplit=ks, out_split_stride=n,
+                        colsum=part[:, o_bd:], colsum_split_stride=n)
+            L.reduce_partials(part, n, ks, n, self.ad[a].g[layer * n:(layer + 1) * n])
+
+    # ------------------------------------------------------------------------------------------ train step
+    def begin_local_update(self, task: str, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,
+                           opt_adapters: Sequence[int] = (0, 1)):
+        """TaskTrainer.train prologue (task_trainer.py:36-59): teacher snapshot, fresh AdamW state and schedule."""
+        self.task = task
+        self.copy_global_to_teacher()
+        total = steps_per_epoch * num_epochs
+        self.sched = dict(total=total, warmup=int(total * warmup_ratio))
+        self.opt_adapters = tuple(opt_adapters)
+        for grp in (self.ad[0], self.ad[1], self.head[task]):
+            grp.m.zero_()
+            grp.v.zero_()
+            grp.g.zero_()
+        # scheduler index / Adam step count per group: adapter_1 is stepped at 2b, adapter_0 at 2b+1, head at both
+        self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))
+        self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))
+        self.head[task].state.copy_(torch.tensor([0, 0], dtype=torch.int32))
+        self.graph = None
+
+    def _step_kernels(self):
+        B, task = self.B, self.task
+        hp = self.head[task]
+        self._forward_dual()
+        pooled_g, pooled_s = self.pooled[:B], self.pooled[B:]
+        # P0: logits of the gated pass with the current head (no grad)          task_trainer.py:283-287
+        logits_all = self._head_fwd(pooled_g, "all", task)
+        # P1: adapter_1 pass, KL to P0                                           task_trainer.py:290-308
+        logits_1 = self._head_fwd(pooled_s, "p1", task)
+        L.dat_loss_fwd_bwd(logits_1, logits_all, self.inp["target"], self.dlogits, self.loss_buf["p1"])
+        self._head_bwd(pooled_s, "p1", task, self.dpooled[B:])
+        self._adamw(hp)
+        L.step_tick(hp.state, 1, 1)
+        # P2: gated pass again -- same pooled features, UPDATED head, KL to logits_1     task_trainer.py:311-328
+        logits_0 = self._head_fwd(pooled_g, "p2", task)
+        L.dat_loss_fwd_bwd(logits_0, logits_1, self.inp["target"], self.dlogits, self.loss_buf["p2"])
+        self._head_bwd(pooled_g, "p2", task, self.dpooled[:B])
+        # one backward for both passes, then the deferred adapter_1 step (lr index 2b) and the P2 steps (2b+1)
+        self._backward_dual()
+        if 1 in self.opt_adapters:
+            self._adamw(self.ad[1])
+            self.repack_adapter(1)
+        L.step_tick(self.ad[1].state, 2, 1)
+        self._adamw(hp)
+        L.step_tick(hp.state, 1, 1)
+        if 0 in self.opt_adapters:
+            self._adamw(self.ad[0])
+            self.repack_adapter(0)
+        L.step_tick(self.ad[0].state, 2, 1)
+
+    def train_step(self, batch: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False):
+        """One DAT+MKD step (task_trainer.py:280-330).  Returns the device tensor holding what the reference
+        returns: loss_0 = BCE * num_labels of the P2 pass (loss_buf['p2'][0]); [1] = KL, [2] = L_0."""
+        if batch is not None:
+            self.set_batch(batch)
+        if not use_graph:
+            self._step_kernels()
+        else:
+            if self.graph is None:
+                self._capture()
+            self.graph.replay()
+        return self.loss_buf["p2"]
+
+    def _capture(self):
+        """Capture the whole step into one hipGraph (all launches are on static buffers; the LR schedule and Adam
+        step counts live on the device).  The optimizer state is saved/restored around the warm-up + capture
+        run so that capturing does not advance training."""
+        groups = [self.ad[0], self.ad[1], self.head[self.task]]
+        saved = [(g.p.clone(), g.m.clone(), g.v.clone(), g.state.clone()) for g in groups]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._step_kernels()      # warm-up (sets function attributes, allocates lazily created scratch)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._step_kernels()
+        torch.cuda.synchronize()
+        for g, (p, m, v, st) in zip(groups, saved):
+            g.p.copy_(p)
+            g.m.copy_(m)
+            g.v.copy_(v)
+            g.state.copy_(st)
+        for a in (0, 1):
+            self.repack_adapter(a)
+        torch.cuda.synchronize()
+        self.graph = graph
+
+    # ------------------------------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def forward(self, batch: Dict[str, torch.Tensor], mode: str, task: Optional[str] = None):
+        """model(task_key, images, texts) -> (pooled, logits) in adapter mode `mode` ('gating' | 'adapter_k')
+        (vilt.py:244-264 with the adapter switches of vilt.py:363-373).  Single pass over B*S rows."""
+        task = task or self.task
+        self.set_batch(batch)
+        R, B = self.R, self.B
+        self._embed()
+        l0 = self.l0
+        m1 = self.inp["key_mask"] if self.use_mask else None
+        h = self.h0
+        for i in range(self.nl):
+            self._layer_body(i, h, R, B, l0["qkv"], l0["ctx"], l0["lse"], l0["h2"], l0["h3"], st1=self.st0,
+                             st2=self.st0, mask=m1)
+            h = self.dh[i & 1][:R]
+            L.adapter_fwd(l0["h3"], h, self._single_segs(i, mode, R), R)
+        self._pool(h, B)
+        logits = self._head_fwd(self.pooled[:B], "all", task)
+        return self.pooled[:B].clone(), logits.clone()
+
+    # ------------------------------------------------------------------------------------------ state dict
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Trainable tensors under the reference's state-dict keys (views into the flat buffers)."""
+        out = {}
+        for grp in self.ad + list(self.head.values()):
+            for n in grp.names:
+                out[n] = grp.view(n)
+        return out
+
+    def load_tensors(self, tensors: Dict[str, torch.Tensor]):
+        sd = self.state_dict()
+        touched = set()
+        for n, v in tensors.items():
+            sd[n].copy_(v.to(self.dev, torch.float32))
+            for a in range(3):
+                if f"adapter_{a}_" in n:
+                    touched.add(a)
+        for a in touched:
+            self.repack_adapter(a)
+
+    def comm_flat(self) -> torch.Tensor:
+        """The FedAvg payload: all adapter_1 tensors back-to-back in state-dict order (main.py:154-163,499-503)."""
+        return self.ad[1].p

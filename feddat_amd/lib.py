@@ -22,7 +22,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 class AdapterSeg(C.Structure):
     _fields_ = [("row_begin", i32), ("row_end", i32), ("n_adapters", i32), ("train_slot", i32),
-                ("scale", f32 * 2), ("wd", vp * 2), ("wdT", vp * 2), ("wu", vp * 2), ("wuT", vp * 2),
+                ("x_row_delta", i32), ("reserved", i32), ("scale", f32 * 2), ("wd", vp * 2), ("wdT", vp * 2), ("wu", vp * 2), ("wuT", vp * 2),
                 ("bd", vp * 2), ("bu", vp * 2)]
 
 
@@ -37,7 +37,7 @@ _SIGS = {
     "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_pack": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
-    "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, vp],
+    "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
     "feddat_adamw_flat": [vp, vp, vp, vp, i64, vp, vp, i32, vp, f32, i32, i32, f32, f32, f32, vp],
@@ -167,6 +167,7 @@ def make_segs(segs: Sequence[dict]):
         ads = d["adapters"]  # list of dicts with wd, wdT, wu, wuT (bf16), bd, bu (fp32), scale
         s.n_adapters = len(ads)
         s.train_slot = d.get("train_slot", -1)
+        s.x_row_delta = d.get("x_row_delta", 0)
         for a, ad in enumerate(ads):
             s.scale[a] = ad["scale"]
             s.wd[a] = ad["wd"].data_ptr()
@@ -196,10 +197,11 @@ def adapter_pack(wd, wu, wd16, wdT16, wu16, wuT16, H=768, r=48):
 
 
 def sgemm_f32(A, sa_i, sa_k, B, sb_k, sb_j, I, J, K, out, *, ldo=None, ksplit=1, alpha=1.0, bias_j=None,
-              out_split_stride=0, colsum=None):
+              out_split_stride=0, colsum=None, colsum_split_stride=None):
     _dev(A, B, out)
     _chk(load().feddat_sgemm_f32(_p(A), sa_i, sa_k, _p(B), sb_k, sb_j, I, J, K, ksplit, alpha, _p(bias_j), _p(out),
-                                 J if ldo is None else ldo, out_split_stride, _p(colsum), _stream()),
+                                 J if ldo is None else ldo, out_split_stride, _p(colsum),
+                                 I if colsum_split_stride is None else colsum_split_stride, _stream()),
          "feddat_sgemm_f32")
 
 

@@ -86,6 +86,8 @@ typedef struct {
     int row_begin, row_end;
     int n_adapters;   /* 1 or 2 */
     int train_slot;   /* backward: which adapter slot (0/1) gets weight grads, -1 = none */
+    int x_row_delta;  /* input row = output row + x_row_delta (lets two segments share one input, layer 0) */
+    int reserved;
     float scale[2];
     const void* wd[2];   /* bf16 [r,H]  */
     const void* wdT[2];  /* bf16 [H,r]  (backward) */
@@ -97,9 +99,11 @@ typedef struct {
 
 int feddat_adapter_fwd(const float* x, float* out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg,
                        hipStream_t stream);
-/* backward: dx = dy + sum_a W_down[a]^T (relu' .* (scale[a] * W_up[a]^T dy)); optional bf16 copy of dx.
- * For the segment's train_slot the kernel also writes z = relu(.) and dz (fp32 [T,r] each, rows of that
- * segment) that feddat_sgemm_f32 turns into dW_up = dy^T (scale*z), dW_down = dz^T x. */
+/* backward: dx = dy + sum_a W_down[a]^T (relu' .* (scale[a] * W_up[a]^T dy)); optional bf16 copy of dx;
+ * dx may be NULL (only z/dz are produced: nothing trainable lies below the first adapter).
+ * For the segment's train_slot the kernel also writes z = relu(W_down x + b_down) and dz = scale * relu' .* (W_up^T dy)
+ * (fp32 [T,r] each, rows of that segment) that feddat_sgemm_f32 turns into dW_up = scale * dy^T z,
+ * db_up = scale * sum_t dy, dW_down = dz^T x, db_down = sum_t dz. */
 int feddat_adapter_bwd(const float* x, const float* dy, float* dx, void* dx_bf16, float* z_out, float* dz_out, int T,
                        int H, int r, const feddat_adapter_seg* segs, int nseg, hipStream_t stream);
 /* fp32 master [wd(r*H), bd(r), wu(H*r), bu(H)] -> bf16 wd, wdT, wu, wuT. */
@@ -111,12 +115,12 @@ int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* w
  *   for split s: D_s[i][j] = alpha * sum_{k in chunk s} A[i*sa_i + k*sa_k] * B[k*sb_k + j*sb_j]
  *   out[s*out_split_stride + i*ldo + j] = D_s[i][j] (+ bias_j[j] if s == 0 and bias_j) .
  * Used for the task head (vilt.py:202-209) forward/backward, the ViLT pooler, and the adapter
- * weight gradients (contraction over tokens).  colsum: optional fp32 [ksplit, I] receiving
+ * weight gradients (contraction over tokens).  colsum: optional fp32 (split s at colsum + s*colsum_split_stride) receiving
  * alpha * sum_k A[i][k] for the i-tiles (used for bias gradients), or NULL.
  * ------------------------------------------------------------------------------------------- */
 int feddat_sgemm_f32(const float* A, long sa_i, long sa_k, const float* B, long sb_k, long sb_j, int I, int J, int K,
                      int ksplit, float alpha, const float* bias_j, float* out, long ldo, long out_split_stride,
-                     float* colsum, hipStream_t stream);
+                     float* colsum, long colsum_split_stride, hipStream_t stream);
 /* out[i] = sum_s in[s*stride + i], i < n   (deterministic reduction of split-K partials). */
 int feddat_reduce_partials(const float* in, long stride, int nsplit, long n, float* out, hipStream_t stream);
 

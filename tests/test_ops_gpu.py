@@ -212,17 +212,17 @@ def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
         n = hi - lo
         dWu = torch.empty(768, 48, device=DEV)
         dbu = torch.empty(768, device=DEV)
-        L.sgemm_f32(dy[lo:], 1, 768, z[lo:], 48, 1, 768, 48, n, dWu, colsum=dbu)
+        L.sgemm_f32(dy[lo:], 1, 768, z[lo:], 48, 1, 768, 48, n, dWu, alpha=sc, colsum=dbu)
         dWd = torch.empty(48, 768, device=DEV)
         dbd = torch.empty(48, device=DEV)
         L.sgemm_f32(dz[lo:], 1, 48, x[lo:], 768, 1, 48, 768, n, dWd, colsum=dbd)
         ref_dWu = dy_.t() @ (zz * sc)
         ref_dWd = dzz.t() @ x_
-        assert rel_err(z[lo:hi], zz * sc) < 1e-2
+        assert rel_err(z[lo:hi], zz) < 1e-2
         assert rel_err(dz[lo:hi], dzz) < 2e-2
         assert rel_err(dWu, ref_dWu) < 1e-2
         assert rel_err(dWd, ref_dWd) < 2e-2
-        assert rel_err(dbu, dy_.sum(0) * 1.0) < 1e-5   # colsum of A = dy (scale folded into z)
+        assert rel_err(dbu, dy_.sum(0) * sc) < 1e-5
         assert rel_err(dbd, dzz.sum(0)) < 2e-2
 
 
