@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: VQA samples/sec of the ViLT-B/32 dual-adapter (DAT + MKD) local step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank = one GPU = one federated client)
+
+A "step" is one full reference train_step (task_trainer.py:280-330: P0 + P1 + P2, two AdamW/scheduler steps) on one
+batch of B=32 synthetic 384x384 image / 40-token question pairs per client (BASELINE.json configs[1]; configs[2] for
+N > 1).  Inputs are resident in HBM before the timed region.  With N clients the timed region also contains the
+round's FedAvg exchange (one RCCL all-reduce of the 3.58 MB adapter_1 buffer, main.py:50-65).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16 = 2.5e15          # dense bf16 MFMA peak of gfx950 (MI355X_MICROARCH.md)
+REF_FLOPS_PER_SAMPLE = 1.6564e11   # algorithmic FLOPs of one reference DAT step, S=185
+
+
+def flops_tables(B, S, layers=12, H=768, I=3072, heads=12, r=48, npatch=144):
+    """Executed FLOPs of OUR step per batch (see DESIGN.md 'step algebra') and the GEMM launch list."""
+    R = B * S
+    lin = lambda M, N, K: 2.0 * M * N * K  # noqa: E731
+    gemms = []  # (M, N, K, epi, count)
+    fwd_shapes = [(3 * H, H, 0), (H, H, 1), (I, H, 2), (H, I, 1)]
+    bwd_shapes = [(I, H, 3), (H, I, 0), (H, H, 0), (H, 3 * H, 0)]
+    for N, K, epi in fwd_shapes:
+        gemms.append((R, N, K, epi, 1))
+        gemms.append((2 * R, N, K, epi, layers - 1))
+    for N, K, epi in bwd_shapes:
+        gemms.append((2 * R, N, K, epi, layers - 1))
+    gemms.append((B * npatch, H, 3 * 32 * 32, 4, 1))
+    gemm_flops = sum(lin(M, N, K) * c for M, N, K, _, c in gemms)
+    attn_fwd = 4.0 * S * S * 64 * heads * B           # per B samples
+    attn = attn_fwd * (1 + 2 * (layers - 1)) + 2.5 * attn_fwd * 2 * (layers - 1)
+    ad1 = 2.0 * R * H * r * 2                          # one adapter forward over R rows
+    adapters = layers * 3 * ad1 + layers * 3 * 3 * ad1 + layers * 2 * 2 * ad1  # fwd + (recompute, g, dx) + dW
+    head = 3 * 2.0 * B * (H * 2 * H + 2 * H * 100) * 3
+    return gemms, gemm_flops, gemm_flops + attn + adapters + head
+
+
+def measure_gemms(L, gemms, iters=10):
+    """Average launch duration of the dominant kernel (gemm_nt_kernel) per shape, HIP events on the launch stream."""
+    dev = "cuda"
+    tot_t, tot_f, rows = 0.0, 0.0, []
+    for M, N, K, epi, count in gemms:
+        A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        Bw = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev)
+        kw = {}
+        if epi in (0, 3):
+            kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        if epi == 3:
+            kw["aux"] = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        if epi == 2:
+            kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw["out2_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        if epi == 1:
+            kw["resid"] = torch.randn(M, N, device=dev)
+            kw["out_f32"] = torch.empty(M, N, device=dev)
+        if epi == 4:
+            kw["out_f32"] = torch.empty(M, N, device=dev)
+        if epi != 3:
+            kw["bias"] = bias
+        for _ in range(3):
+            L.gemm_bf16_nt(A, Bw, epi, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            L.gemm_bf16_nt(A, Bw, epi, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / iters
+        f = 2.0 * M * N * K
+        rows.append(dict(M=M, N=N, K=K, epi=epi, count=count, us=round(t * 1e6, 2), tflops=round(f / t / 1e12, 1)))
+        tot_t += t * count
+        tot_f += f * count
+    return tot_f / tot_t, tot_t, rows
+
+
+def cpu_baseline(params_cpu, B, res, task, budget_s=20.0):
+    """The CPU restatement of the reference path (oracle/, validated against the reference's goldens) timed on
+    this node's host cores on a BOUNDED sample of the same workload: same model / resolution / sequence length,
+    batch 8 instead of 32 (CPU throughput is flat in the batch size), 1 warm-up + up to 2 timed
+    train_steps.  Thread count capped at 32: PyTorch-CPU gets slower, not faster, beyond that on this model."""
+    from oracle import feddat_oracle as O
+    B = min(B, 8)
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    d = O.ViltDims(layers=12)
+    P = {k: v.clone() for k, v in params_cpu.items()}
+    client = O.DatClient(P, d, task, lr=1e-4, steps_per_epoch=50)
+    batches = [O.synthetic_batch(B, res, 1234 + i) for i in range(3)]
+    t0 = time.time()
+    client.train_step(batches[0])
+    warm = time.time() - t0
+    n, t1 = 0, time.time()
+    while n < 2 and (time.time() - t1) + warm * (n + 1) / max(n, 1) < budget_s + warm:
+        client.train_step(batches[1 + n])
+        n += 1
+    dt = time.time() - t1
+    if n == 0:
+        n, dt = 1, warm
+    return dict(value=round(B * n / dt, 3), unit="samples/s", cores=torch.get_num_threads(),
+                host_cores=os.cpu_count(), kind="port",
+                sample=f"{n} timed train_step(s) after 1 warm-up, B={B}, {res}x{res}, 40 tokens, fp32, "
+                       f"torch {torch.__version__} CPU, {torch.get_num_threads()} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--res", type=int, default=384)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from feddat_amd import engine, lib as L, vilt_spec
+    from feddat_amd.fedavg import allreduce_average
+    dev = torch.device("cuda", local)
+    B, res = args.batch, args.res
+    tasks = [f"client{r}" for r in range(world)]
+    task = tasks[rank]
+    # identical frozen backbone + server adapter on every client (seed 0); heterogeneous data per client
+    params = vilt_spec.random_init(12, tasks, seed=0, device="cpu")
+    eng = engine.ViltDatEngine(params, [task], dev, batch=B, res=res, layers=12)
+    nb = 4
+    batches = [vilt_spec.synthetic_batch(B, res, 1234 + 100 * rank + i, device=dev) for i in range(nb)]
+    steps_per_epoch = max(args.steps + args.warmup, 40)
+    eng.begin_local_update(task, steps_per_epoch=steps_per_epoch)
+    use_graph = not args.no_graph
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.train_step(batches[i % nb], use_graph=use_graph)
+    if dist is not None:
+        allreduce_average(eng, world)       # warm the communicator
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(batches[i % nb], use_graph=use_graph)
+    if dist is not None:
+        allreduce_average(eng, world)       # the round's FedAvg exchange
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(eng.loss_buf["p2"][0])
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    if not (loss == loss) or abs(loss) > 1e6:
+        raise RuntimeError(f"non-finite loss {loss}")
+
+    out = None
+    if rank == 0:
+        S = eng.S
+        gemms, gemm_flops, exec_flops = flops_tables(B, S)
+        sps = world * B * args.steps / dt
+        out = {
+            "metric": "VQA samples/sec, ViLT-B/32 dual-adapter local step", "value": round(sps, 2),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, bf16 MFMA, batch=32/client, "
+                                   "384x384 synthetic + 40-token questions, MKD on"
+                                   + (f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else ""),
+                       "batch_per_client": B, "seq_len": S, "clients": world, "hip_graph": use_graph,
+                       "last_loss_0": round(loss, 4)},
+            "samples_per_sec_per_gpu": round(sps / world, 2),
+            "mfma_frac_executed_flops": round(exec_flops * args.steps / dt / PEAK_BF16, 4),
+            "mfma_frac_reference_flops": round(sps / world * REF_FLOPS_PER_SAMPLE / PEAK_BF16, 4),
+        }
+        if not args.no_roofline:
+            ach, tsum, rows = measure_gemms(L, gemms)
+            out["roofline"] = {"kernel": "gemm_nt_kernel (K1, frozen-linear bf16 MFMA GEMM, all 13 launch shapes "
+                                         "of one step, FLOP-weighted)",
+                               "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16, 4), "traffic": None,
+                               "gemm_ms_per_step": round(tsum * 1e3, 3), "shapes": rows}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline({k: v.float().cpu() for k, v in params.items()}, B, res, task)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

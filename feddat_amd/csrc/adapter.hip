@@ -2,8 +2,8 @@
 // Reference: src/modeling/models/adapter.py:124-163 (single: 125-131; gating: 133-146, get_agg_out 118-122),
 // called as adapter(h, h) from Adaptered_ViltOutput.forward (src/modeling/adaptered_output.py:77).
 //
-// One wave owns 16 tokens.  The token rows stream straight from HBM into MFMA operand registers
-// (fp32 -> bf16 in flight), the [16 x 48] bottleneck never leaves registers: the down-projection is
+// One block (4 waves) owns 16 tokens.  The token rows stream straight from HBM into MFMA operand registers
+// (fp32 -> bf16 in flight), the [16 x 48] bottleneck never reaches HBM: the down-projection is
 // computed as Z^T[r, tok] so that its accumulator layout (lane: token = lane & 15, four consecutive r)
 // is already the operand layout of the up-projection (contraction slots are paired (g, j) <-> (g, j),
 // so the slot -> r permutation only has to be applied to the weight operand).  The up-projection is
@@ -28,13 +28,14 @@ __device__ __forceinline__ bf16x8 load_x8(const float* p) {
     return cvt8(a, b);
 }
 
-// Z^T[a][nt] += Wd[a] (rows r) x X^T (cols tok), contraction over the 768 features.
+// Z^T[a][nt] += W[a] (rows r) x X^T (cols tok), contraction over features [k_begin, k_begin + 32 * nks).
 template <int NA>
-__device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const bf16* const* wd, int lane,
+__device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const bf16* const* wd, int lane, int ks0,
                                           f32x4 (&z)[2][NT]) {
     const int g = lane >> 4, i16 = lane & 15;
-#pragma unroll 4
-    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int k = 0; k < KS / 4; ++k) {
+        const int ks = ks0 + k;
         const bf16x8 xf = load_x8(xrow + ks * 32 + g * 8);
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -64,19 +65,32 @@ __device__ __forceinline__ bf16x8 pad8(const f32x4 a) {
     return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], 0, 0, 0, 0};
 }
 
+// cross-wave sum of the K-split partial bottleneck tiles: part[w][slot][lane] (f32x4), slot = a * NT + nt
 template <int NA>
-__global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                          AdapterLaunch L) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // this kernel instance serves the segments whose n_adapters == NA
-    int s, t;
-    if (tile < L.tiles0) { s = 0; t = tile; } else { s = 1; t = tile - L.tiles0; }
-    if (s >= L.nseg) return;
-    const feddat_adapter_seg& sg = L.seg[s];
-    if (sg.n_adapters != NA) return;
-    const int row0 = sg.row_begin + t * 16;
-    if (row0 >= sg.row_end) return;
+__device__ __forceinline__ void ksplit_reduce(f32x4* part, int wave, int lane, f32x4 (&z)[2][NT]) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) part[(wave * (2 * NT) + a * NT + nt) * 64 + lane] = z[a][nt];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 s = part[(0 * (2 * NT) + a * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s = s + part[(w * (2 * NT) + a * NT + nt) * 64 + lane];
+            z[a][nt] = s;
+        }
+}
+
+// One block (4 waves) = 16 tokens.  Each wave contracts a quarter of the 768 features in the down-projection
+// (partials summed through LDS, fixed order) and then owns a quarter of the 768 output columns of the
+// up-projection: 4x shorter dependent chain per wave and 4x more waves in flight than one-wave-per-tile.
+template <int NA>
+__device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __restrict__ out,
+                                         const feddat_adapter_seg& sg, int row0, f32x4* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int row = row0 + i16;
     const bool valid = row < sg.row_end;
@@ -88,10 +102,10 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restric
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    down_proj<NA>(xrow, wd, lane, z);
+    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z);
+    ksplit_reduce<NA>(part, wave, lane, z);
 
-    bf16x8 zb01[NA];
-    bf16x8 zb2[NA];
+    bf16x8 zb01[NA], zb2[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
@@ -103,9 +117,9 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restric
         zb01[a] = cvt8(z[a][0], z[a][1]);
         zb2[a] = pad8(z[a][2]);
     }
-
-#pragma unroll 2
-    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll 4
+    for (int k = 0; k < CT / 4; ++k) {
+        const int ct = wave * (CT / 4) + k;
         const int c = ct * 16 + 4 * g;
         f32x4 o = *reinterpret_cast<const f32x4*>(xrow + c);
 #pragma unroll
@@ -123,20 +137,24 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restric
     }
 }
 
-template <int NA>
-__global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ dx, bf16* __restrict__ dx16,
-                                                          float* __restrict__ z_out, float* __restrict__ dz_out,
+__global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           AdapterLaunch L) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int s, t;
-    if (tile < L.tiles0) { s = 0; t = tile; } else { s = 1; t = tile - L.tiles0; }
-    if (s >= L.nseg) return;
+    __shared__ __attribute__((aligned(16))) f32x4 part[4 * 2 * NT * 64];
+    const int tile = blockIdx.x;
+    const int s = tile < L.tiles0 ? 0 : 1;
+    const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
-    if (sg.n_adapters != NA) return;
     const int row0 = sg.row_begin + t * 16;
-    if (row0 >= sg.row_end) return;
+    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, part);
+    else fwd_body<1>(x, out, sg, row0, part);
+}
+
+template <int NA>
+__device__ __forceinline__ void bwd_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                         float* __restrict__ dx, bf16* __restrict__ dx16, float* __restrict__ z_out,
+                                         float* __restrict__ dz_out, const feddat_adapter_seg& sg, int row0,
+                                         f32x4* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int row = row0 + i16;
     const bool valid = row < sg.row_end;
@@ -144,26 +162,24 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
     const float* xrow = x + (rclamp + sg.x_row_delta) * H;
     const float* dyrow = dy + rclamp * H;
 
-    // 1. recompute z = relu(Wd x + bd)
+    // 1. recompute z = relu(Wd x + bd);  2. g = Wu^T dy (weight operand = WuT [48, 768]); both K-split over the waves
     const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
-    f32x4 z[2][NT];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    down_proj<NA>(xrow, wd, lane, z);
-    // 2. g = Wu^T dy  (same contraction over the 768 features, weight operand = WuT [48, 768])
     const bf16* wuT[2] = {(const bf16*)sg.wuT[0], (const bf16*)sg.wuT[NA - 1]};
-    f32x4 gr[2][NT];
+    f32x4 z[2][NT], gr[2][NT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    down_proj<NA>(dyrow, wuT, lane, gr);
+        for (int nt = 0; nt < NT; ++nt) {
+            z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z);
+    down_proj<NA>(dyrow, wuT, lane, wave * (KS / 4), gr);
+    ksplit_reduce<NA>(part, wave, lane, z);
+    ksplit_reduce<NA>(part + 4 * 2 * NT * 64, wave, lane, gr);
 
     // 3. dz = scale * g * (z > 0); export z and dz of the trainable slot for the weight gradients
-    bf16x8 dzb01[NA];
-    bf16x8 dzb2[NA];
+    bf16x8 dzb01[NA], dzb2[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         const float sc = sg.scale[a];
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
                 dz[e] = zz[e] > 0.f ? sc * gr[a][nt][e] : 0.f;
             }
             gr[a][nt] = dz;
-            if (a == sg.train_slot && valid && z_out) {
+            if (a == sg.train_slot && nt == wave && valid && z_out) {
                 *reinterpret_cast<f32x4*>(z_out + (size_t)row * R + nt * 16 + 4 * g) = zz;
                 *reinterpret_cast<f32x4*>(dz_out + (size_t)row * R + nt * 16 + 4 * g) = dz;
             }
@@ -186,10 +202,11 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
         dzb2[a] = pad8(gr[a][2]);
     }
 
-    // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48])
+    // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48]); this wave's quarter of the columns
     if (!dx) return;
-#pragma unroll 2
-    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll 4
+    for (int k = 0; k < CT / 4; ++k) {
+        const int ct = wave * (CT / 4) + k;
         const int c = ct * 16 + 4 * g;
         f32x4 o = *reinterpret_cast<const f32x4*>(dyrow + c);
 #pragma unroll
@@ -205,6 +222,20 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
             if (dx16) *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * H + c) = cvt4(o);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, bf16* __restrict__ dx16,
+                                                          float* __restrict__ z_out, float* __restrict__ dz_out,
+                                                          AdapterLaunch L) {
+    __shared__ __attribute__((aligned(16))) f32x4 part[2 * 4 * 2 * NT * 64];
+    const int tile = blockIdx.x;
+    const int s = tile < L.tiles0 ? 0 : 1;
+    const int t = s ? tile - L.tiles0 : tile;
+    const feddat_adapter_seg& sg = L.seg[s];
+    const int row0 = sg.row_begin + t * 16;
+    if (sg.n_adapters == 2) bwd_body<2>(x, dy, dx, dx16, z_out, dz_out, sg, row0, part);
+    else bwd_body<1>(x, dy, dx, dx16, z_out, dz_out, sg, row0, part);
 }
 
 __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
@@ -259,11 +290,7 @@ extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int
     const int rc = prep_launch(segs, nseg, T, L, tiles, false);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    bool need[3] = {false, false, false};
-    for (int s = 0; s < nseg; ++s) need[segs[s].n_adapters] = true;
-    const dim3 grid((tiles + 3) / 4);
-    if (need[1]) hipLaunchKernelGGL(adapter_fwd_kernel<1>, grid, dim3(256), 0, stream, x, out, L);
-    if (need[2]) hipLaunchKernelGGL(adapter_fwd_kernel<2>, grid, dim3(256), 0, stream, x, out, L);
+    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), 0, stream, x, out, L);
     FD_LAUNCH_RET();
 }
 
@@ -277,15 +304,8 @@ extern "C" int feddat_adapter_bwd(const float* x, const float* dy, float* dx, vo
     const int rc = prep_launch(segs, nseg, T, L, tiles, true);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    bool need[3] = {false, false, false};
-    for (int s = 0; s < nseg; ++s) need[segs[s].n_adapters] = true;
-    const dim3 grid((tiles + 3) / 4);
-    if (need[1])
-        hipLaunchKernelGGL(adapter_bwd_kernel<1>, grid, dim3(256), 0, stream, x, dy, dx, (bf16*)dx_bf16, z_out, dz_out,
-                           L);
-    if (need[2])
-        hipLaunchKernelGGL(adapter_bwd_kernel<2>, grid, dim3(256), 0, stream, x, dy, dx, (bf16*)dx_bf16, z_out, dz_out,
-                           L);
+    hipLaunchKernelGGL(adapter_bwd_kernel, dim3(tiles), dim3(256), 0, stream, x, dy, dx, (bf16*)dx_bf16, z_out, dz_out,
+                       L);
     FD_LAUNCH_RET();
 }
 

@@ -1,0 +1,179 @@
+// Adapter weight gradients (autograd of src/modeling/models/adapter.py:125-146 w.r.t. the trainable adapter):
+//     dW_down[r][c] = sum_t dz[t][r] * x[t][c]          db_down[r] = sum_t dz[t][r]
+//     dW_up  [c][r] = s * sum_t dy[t][c] * z[t][r]      db_up  [c] = s * sum_t dy[t][c]
+// Both are "small^T x big" products contracted over the tokens: small = [T,48], big = [T,768], fp32.
+// Exact-fp32 MFMA (v_mfma_f32_16x16x4_f32; its operands are one dword per lane, (index, token) = (lane & 15,
+// lane >> 4), so the token-major activations are consumed as they lie in HBM, no transposes).  A wave owns 64
+// columns x all 48 bottleneck units for a range of tokens: one float4 load of `big` feeds 4 interleaved column
+// tiles, 3 dword loads of `small` feed the 3 r-tiles -> 12 MFMAs per 4 tokens.  The 4 waves of a block own 4
+// consecutive token ranges and are summed through LDS; the 16 blocks per column chunk leave 16 partials that
+// the (deterministic) reduce kernel folds straight into the flat gradient buffer [wd | bd | wu | bu].
+// HBM-bound in bytes (x and dy are each read once: 2 x T x 768 x 4 B), MFMA-f32-bound in time (1/16 of bf16 rate).
+#include "common.hip.h"
+
+namespace {
+
+constexpr int H = 768, R = 48, NRT = 3, CW = 64;          // columns per wave
+constexpr int NCH = H / CW;                                 // 12 column chunks
+constexpr int NBLK = 16;                                    // token-split blocks per column chunk
+constexpr int PSTRIDE = R * H + R + H;                      // one partial: [out r x c | colsum_small | colsum_big]
+
+struct WgradLaunch {
+    feddat_wgrad_seg seg[2];
+    float* partials;
+    int nseg;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradLaunch L) {
+    __shared__ __attribute__((aligned(16))) float red[3][64][NRT * 4 * 4 + 4];  // waves 1..3 -> wave 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int chunk = blockIdx.x, blk = blockIdx.y;
+    const int prob = blockIdx.z;            // 2 * seg + which (0: dW_down = dz^T x, 1: dW_up^T = z^T dy)
+    const feddat_wgrad_seg& sg = L.seg[prob >> 1];
+    const bool up = prob & 1;
+    const float* big = up ? sg.dy : sg.x;
+    const float* sm = up ? sg.z : sg.dz;
+    const float alpha = up ? sg.scale : 1.0f;
+    const int T = sg.rows;
+    int tps = (T + NBLK * 4 - 1) / (NBLK * 4);
+    tps = (tps + 3) & ~3;
+    const int t_begin = (blk * 4 + wave) * tps;
+    const int t_end = min(T, t_begin + tps);
+    const int c0 = chunk * CW;
+
+    f32x4 acc[NRT][4];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[rt][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    float ssum[NRT] = {0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int t0 = t_begin; t0 < t_end; t0 += 4) {
+        const int t = t0 + g;
+        const bool ok = t < t_end;
+        const int tc = ok ? t : t_begin;
+        f32x4 b4 = *reinterpret_cast<const f32x4*>(big + (size_t)tc * H + c0 + 4 * i16);
+        float s[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) s[rt] = sm[(size_t)tc * R + rt * 16 + i16];
+        if (!ok) {
+            b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) s[rt] = 0.f;
+        }
+        bsum = bsum + b4;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            ssum[rt] += s[rt];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[rt][v] = mfma16x4_f32(s[rt], b4[v], acc[rt][v]);
+        }
+    }
+    // column sums: reduce over the 4 token slots (g) of the wave
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bsum[v] += __shfl_xor(bsum[v], 16, 64);
+        bsum[v] += __shfl_xor(bsum[v], 32, 64);
+    }
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        ssum[rt] += __shfl_xor(ssum[rt], 16, 64);
+        ssum[rt] += __shfl_xor(ssum[rt], 32, 64);
+    }
+    // block reduction of the 4 waves through LDS (fixed order: deterministic)
+    if (wave > 0) {
+        float* dst = red[wave - 1][lane];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(dst + (rt * 4 + v) * 4) = acc[rt][v];
+        // lanes with g == 0 carry the column sums: big (4 values) for lane i16, small (3 values)
+        if (g == 0) *reinterpret_cast<f32x4*>(dst + NRT * 16) = bsum;
+    }
+    __shared__ float red_s[3][NRT][16];
+    if (wave > 0 && g == 0) {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) red_s[wave - 1][rt][i16] = ssum[rt];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float* src = red[w][lane];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[rt][v] = acc[rt][v] + *reinterpret_cast<const f32x4*>(src + (rt * 4 + v) * 4);
+        if (g == 0) {
+            bsum = bsum + *reinterpret_cast<const f32x4*>(src + NRT * 16);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) ssum[rt] += red_s[w][rt][i16];
+        }
+    }
+    // D layout: acc[rt][v] row r = rt*16 + 4*(lane>>4) + e, col (lane & 15) -> column c = c0 + 4*(lane & 15) + v
+    float* P = L.partials + ((size_t)prob * NBLK + blk) * PSTRIDE;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = rt * 16 + 4 * g + e;
+            f32x4 o = {alpha * acc[rt][0][e], alpha * acc[rt][1][e], alpha * acc[rt][2][e], alpha * acc[rt][3][e]};
+            *reinterpret_cast<f32x4*>(P + (size_t)r * H + c0 + 4 * i16) = o;
+        }
+    if (g == 0) {
+        f32x4 o = {alpha * bsum[0], alpha * bsum[1], alpha * bsum[2], alpha * bsum[3]};
+        *reinterpret_cast<f32x4*>(P + R * H + R + c0 + 4 * i16) = o;
+        if (chunk == 0) {
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) P[R * H + rt * 16 + i16] = ssum[rt];
+        }
+    }
+}
+
+// grad layer layout: [wd (R x H) | bd (R) | wu (H x R) | bu (H)]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradLaunch L) {
+    const int seg = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= PSTRIDE) return;
+    const float* Pd = L.partials + (size_t)(2 * seg) * NBLK * PSTRIDE;       // dW_down problem
+    const float* Pu = L.partials + (size_t)(2 * seg + 1) * NBLK * PSTRIDE;   // dW_up^T problem
+    float sd = 0.f, su = 0.f;
+#pragma unroll 4
+    for (int b = 0; b < NBLK; ++b) {
+        sd += Pd[(size_t)b * PSTRIDE + i];
+        su += Pu[(size_t)b * PSTRIDE + i];
+    }
+    float* gl = L.seg[seg].grad;
+    if (i < R * H) {
+        gl[i] = sd;                                   // wd[r][c]
+        const int r = i / H, c = i - r * H;
+        gl[R * H + R + (size_t)c * R + r] = su;       // wu[c][r] (transpose of the computed [r][c])
+    } else if (i < R * H + R) {
+        gl[i] = sd;                                   // bd[r] = sum dz
+    } else {
+        gl[R * H + R + H * R + (i - R * H - R)] = su;  // bu[c] = s * sum dy
+    }
+}
+
+}  // namespace
+
+extern "C" long feddat_adapter_wgrad_workspace_elems(int nseg) { return (long)nseg * 2 * NBLK * PSTRIDE; }
+
+extern "C" int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems,
+                                    int Hd, int r, hipStream_t stream) {
+    FD_CHECK_ARG(segs && nseg >= 1 && nseg <= 2 && partials && Hd == H && r == R);
+    FD_CHECK_ARG(partials_elems >= (long)nseg * 2 * NBLK * PSTRIDE);
+    WgradLaunch L;
+    L.nseg = nseg;
+    L.partials = partials;
+    for (int s = 0; s < nseg; ++s) {
+        FD_CHECK_ARG(segs[s].x && segs[s].dy && segs[s].z && segs[s].dz && segs[s].grad && segs[s].rows > 0);
+        L.seg[s] = segs[s];
+    }
+    if (nseg == 1) L.seg[1] = L.seg[0];
+    hipLaunchKernelGGL(wgrad_kernel, dim3(NCH, NBLK, 2 * nseg), dim3(256), 0, stream, L);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((PSTRIDE + 255) / 256, nseg), dim3(256), 0, stream, L);
+    FD_LAUNCH_RET();
+}

@@ -194,7 +194,7 @@ class ViltDatEngine:
         self.dqkv = b16(R2, 3 * H)
         self.z = f32(R2, self.r)
         self.dz = f32(R2, self.r)
-        self.wpart = f32(self.ksplit, self.ad_layer_numel)
+        self.wpart = f32(L.adapter_wgrad_workspace_elems(2))
         self._segs_cache: Dict = {}
         self.graph = None
         self.sched = dict(warmup=1, total=2)
@@ -395,21 +395,21 @@ class ViltDatEngine:
         self._adapter_wgrads(0, self.l0["h3"], -R, cur)
 
     def _adapter_wgrads(self, layer: int, x, x_delta_s: int, dy):
-        """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146):
-        exact fp32 MFMA, split over tokens, deterministic reduction straight into the flat gradient buffers."""
-        R, H, r, ks = self.R, self.H, self.r, self.ksplit
-        n = self.ad_layer_numel
-        o_wd, o_bd, o_wu, o_bu = 0, r * H, r * H + r, r * H + r + H * r
-        part = self.wpart
-        for a, row0, xrow0, sc in ((0, 0, 0, 0.5), (1, R, R + x_delta_s, 1.0)):
-            if a not in self.opt_adapters:
-                continue
-            dy_s, z_s, dz_s, x_s = dy[row0:], self.z[row0:], self.dz[row0:], x[xrow0:]
-            L.sgemm_f32(dy_s, 1, H, z_s, r, 1, H, r, R, part[:, o_wu:], ldo=r, ksplit=ks, out_split_stride=n,
-                        alpha=sc, colsum=part[:, o_bu:], colsum_split_stride=n)
-            L.sgemm_f32(dz_s, 1, r, x_s, H, 1, r, H, R, part[:, o_wd:], ldo=H, ksplit=ks, out_split_stride=n,
-                        colsum=part[:, o_bd:], colsum_split_stride=n)
-            L.reduce_partials(part, n, ks, n, self.ad[a].g[layer * n:(layer + 1) * n])
+        """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146)
+        for adapter_0 (rows [0,R)) and adapter_1 (rows [R,2R)): exact fp32 MFMA, split over tokens, deterministic
+        reduction straight into the flat gradient buffers."""
+        key = ("wg", layer, x.data_ptr(), dy.data_ptr(), self.opt_adapters)
+        if key not in self._segs_cache:
+            R, n = self.R, self.ad_layer_numel
+            segs = []
+            for a, row0, xrow0, sc in ((0, 0, 0, 0.5), (1, R, R + x_delta_s, 1.0)):
+                if a in self.opt_adapters:
+                    segs.append(dict(x=x[xrow0:], dy=dy[row0:], z=self.z[row0:], dz=self.dz[row0:],
+                                     grad=self.ad[a].g[layer * n:(layer + 1) * n], rows=R, scale=sc))
+            self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
+        segs = self._segs_cache[key]
+        if segs is not None:
+            L.adapter_wgrad(segs, self.wpart)
 
     # ------------------------------------------------------------------------------------------ train step
     def begin_local_update(self, task: str, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,

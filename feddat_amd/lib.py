@@ -26,6 +26,10 @@ class AdapterSeg(C.Structure):
                 ("bd", vp * 2), ("bu", vp * 2)]
 
 
+class WgradSeg(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("z", vp), ("dz", vp), ("grad", vp), ("rows", i32), ("scale", f32)]
+
+
 _SIGS = {
     "feddat_abi_version": [],
     "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
@@ -37,6 +41,8 @@ _SIGS = {
     "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_pack": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "feddat_adapter_wgrad_workspace_elems": [i32],
+    "feddat_adapter_wgrad": [C.POINTER(WgradSeg), i32, vp, i64, i32, i32, vp],
     "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
@@ -80,7 +86,7 @@ def load() -> C.CDLL:
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = i32
+        fn.restype = i64 if name.endswith("_workspace_elems") else i32
     if lib.feddat_abi_version() != 1:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
     _lib = lib
@@ -188,6 +194,24 @@ def adapter_bwd(x, dy, dx, segs_arr, T, *, dx_bf16=None, z_out=None, dz_out=None
     _dev(x, dy, dx)
     _chk(load().feddat_adapter_bwd(_p(x), _p(dy), _p(dx), _p(dx_bf16), _p(z_out), _p(dz_out), T, H, r, segs_arr,
                                    len(segs_arr), _stream()), "feddat_adapter_bwd")
+
+
+def make_wgrad_segs(segs: Sequence[dict]):
+    arr = (WgradSeg * len(segs))()
+    for s, d in zip(arr, segs):
+        s.x, s.dy, s.z, s.dz, s.grad = (d[k].data_ptr() for k in ("x", "dy", "z", "dz", "grad"))
+        s.rows, s.scale = d["rows"], d["scale"]
+    return arr
+
+
+def adapter_wgrad_workspace_elems(nseg: int) -> int:
+    return int(load().feddat_adapter_wgrad_workspace_elems(nseg))
+
+
+def adapter_wgrad(segs_arr, partials, H=768, r=48):
+    _dev(partials)
+    _chk(load().feddat_adapter_wgrad(segs_arr, len(segs_arr), _p(partials), partials.numel(), H, r, _stream()),
+         "feddat_adapter_wgrad")
 
 
 def adapter_pack(wd, wu, wd16, wdT16, wu16, wuT16, H=768, r=48):

@@ -106,6 +106,22 @@ int feddat_adapter_fwd(const float* x, float* out, int T, int H, int r, const fe
  * db_up = scale * sum_t dy, dW_down = dz^T x, db_down = sum_t dz. */
 int feddat_adapter_bwd(const float* x, const float* dy, float* dx, void* dx_bf16, float* z_out, float* dz_out, int T,
                        int H, int r, const feddat_adapter_seg* segs, int nseg, hipStream_t stream);
+/* Weight gradients of the trainable adapter of up to two row segments, from the z/dz written by
+ * feddat_adapter_bwd: grad = flat fp32 [wd (r x H) | bd (r) | wu (H x r) | bu (H)] (the state-dict order of one
+ * layer's adapter), fully overwritten.  x, dy: fp32 [rows, H] (row stride H); z, dz: fp32 [rows, r].
+ * partials: scratch of feddat_adapter_wgrad_workspace_elems(nseg) floats. */
+typedef struct {
+    const float* x;
+    const float* dy;
+    const float* z;
+    const float* dz;
+    float* grad;
+    int rows;
+    float scale;
+} feddat_wgrad_seg;
+long feddat_adapter_wgrad_workspace_elems(int nseg);
+int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int H, int r,
+                         hipStream_t stream);
 /* fp32 master [wd(r*H), bd(r), wu(H*r), bu(H)] -> bf16 wd, wdT, wu, wuT. */
 int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* wdT_bf16, void* wu_bf16,
                         void* wuT_bf16, int H, int r, hipStream_t stream);

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     src = open(os.path.join(ROOT, "include", "feddat_hip.h")).read()
-    return sorted(set(re.findall(r"^int (feddat_[a-z0-9_]+)\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long) (feddat_[a-z0-9_]+)\(", src, flags=re.M)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():

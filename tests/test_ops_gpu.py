@@ -199,8 +199,13 @@ def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
     L.adapter_bwd(x, dy, dx, segs, T, dx_bf16=dx16, z_out=z, dz_out=dz)
     dxg = torch.from_numpy(g["gating.dx"]).reshape(-1, 768).to(DEV)
     dxs = torch.from_numpy(g["adapter_1.dx"]).reshape(-1, 768).to(DEV)
-    assert (dx[:h] - dxg[:h]).abs().max() < 2e-2   # |dx - dy| ~ 1, bf16 operands
-    assert (dx[h:] - dxs[h:]).abs().max() < 2e-2
+    # |dx - dy| ~ 1 with bf16 operands -> ~1e-3 typical error.  A bottleneck unit whose pre-activation is within
+    # bf16 noise of 0 may flip its ReLU mask relative to the fp32 reference; one flip moves that token's dx row by
+    # up to |g| * |Wd| ~ 0.1, so the bound on the max is looser than the bound on the 99.9th percentile.
+    for a_, b_ in ((dx[:h], dxg[:h]), (dx[h:], dxs[h:])):
+        d_ = (a_ - b_).abs().flatten()
+        assert float(torch.quantile(d_, 0.999)) < 1e-2
+        assert float(d_.max()) < 0.2
     assert rel_err(dx16, dx) < 1e-2
     # weight gradients from (z, dz) with the exact-fp32 MFMA GEMM; compare with an fp32 restatement on the SAME
     # rows (the golden weight grads cover all T rows, ours half of them per mode)
@@ -224,6 +229,16 @@ def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
         assert rel_err(dWd, ref_dWd) < 2e-2
         assert rel_err(dbu, dy_.sum(0) * sc) < 1e-5
         assert rel_err(dbd, dzz.sum(0)) < 2e-2
+        # the dedicated weight-gradient kernel (what the engine uses) must agree with the generic fp32 GEMM
+        grad = torch.full((48 * 768 + 48 + 768 * 48 + 768,), float("nan"), device=DEV)
+        part = torch.empty(L.adapter_wgrad_workspace_elems(1), device=DEV)
+        L.adapter_wgrad(L.make_wgrad_segs([dict(x=x[lo:], dy=dy[lo:], z=z[lo:], dz=dz[lo:], grad=grad, rows=n,
+                                                scale=sc)]), part)
+        o = 48 * 768
+        assert (grad[:o].view(48, 768) - dWd).abs().max() < 1e-4 * float(dWd.abs().max())
+        assert (grad[o:o + 48] - dbd).abs().max() < 1e-4 * float(dbd.abs().max())
+        assert (grad[o + 48:o + 48 + o].view(768, 48) - dWu).abs().max() < 1e-4 * float(dWu.abs().max())
+        assert (grad[o + 48 + o:] - dbu).abs().max() < 1e-4 * float(dbu.abs().max())
 
 
 def test_adapter_full_size_and_ragged_rows(L):
@@ -255,6 +270,28 @@ def test_adapter_full_size_and_ragged_rows(L):
     ref1 = x[h:] + ref_ad(x[h:], ads[1])
     assert (out[:h] - ref0).abs().max() < 2e-3
     assert (out[h:] - ref1).abs().max() < 2e-3
+    # weight gradients at full size (T = 5920 + 7 and 5920 rows) against fp64
+    dy = torch.randn(T, 768, generator=g).to(DEV)
+    dx = torch.empty_like(x)
+    z = torch.empty(T, 48, device=DEV)
+    dz = torch.empty(T, 48, device=DEV)
+    segs_b = L.make_segs([
+        dict(row_begin=0, row_end=h, train_slot=0, adapters=[dict(ads[0], scale=0.5), dict(ads[2], scale=0.5)]),
+        dict(row_begin=h, row_end=T, train_slot=0, adapters=[dict(ads[1], scale=1.0)]),
+    ])
+    L.adapter_bwd(x, dy, dx, segs_b, T, z_out=z, dz_out=dz)
+    n = 48 * 768 + 48 + 768 * 48 + 768
+    grads = torch.full((2, n), float("nan"), device=DEV)
+    part = torch.empty(L.adapter_wgrad_workspace_elems(2), device=DEV)
+    L.adapter_wgrad(L.make_wgrad_segs([
+        dict(x=x, dy=dy, z=z, dz=dz, grad=grads[0], rows=h, scale=0.5),
+        dict(x=x[h:], dy=dy[h:], z=z[h:], dz=dz[h:], grad=grads[1], rows=T - h, scale=1.0)]), part)
+    o = 48 * 768
+    for k, (lo, hi, sc) in enumerate(((0, h, 0.5), (h, T, 1.0))):
+        xd, dyd, zd, dzd = (t[lo:hi].double() for t in (x, dy, z, dz))
+        ref = torch.cat([(dzd.t() @ xd).flatten(), dzd.sum(0), (sc * dyd.t() @ zd).flatten(), sc * dyd.sum(0)])
+        err = (grads[k].double() - ref).abs().max() / ref.abs().max()
+        assert float(err) < 1e-5, (k, float(err))
 
 
 # ------------------------------------------------------------------ exact fp32 small GEMM
