@@ -2,8 +2,8 @@
 // (HF ViltSelfAttention: softmax(Q K^T / sqrt(64) + mask) V; reference call site src/modeling/vilt.py:127,
 // backward = autograd through it from task_trainer.py:302,323).
 //
-// One workgroup (4 waves) per (sample, head).  S <= 256 so Q, K, V (and dO in the backward) of one head live in
-// LDS for the whole kernel (row-major [S_pad][64] bf16, 16-byte chunks XOR-swizzled by (row & 7) so that the
+// One workgroup (4 waves) per (sample, head) (two per (sample, head) in the backward).  S <= 256 so the operands
+// of one head live in LDS for the whole kernel (row-major [S_pad][64] bf16, 16-byte chunks XOR-swizzled by (row & 7) so that the
 // ds_read_b128 row-fragment reads are conflict-free).  No S x S matrix ever reaches HBM: scores stay in MFMA
 // accumulators; the only saved statistic is the per-row log-sum-exp.
 //
@@ -138,6 +138,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
 }
 
+// Backward, split into two independent block roles (blockIdx.y) so that each block keeps only two of the four
+// [S_pad x 64] operands in LDS (3 blocks / 12 waves per CU instead of 1 block / 4 waves):
+//   role 0 (dK, dV): waves own 16-key tiles; Q and dO live in LDS (row + transposed fragments), the tile's K / V row
+//                    fragments come straight from HBM into registers; scores in [q rows, key col] orientation.
+//   role 1 (dQ):     waves own 16-query tiles; K and V live in LDS, the tile's Q / dO fragments, LSE and
+//                    D = rowsum(dO * O) come from HBM; scores in [key rows, q col] orientation.
+__device__ __forceinline__ bf16x8 gload_frag(const bf16* base, long ld, int row, int S, int chunk) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < S) v = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + chunk * 8);
+    return v;
+}
+
 template <int NKS>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask,
                                                        const bf16* __restrict__ ctx, const float* __restrict__ lse,
@@ -145,26 +157,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                                                        int heads) {
     constexpr int S_pad = NKS * 32, NKT = NKS * 2, NQT = NKS * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qs = smem;
-    char* Ks = Qs + S_pad * ROWB;
-    char* Vs = Ks + S_pad * ROWB;
-    char* Gs = Vs + S_pad * ROWB;  // dO
-    float* Dv = reinterpret_cast<float*>(Gs + S_pad * ROWB);
+    char* M0 = smem;                  // role 0: Q   | role 1: K
+    char* M1 = M0 + S_pad * ROWB;     // role 0: dO  | role 1: V
+    float* Dv = reinterpret_cast<float*>(M1 + S_pad * ROWB);
     float* Ls = Dv + S_pad;
     float* kvalid = Ls + S_pad;  // 1 / 0 per key
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int role = blockIdx.y;
     const int H = heads * D;
     const long ld = 3L * H;
     const bf16* base = qkv + (size_t)b * S * ld + h * D;
-    load_head(base, ld, S, S_pad, Qs, tid);
-    load_head(base + H, ld, S, S_pad, Ks, tid);
-    load_head(base + 2 * H, ld, S, S_pad, Vs, tid);
-    // dO into LDS, and Dv[q] = sum_d dO[q][d] * O[q][d]
-    {
-        const bf16* gO = ctx + (size_t)b * S * H + h * D;
-        const bf16* gG = dctx + (size_t)b * S * H + h * D;
+    const bf16* gO = ctx + (size_t)b * S * H + h * D;
+    const bf16* gG = dctx + (size_t)b * S * H + h * D;
+    const int g = lane >> 4, i16 = lane & 15;
+    bf16* dq_base = dqkv + (size_t)b * S * ld + h * D;
+    for (int k = tid; k < S_pad; k += 256) {
+        Ls[k] = k < S ? lse[((size_t)b * heads + h) * S + k] : 0.f;
+        kvalid[k] = (k < S && (!kmask || kmask[(size_t)b * S + k])) ? 1.f : 0.f;
+    }
+
+    if (role == 0) {
+        load_head(base, ld, S, S_pad, M0, tid);   // Q
+        // dO into LDS, and Dv[q] = sum_d dO[q][d] * O[q][d]
         for (int idx = tid; idx < S_pad * 8; idx += 256) {
             const int row = idx >> 3, chunk = idx & 7;
             bf16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -175,114 +191,118 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) part += (float)gv[e] * (float)ov[e];
             }
-            *reinterpret_cast<bf16x8*>(Gs + sw_off(row, chunk)) = gv;
+            *reinterpret_cast<bf16x8*>(M1 + sw_off(row, chunk)) = gv;
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 4, 64);
             if (chunk == 0) Dv[row] = part;
         }
-        for (int k = tid; k < S_pad; k += 256) {
-            Ls[k] = k < S ? lse[((size_t)b * heads + h) * S + k] : 0.f;
-            kvalid[k] = (k < S && (!kmask || kmask[(size_t)b * S + k])) ? 1.f : 0.f;
-        }
-    }
-    __syncthreads();
-
-    const int g = lane >> 4, i16 = lane & 15;
-    bf16* dq_base = dqkv + (size_t)b * S * ld + h * D;
-
-    // ---- phase 1: dK, dV.  wave owns key tiles; scores in [q rows, key col] orientation ----
-    for (int kt = wave; kt < NKT; kt += 4) {
-        if (kt * 16 >= S) break;
-        const int key = kt * 16 + i16;
-        const bf16x8 kf0 = row_frag(Ks, key, g), kf1 = row_frag(Ks, key, 4 + g);
-        const bf16x8 vf0 = row_frag(Vs, key, g), vf1 = row_frag(Vs, key, 4 + g);
-        const float kv = kvalid[key];
-        f32x4 dv[4], dk[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll 1
-        for (int qs = 0; qs < NKS; ++qs) {
-            if (qs * 32 >= S) break;
-            f32x4 p[2], ds[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int qrow = (2 * qs + t) * 16;
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                sc = mfma16x32(row_frag(Qs, qrow + i16, g), kf0, sc);
-                sc = mfma16x32(row_frag(Qs, qrow + i16, 4 + g), kf1, sc);
-                dp = mfma16x32(row_frag(Gs, qrow + i16, g), vf0, dp);
-                dp = mfma16x32(row_frag(Gs, qrow + i16, 4 + g), vf1, dp);
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qrow + 4 * g);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + qrow + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = kv * __expf(sc[e] * 0.125f - l4[e]);
-                    p[t][e] = pe;
-                    ds[t][e] = pe * (dp[e] - d4[e]) * 0.125f;
-                }
-            }
-            const bf16x8 pb = cvt8(p[0], p[1]);
-            const bf16x8 dsb = cvt8(ds[0], ds[1]);
-            const int r0a = (2 * qs) * 16 + 4 * g, r0b = (2 * qs + 1) * 16 + 4 * g;
+        __syncthreads();
+        const char* Qs = M0;
+        const char* Gs = M1;
+        for (int kt = wave; kt < NKT; kt += 4) {
+            if (kt * 16 >= S) break;
+            const int key = kt * 16 + i16;
+            const bf16x8 kf0 = gload_frag(base + H, ld, key, S, g), kf1 = gload_frag(base + H, ld, key, S, 4 + g);
+            const bf16x8 vf0 = gload_frag(base + 2 * H, ld, key, S, g), vf1 = gload_frag(base + 2 * H, ld, key, S, 4 + g);
+            const float kv = kvalid[key];
+            f32x4 dv[4], dk[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = mfma16x32(tr_frag8(Gs, r0a, r0b, dt * 16, lane), pb, dv[dt]);
-                dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
+                dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        }
-        if (key < S) {
-            bf16* ok = dq_base + (size_t)key * ld + H;
-            bf16* ov = dq_base + (size_t)key * ld + 2 * H;
+#pragma unroll 2
+            for (int qs = 0; qs < NKS; ++qs) {
+                if (qs * 32 >= S) break;
+                f32x4 p[2], ds[2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                *reinterpret_cast<bf16x4*>(ok + dt * 16 + 4 * g) = cvt4(dk[dt]);
-                *reinterpret_cast<bf16x4*>(ov + dt * 16 + 4 * g) = cvt4(dv[dt]);
-            }
-        }
-    }
-
-    // ---- phase 2: dQ.  wave owns query tiles; scores in [key rows, q col] orientation ----
-    for (int qt = wave; qt < NQT; qt += 4) {
-        if (qt * 16 >= S) break;
-        const int q = qt * 16 + i16;
-        const bf16x8 qf0 = row_frag(Qs, q, g), qf1 = row_frag(Qs, q, 4 + g);
-        const bf16x8 gf0 = row_frag(Gs, q, g), gf1 = row_frag(Gs, q, 4 + g);
-        const float lq = Ls[q], dq_ = Dv[q];
-        f32x4 dq[4];
+                for (int t = 0; t < 2; ++t) {
+                    const int qrow = (2 * qs + t) * 16;
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc = mfma16x32(row_frag(Qs, qrow + i16, g), kf0, sc);
+                    sc = mfma16x32(row_frag(Qs, qrow + i16, 4 + g), kf1, sc);
+                    dp = mfma16x32(row_frag(Gs, qrow + i16, g), vf0, dp);
+                    dp = mfma16x32(row_frag(Gs, qrow + i16, 4 + g), vf1, dp);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qrow + 4 * g);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + qrow + 4 * g);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (ks * 32 >= S) break;
-            f32x4 ds[2];
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = kv * __expf(sc[e] * 0.125f - l4[e]);
+                        p[t][e] = pe;
+                        ds[t][e] = pe * (dp[e] - d4[e]) * 0.125f;
+                    }
+                }
+                const bf16x8 pb = cvt8(p[0], p[1]);
+                const bf16x8 dsb = cvt8(ds[0], ds[1]);
+                const int r0a = (2 * qs) * 16 + 4 * g, r0b = (2 * qs + 1) * 16 + 4 * g;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int krow = (2 * ks + t) * 16;
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                sc = mfma16x32(row_frag(Ks, krow + i16, g), qf0, sc);
-                sc = mfma16x32(row_frag(Ks, krow + i16, 4 + g), qf1, sc);
-                dp = mfma16x32(row_frag(Vs, krow + i16, g), gf0, dp);
-                dp = mfma16x32(row_frag(Vs, krow + i16, 4 + g), gf1, dp);
-                const f32x4 kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = kv4[e] * __expf(sc[e] * 0.125f - lq);
-                    ds[t][e] = pe * (dp[e] - dq_) * 0.125f;
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma16x32(tr_frag8(Gs, r0a, r0b, dt * 16, lane), pb, dv[dt]);
+                    dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
                 }
             }
-            const bf16x8 dsb = cvt8(ds[0], ds[1]);
-            const int r0a = (2 * ks) * 16 + 4 * g, r0b = (2 * ks + 1) * 16 + 4 * g;
+            if (key < S) {
+                bf16* ok = dq_base + (size_t)key * ld + H;
+                bf16* ov = dq_base + (size_t)key * ld + 2 * H;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<bf16x4*>(ok + dt * 16 + 4 * g) = cvt4(dk[dt]);
+                    *reinterpret_cast<bf16x4*>(ov + dt * 16 + 4 * g) = cvt4(dv[dt]);
+                }
+            }
         }
-        if (q < S) {
-            bf16* oq = dq_base + (size_t)q * ld;
+    } else {
+        load_head(base + H, ld, S, S_pad, M0, tid);       // K
+        load_head(base + 2 * H, ld, S, S_pad, M1, tid);   // V
+        __syncthreads();
+        const char* Ks = M0;
+        const char* Vs = M1;
+        for (int qt = wave; qt < NQT; qt += 4) {
+            if (qt * 16 >= S) break;
+            const int q = qt * 16 + i16;
+            const bf16x8 qf0 = gload_frag(base, ld, q, S, g), qf1 = gload_frag(base, ld, q, S, 4 + g);
+            const bf16x8 gf0 = gload_frag(gG, H, q, S, g), gf1 = gload_frag(gG, H, q, S, 4 + g);
+            const bf16x8 of0 = gload_frag(gO, H, q, S, g), of1 = gload_frag(gO, H, q, S, 4 + g);
+            float dq_ = 0.f;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt]);
+            for (int e = 0; e < 8; ++e) dq_ += (float)gf0[e] * (float)of0[e] + (float)gf1[e] * (float)of1[e];
+            dq_ += __shfl_xor(dq_, 16, 64);
+            dq_ += __shfl_xor(dq_, 32, 64);
+            const float lq = Ls[q];
+            f32x4 dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks * 32 >= S) break;
+                f32x4 ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int krow = (2 * ks + t) * 16;
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc = mfma16x32(row_frag(Ks, krow + i16, g), qf0, sc);
+                    sc = mfma16x32(row_frag(Ks, krow + i16, 4 + g), qf1, sc);
+                    dp = mfma16x32(row_frag(Vs, krow + i16, g), gf0, dp);
+                    dp = mfma16x32(row_frag(Vs, krow + i16, 4 + g), gf1, dp);
+                    const f32x4 kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = kv4[e] * __expf(sc[e] * 0.125f - lq);
+                        ds[t][e] = pe * (dp[e] - dq_) * 0.125f;
+                    }
+                }
+                const bf16x8 dsb = cvt8(ds[0], ds[1]);
+                const int r0a = (2 * ks) * 16 + 4 * g, r0b = (2 * ks + 1) * 16 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
+            }
+            if (q < S) {
+                bf16* oq = dq_base + (size_t)q * ld;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt]);
+            }
         }
     }
 }
@@ -335,13 +355,13 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
                                const void* dctx, void* dqkv, int B, int S, int heads, hipStream_t stream) {
     FD_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && B > 0 && S > 0 && S <= 256 && heads > 0);
     const int nks = (S + 31) / 32;
-    const int lds = nks * 32 * ROWB * 4 + nks * 32 * 4 * 3;
+    const int lds = nks * 32 * ROWB * 2 + nks * 32 * 4 * 3;
     static bool bdone[9] = {false};
-#define NKS_MAX_LDS_B(N) ((N) * 32 * ROWB * 4 + (N) * 32 * 4 * 3)
+#define NKS_MAX_LDS_B(N) ((N) * 32 * ROWB * 2 + (N) * 32 * 4 * 3)
 #define ATTN_BWD(N)                                                                                           \
     case N:                                                                                                   \
         if (set_lds(attn_bwd_kernel<N>, NKS_MAX_LDS_B(N), bdone[N])) return FEDDAT_ELAUNCH;                                        \
-        hipLaunchKernelGGL(attn_bwd_kernel<N>, dim3(B * heads), dim3(256), lds, stream, (const bf16*)qkv,     \
+        hipLaunchKernelGGL(attn_bwd_kernel<N>, dim3(B * heads, 2), dim3(256), lds, stream, (const bf16*)qkv,     \
                            key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads);        \
         break;
     switch (nks) {

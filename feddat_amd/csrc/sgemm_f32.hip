@@ -21,14 +21,18 @@ struct SgemmArgs {
     float alpha;
 };
 
+// One block = one (i-tile, j-group) x one grid split; its 4 waves take interleaved K sub-ranges and are summed
+// through LDS in fixed order.  Loads are unconditional (indices clamped, values masked) so that the unrolled
+// loop keeps 8 steps of loads in flight -- these products are latency-bound, not bandwidth-bound.
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float red[3][64][JT * 4 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wid = blockIdx.x;
     const int itile = wid / p.jgroups, jgrp = wid - itile * p.jgroups;
-    if (itile * 16 >= p.I) return;
     const int split = blockIdx.y;
-    const int k_begin = split * p.kchunk;
-    const int k_end = min(p.K, k_begin + p.kchunk);
+    // grid split -> [k_lo, k_hi); inside it wave w owns k-steps w, w+4, w+8, ... (4 consecutive k each)
+    const int k_lo = split * p.kchunk;
+    const int k_hi = min(p.K, k_lo + p.kchunk);
     const int i16 = lane & 15, g = lane >> 4;
     const int i = itile * 16 + i16;
     const bool iv = i < p.I;
@@ -46,17 +50,43 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs p) {
 #pragma unroll
     for (int t = 0; t < JT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-#pragma unroll 4
-    for (int k0 = k_begin; k0 < k_end; k0 += 4) {
-        const int k = k0 + g;
-        const bool kv = k < k_end;
-        const float a = (iv && kv) ? ap[(size_t)k * p.sa_k] : 0.f;
-        asum += a;
+    const int kmax = max(k_hi - 1, k_lo);
+    constexpr int U = 4;   // manual unroll: 4 k-steps (20 loads) in flight per wave
+    for (int kb = k_lo + 4 * wave; kb < k_hi; kb += 16 * U) {
+        float a[U], b[U][JT];
 #pragma unroll
-        for (int t = 0; t < JT; ++t) {
-            const float b = (jv[t] && kv) ? bp[t][(size_t)k * p.sb_k] : 0.f;
-            acc[t] = mfma16x4_f32(a, b, acc[t]);
+        for (int u = 0; u < U; ++u) {
+            const int k = kb + 16 * u + g;
+            const int kc = min(k, kmax);
+            a[u] = ap[(size_t)kc * p.sa_k];
+#pragma unroll
+            for (int t = 0; t < JT; ++t) b[u][t] = bp[t][(size_t)kc * p.sb_k];
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool kv = (kb + 16 * u + g) < k_hi;
+            const float av = (iv && kv) ? a[u] : 0.f;
+            asum += av;
+#pragma unroll
+            for (int t = 0; t < JT; ++t) acc[t] = mfma16x4_f32(av, (jv[t] && kv) ? b[u][t] : 0.f, acc[t]);
+        }
+    }
+    asum += __shfl_xor(asum, 16, 64);
+    asum += __shfl_xor(asum, 32, 64);
+    if (wave > 0) {
+        float* dst = red[wave - 1][lane];
+#pragma unroll
+        for (int t = 0; t < JT; ++t) *reinterpret_cast<f32x4*>(dst + 4 * t) = acc[t];
+        dst[JT * 4] = asum;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float* src = red[w][lane];
+#pragma unroll
+        for (int t = 0; t < JT; ++t) acc[t] = acc[t] + *reinterpret_cast<const f32x4*>(src + 4 * t);
+        asum += src[JT * 4];
     }
     float* o = p.out + (size_t)split * p.out_split_stride;
 #pragma unroll
@@ -69,11 +99,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs p) {
             if (io < p.I) o[(size_t)io * p.ldo + j[t]] = p.alpha * acc[t][e] + bj;
         }
     }
-    if (p.colsum && jgrp == 0) {
-        asum += __shfl_xor(asum, 16, 64);
-        asum += __shfl_xor(asum, 32, 64);
-        if (g == 0 && iv) p.colsum[(size_t)split * p.colsum_split_stride + i] = p.alpha * asum;
-    }
+    if (p.colsum && jgrp == 0 && g == 0 && iv) p.colsum[(size_t)split * p.colsum_split_stride + i] = p.alpha * asum;
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, long stride, int nsplit,
@@ -102,8 +128,7 @@ extern "C" int feddat_sgemm_f32(const float* A, long sa_i, long sa_k, const floa
     p.kchunk = kchunk;
     const int itiles = (I + 15) / 16;
     p.jgroups = (J + 16 * JT - 1) / (16 * JT);
-    const int waves = itiles * p.jgroups;
-    hipLaunchKernelGGL(sgemm_kernel, dim3((waves + 3) / 4, ksplit), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(sgemm_kernel, dim3(itiles * p.jgroups, ksplit), dim3(256), 0, stream, p);
     FD_LAUNCH_RET();
 }
 

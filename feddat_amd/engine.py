@@ -312,12 +312,27 @@ class ViltDatEngine:
             L.adapter_fwd(a["h3"], nxt, self._segs(i, False, False), R2)
         self._pool(self.h_out, 2 * B)
 
+    def _sg(self, A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, out, ksplit=1, bias_j=None):
+        """Skinny exact-fp32 product; long contractions are split over the grid and reduced deterministically."""
+        if ksplit <= 1:
+            L.sgemm_f32(A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, out, bias_j=bias_j)
+            return
+        part = self._scratch1(ksplit * I * J)
+        L.sgemm_f32(A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, part, ksplit=ksplit, bias_j=bias_j,
+                    out_split_stride=I * J)
+        L.reduce_partials(part, I * J, ksplit, I * J, out)
+
+    def _scratch1(self, n):
+        if not hasattr(self, "_scr") or self._scr.numel() < n:
+            self._scr = torch.empty(n, device=self.dev)
+        return self._scr
+
     def _pool(self, h_last, nb: int):
         """ViltModel.layernorm on token 0 + ViltPooler (dense + tanh) -> self.pooled[:nb]."""
         H = self.H
         L.layernorm_fwd(h_last, self.lnf_g, self.lnf_b, self.ln_eps, nb, H, x_stride=self.S * H,
                         y_f32=self.cls_ln, stats=self.cls_st)
-        L.sgemm_f32(self.cls_ln, H, 1, self.pool_w, 1, H, nb, H, H, self.pooled, bias_j=self.pool_b)
+        self._sg(self.cls_ln, H, 1, self.pool_w, 1, H, nb, H, H, self.pooled, ksplit=4, bias_j=self.pool_b)
         L.tanh_fwd(self.pooled[:nb])
 
     def _head_fwd(self, pooled, slot: str, task: str):
@@ -325,13 +340,13 @@ class ViltDatEngine:
         B, H, C = self.B, self.H, self.C
         hp, s = self.head[task], self.hd[slot]
         pre = f"task_layer.{task}."
-        L.sgemm_f32(pooled, H, 1, hp.view(pre + "clf_fc0.weight"), 1, H, B, 2 * H, H, s["a0"],
-                    bias_j=hp.view(pre + "clf_fc0.bias"))
+        self._sg(pooled, H, 1, hp.view(pre + "clf_fc0.weight"), 1, H, B, 2 * H, H, s["a0"], ksplit=4,
+                 bias_j=hp.view(pre + "clf_fc0.bias"))
         L.layernorm_fwd(s["a0"], hp.view(pre + "clf_norm0.weight"), hp.view(pre + "clf_norm0.bias"), 1e-5, B, 2 * H,
                         y_f32=s["n0"], stats=s["st"])
         L.gelu_fwd(s["n0"], s["g0"])
-        L.sgemm_f32(s["g0"], 2 * H, 1, hp.view(pre + "clf_fc1.weight"), 1, 2 * H, B, C, 2 * H, s["logits"],
-                    bias_j=hp.view(pre + "clf_fc1.bias"))
+        self._sg(s["g0"], 2 * H, 1, hp.view(pre + "clf_fc1.weight"), 1, 2 * H, B, C, 2 * H, s["logits"], ksplit=16,
+                 bias_j=hp.view(pre + "clf_fc1.bias"))
         return s["logits"]
 
     def _head_bwd(self, pooled, slot: str, task: str, dpooled_out):
@@ -349,7 +364,7 @@ class ViltDatEngine:
         L.layernorm_bwd_full(self.dn0, s["a0"], s["st"], hp.view(pre + "clf_norm0.weight"), B, 2 * H, self.da0,
                              G("clf_norm0.weight"), G("clf_norm0.bias"))
         L.sgemm_f32(self.da0, 1, 2 * H, pooled, H, 1, 2 * H, H, B, G("clf_fc0.weight"), colsum=G("clf_fc0.bias"))
-        L.sgemm_f32(self.da0, 2 * H, 1, hp.view(pre + "clf_fc0.weight"), H, 1, B, H, 2 * H, dpooled_out)
+        self._sg(self.da0, 2 * H, 1, hp.view(pre + "clf_fc0.weight"), H, 1, B, H, 2 * H, dpooled_out, ksplit=8)
 
     def _adamw(self, grp: FlatGroup):
         L.adamw_flat(grp.p, grp.g, grp.m, grp.v, grp.seg_off, self._wd_vec(grp), grp.state, self.lr,
@@ -367,7 +382,7 @@ class ViltDatEngine:
         R, R2, B, H = self.R, 2 * self.R, self.B, self.H
         nb = 2 * B
         L.tanh_bwd(self.pooled, self.dpooled, self.dpre)
-        L.sgemm_f32(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln)
+        self._sg(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, ksplit=4)
         L.layernorm_bwd_dx(self.h_out, self.cls_st, self.lnf_g, nb, H, dy_f32=self.dcls_ln, x_stride=self.S * H,
                            out_f32=self.dcls)
         cur, oth = self.dh
