@@ -37,14 +37,21 @@ def get_average_net(server, c_models: List[Dict[str, torch.Tensor]], nums: Seque
     return server
 
 
-def allreduce_average(engine, world: int, num: float = 1.0, total: float = None):
+def allreduce_flat(flat: torch.Tensor, buf: torch.Tensor, num: float, total: float, prescale=None):
+    """buf = flat * num / total (device kernel, reference operation order) ; all_reduce(SUM) ; flat <- buf.
+    `prescale(acc, x, num, total)` defaults to the HIP kernel; the world_size-2 gloo test on CPU injects a host
+    stand-in so that rendezvous, collective and write-back are exercised without a GPU."""
     import torch.distributed as dist
+    (prescale or (lambda acc, x, n, t: L.fedavg_accumulate(acc, x, n, t, True)))(buf, flat, num, total)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    flat.copy_(buf)
+    return flat
+
+
+def allreduce_average(engine, world: int, num: float = 1.0, total: float = None):
     flat = engine.comm_flat()
     if not hasattr(engine, "_fedavg_buf"):
         engine._fedavg_buf = torch.empty_like(flat)
-    buf = engine._fedavg_buf
-    L.fedavg_accumulate(buf, flat, num, float(world) if total is None else float(total), True)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-    flat.copy_(buf)
+    allreduce_flat(flat, engine._fedavg_buf, num, float(world) if total is None else float(total))
     engine.repack_adapter(1)
     return flat

@@ -1,0 +1,245 @@
+"""Client trainer + FL outer loop mirroring the reference (src/train/visionlanguage_tasks/task_trainer.py,
+src/train/main.py) on the MI355X engine.
+
+  TaskTrainer.train(model, ...)        -> (0., model)      task_trainer.py:24-111
+  TaskTrainer.train_step(model, step, batch, optimizer, scheduler)  -> loss_0     task_trainer.py:266-330
+  TaskTrainer.create_optimizer(model)  -> handle           task_trainer.py:477-504
+  TaskTrainer.eval(model)              -> [score_gated, score_adapter0, score_adapter1]   task_trainer.py:211-246
+  get_average_net(server, c_models, nums, ordered_tasks, device)   main.py:50-65   (feddat_amd.fedavg)
+  main(argv)                           -> FL rounds x clients, same flags as main.py:262-323
+
+Mapping of the outer loop: the reference visits the clients sequentially on one device from identical server
+state (main.py:466-504).  Here one process owns one GPU and one or more clients; with torch.distributed initialised
+(backend "nccl" == RCCL) the per-round average is ONE all-reduce of the flat adapter_1 buffer over xGMI.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+from . import vilt_spec
+from .fedavg import allreduce_average, get_average_net  # noqa: F401  (re-exported: main.py:50)
+from .modeling import ViltContinualLearner, create_vilt_continual_learner_model
+
+
+class OptimizerHandle:
+    """What create_optimizer returns: the AdamW state lives on the device inside the engine (flat fp32 moments,
+    step counters); the handle records which adapters are members (requires_grad at creation time) and hparams."""
+
+    def __init__(self, adapters: Sequence[int], lr: float, eps: float, weight_decay: float):
+        self.adapters, self.lr, self.eps, self.weight_decay = tuple(adapters), lr, eps, weight_decay
+
+    def step(self):       # the fused train_step applies both AdamW sub-steps itself
+        pass
+
+    def zero_grad(self):
+        pass
+
+
+class SchedulerHandle:
+    def __init__(self, num_warmup_steps: int, num_training_steps: int):
+        self.num_warmup_steps, self.num_training_steps = num_warmup_steps, num_training_steps
+
+    def step(self):
+        pass
+
+
+def get_polynomial_decay_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, lr_end=0, power=1):
+    """HF signature used at task_trainer.py:53-59; lr_end=0 / power=1 is the only form the reference uses and the
+    only one the device-side schedule implements."""
+    if lr_end != 0 or power != 1:
+        raise L.FeddatHipError("only lr_end=0, power=1 (task_trainer.py:57-58) is implemented on device")
+    return SchedulerHandle(num_warmup_steps, num_training_steps)
+
+
+def kl_loss(output: torch.Tensor, target: torch.Tensor, temp: float = 3.0) -> torch.Tensor:
+    """task_trainer.py:506-516 (T^2 * KL_batchmean(log_softmax(out/T) || softmax(tgt/T))) via the fused loss kernel
+    (the BCE half of its output is ignored here)."""
+    B = output.shape[0]
+    buf = torch.empty(4 + 2 * B, device=output.device)
+    dl = torch.empty_like(output)
+    L.dat_loss_fwd_bwd(output.contiguous(), target.contiguous(), torch.zeros_like(output), dl, buf, temp)
+    return buf[1]
+
+
+class TaskTrainer:
+    """VQATrainerCross + TaskTrainer for the dat optimizer_mode (train_vqa_crossvqa.py:39-239, task_trainer.py)."""
+
+    def __init__(self, args, task_key: str, train_batches: List[Dict[str, torch.Tensor]],
+                 eval_batches: Optional[List[Dict[str, torch.Tensor]]] = None, logger=None):
+        self.args = args
+        self.task_key = task_key
+        self.vqa_train_dataloader = train_batches
+        self.vqa_test_dataloader = eval_batches or []
+        self.local_epochs = args.local_epochs
+        self.num_epochs = args.num_epochs                              # train_vqa_crossvqa.py:233
+        self.lr = args.lr
+        self.adam_epsilon, self.weight_decay, self.warmup_ratio = 1e-8, 1e-2, 0.1   # task_configs_fed.py:47-50
+        self.max_steps = len(train_batches) * self.num_epochs          # train_vqa_crossvqa.py:238
+        self.logger = logger or logging.getLogger("feddat_amd")
+        self.use_graph = getattr(args, "hip_graph", True)
+
+    def create_optimizer(self, model: ViltContinualLearner, mode: str = "dat") -> OptimizerHandle:
+        return OptimizerHandle(model.optimizer_adapters(), self.lr, self.adam_epsilon, self.weight_decay)
+
+    def train(self, model: ViltContinualLearner, *unused):
+        eng = model.engine
+        optimizer = self.create_optimizer(model, self.args.optimizer_mode)
+        scheduler = get_polynomial_decay_schedule_with_warmup(
+            optimizer, num_warmup_steps=int(self.max_steps * self.warmup_ratio), num_training_steps=self.max_steps,
+            lr_end=0, power=1)
+        eng.lr, eng.eps, eng.wd = optimizer.lr, optimizer.eps, optimizer.weight_decay
+        # adapter_1 -> adapter_2 copy, freeze, fresh moments + schedule          task_trainer.py:36-59
+        eng.begin_local_update(self.task_key, steps_per_epoch=len(self.vqa_train_dataloader),
+                               num_epochs=self.num_epochs, warmup_ratio=self.warmup_ratio,
+                               opt_adapters=optimizer.adapters)
+        model.adapter_requires_grad[2] = False
+        loss = None
+        for epoch in range(self.local_epochs):
+            for step, batch in enumerate(self.vqa_train_dataloader):
+                if self.args.debug > 0 and step > self.args.debug:     # task_trainer.py:82-83
+                    break
+                loss = self.train_step(model, step, batch, optimizer, scheduler, hooks=None, epoch=epoch)
+        return 0.0, model
+
+    def train_step(self, model: ViltContinualLearner, step, batch, optimizer=None, scheduler=None, hooks=None,
+                   epoch=None):
+        """One DAT + MKD step; returns loss_0 (BCE * num_labels of the P2 pass) as a 0-d device tensor.  The mode
+        switches the reference performs inside (activate_gating / set_active_adapter, task_trainer.py:284-312)
+        leave the model in the same final state: gating on, adapter_0 active."""
+        out = model.engine.train_step(batch, use_graph=self.use_graph)
+        model.activate_gating()
+        model.set_active_adapter("adapter_0")
+        return out[0]
+
+    @torch.no_grad()
+    def eval_one_loader(self, model: ViltContinualLearner, loader) -> float:
+        """VQA score (train_vqa_crossvqa.py:241-257; task_trainer.py:125-157): score of the arg-max answer."""
+        score, seen = 0.0, 0
+        for batch in loader:
+            _, logits = model(task_key=self.task_key, images=batch, texts=None)
+            tgt = batch["target_scores"].to(logits.device)
+            idx = logits.argmax(1, keepdim=True)       # host-side metric bookkeeping, not part of the hot path
+            score += float(tgt.gather(1, idx).sum())
+            seen += logits.shape[0]
+        return 100.0 * score / max(seen, 1)
+
+    def eval(self, model: ViltContinualLearner):
+        loader = self.vqa_test_dataloader
+        model.activate_gating()
+        s = self.eval_one_loader(model, loader)
+        model.deactivate_gating()
+        model.set_active_adapter("adapter_0")
+        s0 = self.eval_one_loader(model, loader)
+        model.deactivate_gating()
+        model.set_active_adapter("adapter_1")
+        s1 = self.eval_one_loader(model, loader)
+        return [s, s0, s1]
+
+
+# -------------------------------------------------------------------------------------------------------------
+def build_parser() -> argparse.ArgumentParser:
+    """Same flags as src/train/main.py:262-323 (unused ones are accepted and ignored) + synthetic-data knobs."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--encoder_name", default="vilt", choices=["vilt"])
+    p.add_argument("--portion", default=1.0, type=float)
+    p.add_argument("--optimizer_mode", default="dat", type=str)
+    p.add_argument("--pretrained_model_name", default=None, type=str)
+    p.add_argument("--climb_data_dir", type=str, default=None)
+    p.add_argument("--debug", type=int, default=0)
+    p.add_argument("--do_single", action="store_true")
+    p.add_argument("--do_train", action="store_true")
+    p.add_argument("--do_eval", action="store_true")
+    p.add_argument("--do_test", action="store_true")
+    p.add_argument("--adapter_config", default=None)
+    p.add_argument("--adapter_reduction_factor", type=int, default=0)
+    p.add_argument("--layers_to_freeze", type=int, default=0)
+    p.add_argument("--output_dir", type=str, default="./out")
+    p.add_argument("--do_wandb_logging", action="store_true")
+    p.add_argument("--wandb_freq", type=int, default=100)
+    p.add_argument("--comm_rounds", type=int, default=20)
+    p.add_argument("--local_epochs", type=int, default=1)
+    p.add_argument("--batch_size", type=int, default=32)
+    p.add_argument("--num_epochs", type=int, default=15)
+    p.add_argument("--val_batch_size", type=int, default=1)
+    p.add_argument("--num_workers", type=int, default=2)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--ordered_cl_tasks", type=str, default="domain")
+    p.add_argument("--lr", default=1e-4, type=float)
+    p.add_argument("--splits", nargs="*", default=["train", "val"])
+    p.add_argument("--checkpoint", type=str, default=None)
+    p.add_argument("--model_path", type=str, default=None)
+    # synthetic stand-ins for the private datasets / checkpoints (no network in this environment)
+    p.add_argument("--synthetic_steps", type=int, default=8, help="batches per client per round")
+    p.add_argument("--image_size", type=int, default=384)
+    p.add_argument("--num_layers", type=int, default=12)
+    p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
+    return p
+
+
+TASK_SETS = {   # main.py:352-359
+    "scene": ["clove_scene_a", "clove_scene_b", "clove_scene_c", "clove_scene_d", "clove_scene_e", "clove_scene_f"],
+    "function": ["clove_function_a", "clove_function_b", "clove_function_c", "clove_function_d", "clove_function_e"],
+    "domain": ["art", "abstract", "vizwiz", "toronto", "gqa"],
+}
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if "dat" not in args.optimizer_mode:
+        raise L.FeddatHipError("only --optimizer_mode dat is on the MI355X hot path (SURVEY.md section 2, row 13)")
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
+    log = logging.getLogger("feddat_amd")
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    tasks = TASK_SETS.get(args.ordered_cl_tasks, args.ordered_cl_tasks.split(","))
+    my_tasks = tasks[rank::world]                       # client -> GPU mapping
+    dev = torch.device("cuda", local)
+    params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)    # stand-in for from_pretrained
+    model = create_vilt_continual_learner_model(params, tasks, dev, args.batch_size, args.image_size,
+                                                args.num_layers, args.lr)
+    eng = model.engine
+    # personal parameters per client (main.py:440-450): head + adapter_0 + adapter_2
+    def personal(sd):
+        return {n: v.clone() for n, v in sd.items() if ("task" in n or "adapter_0" in n or "adapter_2" in n)}
+    personal_params = {t: personal(model.state_dict()) for t in my_tasks}
+    data = {t: [vilt_spec.synthetic_batch(args.batch_size, args.image_size, args.seed + 1000 * ti + s, device=dev)
+                for s in range(args.synthetic_steps)] for ti, t in enumerate(tasks) if t in my_tasks}
+    server_flat = eng.comm_flat().clone()
+    acc = torch.empty_like(server_flat)
+    for comm_round in range(args.comm_rounds):
+        for k, task_key in enumerate(my_tasks):
+            eng.comm_flat().copy_(server_flat)                      # main.py:472 deepcopy(server)
+            eng.repack_adapter(1)
+            model.load_state_dict(personal_params[task_key])        # main.py:473-478
+            trainer = TaskTrainer(args, task_key, data[task_key], data[task_key][:2], log)
+            trainer.train(model, comm_round)
+            personal_params[task_key] = personal(model.state_dict())     # main.py:493-497
+            # local pre-sum in client order, then (if distributed) one all-reduce: main.py:50-65
+            L.fedavg_accumulate(acc, eng.comm_flat(), 1.0, float(len(tasks)), k == 0)
+        if world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        server_flat.copy_(acc)
+        if comm_round % 5 == 0 or comm_round == args.comm_rounds - 1:   # main.py:520
+            for task_key in my_tasks:
+                eng.comm_flat().copy_(server_flat)
+                model.load_state_dict(personal_params[task_key])
+                model.after_load()
+                scores = TaskTrainer(args, task_key, data[task_key], data[task_key][:2], log).eval(model)
+                log.info("round %d %s test score server = %s", comm_round, task_key, scores)
+    if world > 1:
+        dist.destroy_process_group()
+    return model
+
+
+if __name__ == "__main__":
+    main()

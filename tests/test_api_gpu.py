@@ -1,0 +1,105 @@
+"""The drop-in mirrors of the reference's module API (feddat_amd.modeling / feddat_amd.train) -- written the way a
+test of the reference itself would read: build the model, flip adapter modes, run train(), average the clients."""
+import types
+
+import pytest
+import torch
+
+from oracle import feddat_oracle as O
+from tests.golden_util import load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def api():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import modeling, train
+    return types.SimpleNamespace(modeling=modeling, train=train)
+
+
+def _dev(b):
+    return {k: v.to(DEV) for k, v in b.items()}
+
+
+def test_adapter_module_modes_and_flags(api, golden_dir):
+    g = load(golden_dir, "g1_adapter.npz")
+    ad = api.modeling.Adapter(["adapter_0", "adapter_1", "adapter_2"], DEV)
+    for n, p in ad.named_parameters():
+        p.data.copy_(torch.from_numpy(g["p." + n]))
+    ad.refresh()
+    x = torch.from_numpy(g["x"]).to(DEV)
+    ad.deactivate_gating()
+    ad.set_active_adapter("adapter_1")
+    assert ad.adapter_1_down.weight.requires_grad and not ad.adapter_0_down.weight.requires_grad
+    assert not ad.adapter_2_up.bias.requires_grad
+    y = ad(x, x)
+    assert (y.cpu() - torch.from_numpy(g["adapter_1.y"])).abs().max() < 1.2e-2
+    ad.activate_gating()
+    ad.set_active_adapter("adapter_0")
+    assert ad.adapter_0_down.weight.requires_grad and not ad.adapter_1_down.weight.requires_grad
+    y = ad(x, x)
+    assert (y.cpu() - torch.from_numpy(g["gating.y"])).abs().max() < 1.2e-2
+    from feddat_amd.lib import FeddatHipError
+    with pytest.raises(FeddatHipError):
+        ad(x, x.clone())                     # only the adapter(h, h) form exists in the reference
+    with pytest.raises(FeddatHipError):
+        ad(x.cpu(), x.cpu())                 # no CPU path
+
+
+def test_adaptered_vilt_output(api):
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(768, 3072, generator=g) * 0.02).to(DEV)
+    b = (torch.randn(768, generator=g) * 0.02).to(DEV)
+    layer = types.SimpleNamespace(dense=types.SimpleNamespace(weight=w, bias=b))
+    mod = api.modeling.Adaptered_ViltOutput(layer, {"names": ["adapter_0", "adapter_1", "adapter_2"], "device": DEV})
+    x = torch.randn(2, 50, 3072, generator=g).to(DEV)
+    res = torch.randn(2, 50, 768, generator=g).to(DEV)
+    mod.adapter.deactivate_gating()
+    mod.adapter.set_active_adapter("adapter_1")
+    y = mod(x, res)
+    h = x.to(torch.bfloat16).float() @ w.to(torch.bfloat16).float().t() + b + res
+    a = mod.adapter
+    ref = O.adapter_single(h, h, a.adapter_1_down.weight.data, a.adapter_1_down.bias.data,
+                           a.adapter_1_up.weight.data, a.adapter_1_up.bias.data)
+    assert (y - ref).abs().max() < 5e-3
+
+
+def test_continual_learner_train_and_fedavg_round(api, golden_dir):
+    """Two clients x 3 train_steps + get_average_net, against the reference's own round (tests/golden/g5_round.npz)."""
+    r = load(golden_dir, "g5_round.npz")
+    tasks = ["art", "gqa"]
+    d = O.ViltDims(layers=2)
+    P = O.make_params(d, tasks, bias_std=0.02)
+    args = types.SimpleNamespace(local_epochs=1, num_epochs=15, lr=1e-4, optimizer_mode="dat", debug=0, hip_graph=False)
+    server = api.modeling.create_vilt_continual_learner_model(P, tasks, DEV, batch_size=4, image_size=224, num_layers=2)
+    assert len(server.comm_state_dict_names) == 8 and all("adapter_1" in n for n in server.comm_state_dict_names)
+    server_sd = {k: v.clone() for k, v in server.state_dict().items()}
+    c_models = []
+    for ci, t in enumerate(tasks):
+        server.load_state_dict(server_sd)                 # main.py:472 deepcopy(server) + personal params
+        server.adapter_requires_grad.update({0: True, 1: True})
+        batches = [_dev(O.synthetic_batch(4, 224, 777 + 10 * ci + s)) for s in range(3)]
+        trainer = api.train.TaskTrainer(args, t, batches)
+        score, c_model = trainer.train(server)
+        assert score == 0.0 and c_model is server
+        assert server.gating and server.active == "adapter_0"        # final mode of train_step, task_trainer.py:311-312
+        c_models.append({n: server.state_dict()[n].clone() for n in server.comm_state_dict_names})
+        for k in [k for k in r if k.startswith(f"personal.{t}.")]:
+            n = k[len(f"personal.{t}."):]
+            assert (server.state_dict()[n].cpu() - torch.from_numpy(r[k])).abs().max() < 1e-3, k
+    server.load_state_dict(server_sd)
+    api.train.get_average_net(server, c_models, [1, 1], tasks, DEV)
+    for k in [k[7:] for k in r if k.startswith("server.")]:
+        assert (server.state_dict()[k].cpu() - torch.from_numpy(r["server." + k])).abs().max() < 1e-3, k
+    # eval leaves the model in the adapter_1 state -> the next optimizer would not hold adapter_0 (reference quirk)
+    ev = api.train.TaskTrainer(args, "art", [], [_dev(O.synthetic_batch(4, 224, 5))]).eval(server)
+    assert len(ev) == 3 and server.optimizer_adapters() == (1,)
+
+
+def test_kl_loss_op(api, golden_dir):
+    g = load(golden_dir, "g2_loss.npz")
+    kl = api.train.kl_loss(torch.from_numpy(g["logits"]).to(DEV), torch.from_numpy(g["teacher"]).to(DEV))
+    assert abs(float(kl) - float(g["kl"])) < 1e-5
