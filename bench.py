@@ -86,6 +86,22 @@ def measure_gemms(L, gemms, iters=10):
     return tot_f / tot_t, tot_t, rows
 
 
+def profiled_traffic(kernel_substr="gemm_nt_v2_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_per_kernel.csv,
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+    FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
+    if not files:
+        return None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_substr in r["kernel"] and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
+            return {"bytes_per_launch": round((2 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024),
+                    "source": os.path.basename(files[-1]), "note": "average over the launches of one step (all shapes)"}
+    return None
+
+
 def cpu_baseline(params_cpu, B, res, task, budget_s=20.0):
     """The CPU restatement of the reference path (oracle/, validated against the reference's goldens) timed on
     this node's host cores on a BOUNDED sample of the same workload: same model / resolution / sequence length,
@@ -199,7 +215,7 @@ def main():
             out["roofline"] = {"kernel": "gemm_nt_kernel (K1, frozen-linear bf16 MFMA GEMM, all 13 launch shapes "
                                          "of one step, FLOP-weighted)",
                                "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16, 4), "traffic": profiled_traffic(),
                                "gemm_ms_per_step": round(tsum * 1e3, 3), "shapes": rows}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline({k: v.float().cpu() for k, v in params.items()}, B, res, task)
