@@ -28,21 +28,29 @@ __device__ __forceinline__ bf16x8 load_x8(const float* p) {
     return cvt8(a, b);
 }
 
-// Z^T[a][nt] += W[a] (rows r) x X^T (cols tok), contraction over features [k_begin, k_begin + 32 * nks).
+// Z^T[a][nt] += W[a] (rows r) x X^T (cols tok), contraction over the wave's quarter of the 768 features
+// (k-steps ks0 .. ks0+5 of 32 features).  Contraction slots are permuted: in k-step q lane group g supplies features
+// 32q + 4g + (0..3) and 32q + 16 + 4g + (0..3) -- exactly the two float4 this lane needs again for the residual add of
+// output tiles 2q and 2q+1 (accumulator layout: 4 consecutive columns 16 ct + 4g), so the fp32 row values are kept in
+// registers (`keep`) and x is read from HBM once.  The weight operand uses the same permutation: `w` is the
+// slot-permuted bf16 copy written by adapter_pack ([48][768], position 32q + 8g + 4*half + j), one 16-byte load.
 template <int NA>
-__device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const bf16* const* wd, int lane, int ks0,
-                                          f32x4 (&z)[2][NT]) {
+__device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const bf16* const* w, int lane, int ks0,
+                                          f32x4 (&z)[2][NT], f32x4 (&keep)[KS / 4][2]) {
     const int g = lane >> 4, i16 = lane & 15;
 #pragma unroll
     for (int k = 0; k < KS / 4; ++k) {
-        const int ks = ks0 + k;
-        const bf16x8 xf = load_x8(xrow + ks * 32 + g * 8);
+        const int q = ks0 + k;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 4 * g);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 16 + 4 * g);
+        keep[k][0] = x0;
+        keep[k][1] = x1;
+        const bf16x8 xf = cvt8(x0, x1);
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8 wf =
-                    *reinterpret_cast<const bf16x8*>(wd[a] + (size_t)(nt * 16 + i16) * H + ks * 32 + g * 8);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w[a] + (size_t)(nt * 16 + i16) * H + q * 32 + g * 8);
                 z[a][nt] = mfma16x32(wf, xf, z[a][nt]);
             }
     }
@@ -102,7 +110,8 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z);
+    f32x4 xk[KS / 4][2];
+    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z, xk);
     ksplit_reduce<NA>(part, wave, lane, z);
 
     bf16x8 zb01[NA], zb2[NA];
@@ -117,11 +126,11 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
         zb01[a] = cvt8(z[a][0], z[a][1]);
         zb2[a] = pad8(z[a][2]);
     }
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < CT / 4; ++k) {
         const int ct = wave * (CT / 4) + k;
         const int c = ct * 16 + 4 * g;
-        f32x4 o = *reinterpret_cast<const f32x4*>(xrow + c);
+        f32x4 o = xk[k >> 1][k & 1];           // x[row][c .. c+3], kept from the down-projection
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             bf16x8 w01, w2;
@@ -173,8 +182,9 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
             z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z);
-    down_proj<NA>(dyrow, wuT, lane, wave * (KS / 4), gr);
+    f32x4 xk[KS / 4][2], dyk[KS / 4][2];
+    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z, xk);
+    down_proj<NA>(dyrow, wuT, lane, wave * (KS / 4), gr, dyk);
     ksplit_reduce<NA>(part, wave, lane, z);
     ksplit_reduce<NA>(part + 4 * 2 * NT * 64, wave, lane, gr);
 
@@ -204,11 +214,11 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
 
     // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48]); this wave's quarter of the columns
     if (!dx) return;
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < CT / 4; ++k) {
         const int ct = wave * (CT / 4) + k;
         const int c = ct * 16 + 4 * g;
-        f32x4 o = *reinterpret_cast<const f32x4*>(dyrow + c);
+        f32x4 o = dyk[k >> 1][k & 1];          // dy[row][c .. c+3], kept from the Wu^T dy product
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             bf16x8 w01, w2;
@@ -241,20 +251,24 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
                                                            bf16* __restrict__ wd16, bf16* __restrict__ wdT16,
                                                            bf16* __restrict__ wu16, bf16* __restrict__ wuT16) {
-    // wd [R,H] -> wd16 [R,H], wdT16 [H,R];  wu [H,R] -> wu16 [H,R], wuT16 [R,H]
+    // wd [R,H] -> wd16 [R,H] slot-permuted along H, wdT16 [H,R];  wu [H,R] -> wu16 [H,R], wuT16 [R,H] slot-permuted.
+    // permutation of a feature index c (see down_proj): q = c / 32, half = (c % 32) / 16, g = (c % 16) / 4, j = c % 4
+    //   -> position 32 q + 8 g + 4 half + j
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R * H) return;
     {
         const int r = i / H, c = i - r * H;
+        const int pc = (c & ~31) + (((c & 15) >> 2) << 3) + (((c >> 4) & 1) << 2) + (c & 3);
         const bf16 v = (bf16)wd[i];
-        wd16[i] = v;
+        wd16[(size_t)r * H + pc] = v;
         wdT16[(size_t)c * R + r] = v;
     }
     {
         const int c = i / R, r = i - c * R;
+        const int pc = (c & ~31) + (((c & 15) >> 2) << 3) + (((c >> 4) & 1) << 2) + (c & 3);
         const bf16 v = (bf16)wu[i];
         wu16[i] = v;
-        wuT16[(size_t)r * H + c] = v;
+        wuT16[(size_t)r * H + pc] = v;
     }
 }
 

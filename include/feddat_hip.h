@@ -79,8 +79,8 @@ int feddat_layernorm_bwd_dx(const void* dy_bf16, const float* dy_f32, long dy_st
  * One launch handles up to two row segments of x (fp32 [T,768]); segment s covers rows
  * [row_begin, row_end) and applies n_adapters (1 = adapter.py:125-131, 2 = gating 133-146):
  *     out = x + sum_a scale[a] * (W_up[a] * relu(W_down[a] * x + b_down[a]) + b_up[a])
- * Weights are bf16 copies of the fp32 masters (feddat_adapter_pack): wd [r,H], wu [H,r] (+ the
- * transposed copies wdT [H,r], wuT [r,H] for the backward); biases fp32.  H = 768, r = 48.
+ * Weights are the bf16 operand copies written by feddat_adapter_pack (opaque layouts): wd, wu (+ wdT, wuT for the
+ * backward); biases fp32.  H = 768, r = 48.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     int row_begin, row_end;
@@ -122,7 +122,9 @@ typedef struct {
 long feddat_adapter_wgrad_workspace_elems(int nseg);
 int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int H, int r,
                          hipStream_t stream);
-/* fp32 master [wd(r*H), bd(r), wu(H*r), bu(H)] -> bf16 wd, wdT, wu, wuT. */
+/* fp32 masters -> bf16 MFMA operand copies.  wdT [H,r] and wu [H,r] are plain casts/transposes; wd [r,H] and wuT [r,H]
+ * are stored slot-permuted along H (feature c at 32*(c/32) + 8*((c%16)/4) + 4*((c%32)/16) + c%4) so that the fused
+ * kernels' contraction slots coincide with their 16-byte residual columns; treat all four as opaque operands. */
 int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* wdT_bf16, void* wu_bf16,
                         void* wuT_bf16, int H, int r, hipStream_t stream);
 

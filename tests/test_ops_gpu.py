@@ -164,10 +164,14 @@ def _golden_adapter(L, golden_dir):
 
 def test_adapter_pack(L, golden_dir):
     g, par = _golden_adapter(L, golden_dir)
-    assert torch.equal(par[0]["wd"], bf(par[0]["wd32"]))
+    c = torch.arange(768)
+    perm = (c // 32) * 32 + ((c % 16) // 4) * 8 + ((c % 32) // 16) * 4 + c % 4     # documented in feddat_hip.h
+    inv = torch.empty_like(perm)
+    inv[perm] = c
+    assert torch.equal(par[0]["wd"][:, perm.to(DEV)], bf(par[0]["wd32"]))
     assert torch.equal(par[0]["wdT"], bf(par[0]["wd32"]).t().contiguous())
     assert torch.equal(par[0]["wu"], bf(par[0]["wu32"]))
-    assert torch.equal(par[0]["wuT"], bf(par[0]["wu32"]).t().contiguous())
+    assert torch.equal(par[0]["wuT"][:, perm.to(DEV)], bf(par[0]["wu32"]).t().contiguous())
 
 
 def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
