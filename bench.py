@@ -32,17 +32,20 @@ def flops_tables(B, S, layers=12, H=768, I=3072, heads=12, r=48, npatch=144):
     gemms = []  # (M, N, K, epi, count)
     fwd_shapes = [(3 * H, H, 0), (H, H, 1), (I, H, 2), (H, I, 1)]
     bwd_shapes = [(I, H, 3), (H, I, 0), (H, H, 0), (H, 3 * H, 0)]
+    # layer 0: shared body on R rows; layers 1..L-2: both passes batched (2R rows); top layer: QKV (and its dX) on all
+    # tokens, everything behind the attention only on the 2B token-0 rows (negligible, not listed)
     for N, K, epi in fwd_shapes:
         gemms.append((R, N, K, epi, 1))
-        gemms.append((2 * R, N, K, epi, layers - 1))
+        gemms.append((2 * R, N, K, epi, layers - 1 if N == 3 * H else layers - 2))
     for N, K, epi in bwd_shapes:
-        gemms.append((2 * R, N, K, epi, layers - 1))
+        gemms.append((2 * R, N, K, epi, layers - 1 if K == 3 * H else layers - 2))
     gemms.append((B * npatch, H, 3 * 32 * 32, 4, 1))
     gemm_flops = sum(lin(M, N, K) * c for M, N, K, _, c in gemms)
     attn_fwd = 4.0 * S * S * 64 * heads * B           # per B samples
     attn = attn_fwd * (1 + 2 * (layers - 1)) + 2.5 * attn_fwd * 2 * (layers - 1)
     ad1 = 2.0 * R * H * r * 2                          # one adapter forward over R rows
-    adapters = layers * 3 * ad1 + layers * 3 * 3 * ad1 + layers * 2 * 2 * ad1  # fwd + (recompute, g, dx) + dW
+    la = layers - 1                                    # the top layer's adapter sees 2B rows only
+    adapters = la * 3 * ad1 + la * 3 * 3 * ad1 + la * 2 * 2 * ad1  # fwd + (recompute, g, dx) + dW
     head = 3 * 2.0 * B * (H * 2 * H + 2 * H * 100) * 3
     return gemms, gemm_flops, gemm_flops + attn + adapters + head
 

@@ -170,7 +170,12 @@ class ViltDatEngine:
         self.act = [None] + [dict(h_in=f32(R2, H), st1=f32(R2, 2), qkv=b16(R2, 3 * H), ctx=b16(R2, H),
                                   lse=f32(2 * B, self.heads, self.S), h2=f32(R2, H), st2=f32(R2, 2),
                                   u=b16(R2, I), h3=f32(R2, H)) for _ in range(1, layers)]
-        self.h_out = f32(R2, H)        # output of the last adapter
+        self.h_out = f32(R2, H)        # output of the last adapter (dense path: single-layer models only)
+        # top layer: only token 0 of each sample feeds the pooler, so everything after its attention runs on 2B rows
+        nb2 = 2 * B
+        self.top = dict(h2=f32(nb2, H), st2=f32(nb2, 2), u=b16(nb2, I), h3=f32(nb2, H), x16=b16(nb2, H),
+                        f16=b16(nb2, I), h_out=f32(nb2, H), dh3=f32(nb2, H), dh316=b16(nb2, H), dU=b16(nb2, I),
+                        dx2=b16(nb2, H), dh2=f32(nb2, H), dh216=b16(nb2, H), dctx=f32(nb2, H))
         self.st0 = f32(R, 2)
         # head / pooler
         self.cls_ln = f32(2 * B, H)
@@ -304,13 +309,16 @@ class ViltDatEngine:
                          st2=self.st0, mask=m1)
         nxt = self.act[1]["h_in"] if self.nl > 1 else self.h_out
         L.adapter_fwd(l0["h3"], nxt, self._segs(0, True, False), R2)
-        for i in range(1, self.nl):
+        for i in range(1, self.nl - 1):
             a = self.act[i]
             self._layer_body(i, a["h_in"], R2, 2 * B, a["qkv"], a["ctx"], a["lse"], a["h2"], a["h3"], st1=a["st1"],
                              st2=a["st2"], u=a["u"], mask=m2)
-            nxt = self.act[i + 1]["h_in"] if i + 1 < self.nl else self.h_out
-            L.adapter_fwd(a["h3"], nxt, self._segs(i, False, False), R2)
-        self._pool(self.h_out, 2 * B)
+            L.adapter_fwd(a["h3"], self.act[i + 1]["h_in"], self._segs(i, False, False), R2)
+        if self.nl > 1:
+            self._top_layer_fwd(m2)
+            self._pool(self.top["h_out"], 2 * B, x_stride=self.H)
+        else:
+            self._pool(self.h_out, 2 * B)
 
     def _sg(self, A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, out, ksplit=1, bias_j=None):
         """Skinny exact-fp32 product; long contractions are split over the grid and reduced deterministically."""
@@ -327,10 +335,47 @@ class ViltDatEngine:
             self._scr = torch.empty(n, device=self.dev)
         return self._scr
 
-    def _pool(self, h_last, nb: int):
+    def _cls_rows(self, t, nb: int):
+        """Strided view of token 0 of every sample: [nb, width] with row stride S * width (no copy)."""
+        w = t.shape[1]
+        return t.view(nb, self.S * w)[:, :w]
+
+    def _top_layer_fwd(self, mask):
+        """Last layer.  LN1 / QKV / attention see every token (keys and values of all tokens feed token 0), but only
+        token 0 of each sample reaches the pooler (HF ViltPooler takes hidden_states[:, 0]; vilt.py:127), so the
+        attention-output projection, LN2, FFN and the adapter run on the 2B token-0 rows, read in place through
+        strided GEMM operands."""
+        i = self.nl - 1
+        a, W, H, t = self.act[i], self.layers[i], self.H, self.top
+        R2, nb = 2 * self.R, 2 * self.B
+        x16 = self.x16[:R2]
+        L.layernorm_fwd(a["h_in"], W["ln1g"], W["ln1b"], self.ln_eps, R2, H, y_bf16=x16, stats=a["st1"])
+        L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
+        L.attn_fwd(a["qkv"], a["ctx"], a["lse"], nb, self.S, self.heads, key_mask=mask)
+        L.gemm_bf16_nt(self._cls_rows(a["ctx"], nb), W["wo"], L.EPI_RESID_F32, bias=W["bo"],
+                       resid=self._cls_rows(a["h_in"], nb), out_f32=t["h2"])
+        L.layernorm_fwd(t["h2"], W["ln2g"], W["ln2b"], self.ln_eps, nb, H, y_bf16=t["x16"], stats=t["st2"])
+        L.gemm_bf16_nt(t["x16"], W["w1"], L.EPI_GELU, bias=W["b1"], out_bf16=t["f16"], out2_bf16=t["u"])
+        L.gemm_bf16_nt(t["f16"], W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=t["h2"], out_f32=t["h3"])
+        L.adapter_fwd(t["h3"], t["h_out"], self._top_segs(False), nb)
+
+    def _top_segs(self, bwd: bool):
+        key = ("top", bwd)
+        if key not in self._segs_cache:
+            i, B = self.nl - 1, self.B
+            a0, a1, a2 = (self.ad16[a][i] for a in range(3))
+            self._segs_cache[key] = L.make_segs([
+                dict(row_begin=0, row_end=B, train_slot=0 if bwd else -1,
+                     adapters=[dict(a0, scale=0.5), dict(a2, scale=0.5)]),
+                dict(row_begin=B, row_end=2 * B, train_slot=0 if bwd else -1, adapters=[dict(a1, scale=1.0)]),
+            ])
+        return self._segs_cache[key]
+
+    def _pool(self, h_last, nb: int, x_stride: int = None):
         """ViltModel.layernorm on token 0 + ViltPooler (dense + tanh) -> self.pooled[:nb]."""
         H = self.H
-        L.layernorm_fwd(h_last, self.lnf_g, self.lnf_b, self.ln_eps, nb, H, x_stride=self.S * H,
+        self._pool_src, self._pool_stride = h_last, (self.S * H if x_stride is None else x_stride)
+        L.layernorm_fwd(h_last, self.lnf_g, self.lnf_b, self.ln_eps, nb, H, x_stride=self._pool_stride,
                         y_f32=self.cls_ln, stats=self.cls_st)
         self._sg(self.cls_ln, H, 1, self.pool_w, 1, H, nb, H, H, self.pooled, ksplit=4, bias_j=self.pool_b)
         L.tanh_fwd(self.pooled[:nb])
@@ -383,12 +428,17 @@ class ViltDatEngine:
         nb = 2 * B
         L.tanh_bwd(self.pooled, self.dpooled, self.dpre)
         self._sg(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, ksplit=4)
-        L.layernorm_bwd_dx(self.h_out, self.cls_st, self.lnf_g, nb, H, dy_f32=self.dcls_ln, x_stride=self.S * H,
-                           out_f32=self.dcls)
+        L.layernorm_bwd_dx(self._pool_src, self.cls_st, self.lnf_g, nb, H, dy_f32=self.dcls_ln,
+                           x_stride=self._pool_stride, out_f32=self.dcls)
         cur, oth = self.dh
-        L.scatter_cls_rows(self.dcls, cur, None, nb, self.S, H)
         m2 = self.key_mask2 if self.use_mask else None
-        for i in range(self.nl - 1, 0, -1):
+        top = self.nl - 1 if self.nl > 1 else 0
+        if self.nl > 1:
+            self._top_layer_bwd(cur, oth, m2)      # leaves d(h_in of the top layer) in `oth`
+            cur, oth = oth, cur
+        else:
+            L.scatter_cls_rows(self.dcls, cur, None, nb, self.S, H)
+        for i in range(top - 1, 0, -1):
             a, W = self.act[i], self.layers[i]
             # adapter: dh3 (fp32 in `oth`, bf16 copy in dh16), z/dz for the weight gradients
             L.adapter_bwd(a["h3"], cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
@@ -408,6 +458,35 @@ class ViltDatEngine:
         # layer 0: weight gradients only (nothing trainable below)
         L.adapter_bwd(self.l0["h3"], cur, None, self._segs(0, True, True), R2, z_out=self.z, dz_out=self.dz)
         self._adapter_wgrads(0, self.l0["h3"], -R, cur)
+
+    def _top_layer_bwd(self, cur, oth, mask):
+        """Backward of the last layer: the incoming gradient is non-zero only on the 2B token-0 rows, so the adapter,
+        FFN, LN2 and attention-output backward run on those rows; from the attention backward on every token is live."""
+        i = self.nl - 1
+        a, W, H, t = self.act[i], self.layers[i], self.H, self.top
+        R2, nb, B = 2 * self.R, 2 * self.B, self.B
+        L.adapter_bwd(t["h3"], self.dcls, t["dh3"], self._top_segs(True), nb, dx_bf16=t["dh316"], z_out=self.z,
+                      dz_out=self.dz)
+        key = ("wg-top", self.opt_adapters)
+        if key not in self._segs_cache:
+            n = self.ad_layer_numel
+            segs = [dict(x=t["h3"][r0:], dy=self.dcls[r0:], z=self.z[r0:], dz=self.dz[r0:],
+                         grad=self.ad[ad].g[i * n:(i + 1) * n], rows=B, scale=sc)
+                    for ad, r0, sc in ((0, 0, 0.5), (1, B, 1.0)) if ad in self.opt_adapters]
+            self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
+        if self._segs_cache[key] is not None:
+            L.adapter_wgrad(self._segs_cache[key], self.wpart)
+        L.gemm_bf16_nt(t["dh316"], W["w2T"], L.EPI_MUL_DGELU, aux=t["u"], out_bf16=t["dU"])
+        L.gemm_bf16_nt(t["dU"], W["w1T"], L.EPI_BF16, out_bf16=t["dx2"])
+        L.layernorm_bwd_dx(t["h2"], t["st2"], W["ln2g"], nb, H, dy_bf16=t["dx2"], dres=t["dh3"], out_f32=t["dh2"],
+                           out_bf16=t["dh216"])
+        L.gemm_bf16_nt(t["dh216"], W["woT"], L.EPI_F32, out_f32=t["dctx"])
+        # scatter the token-0 rows into the dense operands of the attention / LN1 backward
+        L.scatter_cls_rows(t["dctx"], None, self.dctx, nb, self.S, H)
+        L.scatter_cls_rows(t["dh2"], cur, None, nb, self.S, H)
+        L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=mask)
+        L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
+        L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
 
     def _adapter_wgrads(self, layer: int, x, x_delta_s: int, dy):
         """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146)
