@@ -148,11 +148,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # FEDDAT_FORCE_DEVICE / FEDDAT_DIST_BACKEND exist only so that the multi-rank control flow can be exercised on a
+    # single-GPU box (two ranks on cuda:0 over gloo); the real launch uses one GPU per rank and RCCL ("nccl").
+    if os.environ.get("FEDDAT_FORCE_DEVICE") is not None:
+        local = int(os.environ["FEDDAT_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("FEDDAT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from feddat_amd import engine, lib as L, vilt_spec
     from feddat_amd.fedavg import allreduce_average
     dev = torch.device("cuda", local)
@@ -215,10 +223,13 @@ def main():
         }
         if not args.no_roofline:
             ach, tsum, rows = measure_gemms(L, gemms)
-            out["roofline"] = {"kernel": "gemm_nt_kernel (K1, frozen-linear bf16 MFMA GEMM, all 13 launch shapes "
+            tr = profiled_traffic()
+            out["roofline"] = {"kernel": "gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM, all 13 launch shapes "
                                          "of one step, FLOP-weighted)",
                                "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16, 4), "traffic": profiled_traffic(),
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16, 4),
+                               "traffic": tr["bytes_per_launch"] if tr else None,
+                               "traffic_source": (tr["source"] + ": " + tr["note"]) if tr else None,
                                "gemm_ms_per_step": round(tsum * 1e3, 3), "shapes": rows}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline({k: v.float().cpu() for k, v in params.items()}, B, res, task)
