@@ -2,7 +2,7 @@
 // (HF ViltSelfAttention: softmax(Q K^T / sqrt(64) + mask) V; reference call site src/modeling/vilt.py:127,
 // backward = autograd through it from task_trainer.py:302,323).
 //
-// One workgroup (4 waves) per (sample, head) (two per (sample, head) in the backward).  S <= 256 so the operands
+// One workgroup (4 waves) per (sample, head) (two per (sample, head) in the backward).  S <= 320 so the operands
 // of one head live in LDS for the whole kernel (row-major [S_pad][64] bf16, 16-byte chunks XOR-swizzled by (row & 7) so that the
 // ds_read_b128 row-fragment reads are conflict-free).  No S x S matrix ever reaches HBM: scores stay in MFMA
 // accumulators; the only saved statistic is the per-row log-sum-exp.
@@ -332,10 +332,10 @@ __global__ __launch_bounds__(256) void probe_tr16_kernel(const bf16* __restrict_
 
 extern "C" int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S,
                                int heads, hipStream_t stream) {
-    FD_CHECK_ARG(qkv && ctx && B > 0 && S > 0 && S <= 256 && heads > 0);
+    FD_CHECK_ARG(qkv && ctx && B > 0 && S > 0 && S <= 320 && heads > 0);
     const int nks = (S + 31) / 32;
     const int lds = nks * 32 * ROWB * 3 + nks * 32 * 4;
-    static bool fdone[9] = {false};
+    static bool fdone[11] = {false};
 #define NKS_MAX_LDS_F(N) ((N) * 32 * ROWB * 3 + (N) * 32 * 4)
 #define ATTN_FWD(N)                                                                                           \
     case N:                                                                                                   \
@@ -344,7 +344,8 @@ extern "C" int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* c
                            key_mask, (bf16*)ctx, lse, S, heads);                                              \
         break;
     switch (nks) {
-        ATTN_FWD(1) ATTN_FWD(2) ATTN_FWD(3) ATTN_FWD(4) ATTN_FWD(5) ATTN_FWD(6) ATTN_FWD(7) ATTN_FWD(8)
+        ATTN_FWD(1) ATTN_FWD(2) ATTN_FWD(3) ATTN_FWD(4) ATTN_FWD(5) ATTN_FWD(6) ATTN_FWD(7) ATTN_FWD(8) ATTN_FWD(9)
+        ATTN_FWD(10)
         default: return FEDDAT_EINVAL;
     }
 #undef ATTN_FWD
@@ -353,10 +354,10 @@ extern "C" int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* c
 
 extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse,
                                const void* dctx, void* dqkv, int B, int S, int heads, hipStream_t stream) {
-    FD_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && B > 0 && S > 0 && S <= 256 && heads > 0);
+    FD_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && B > 0 && S > 0 && S <= 320 && heads > 0);
     const int nks = (S + 31) / 32;
     const int lds = nks * 32 * ROWB * 2 + nks * 32 * 4 * 3;
-    static bool bdone[9] = {false};
+    static bool bdone[11] = {false};
 #define NKS_MAX_LDS_B(N) ((N) * 32 * ROWB * 2 + (N) * 32 * 4 * 3)
 #define ATTN_BWD(N)                                                                                           \
     case N:                                                                                                   \
@@ -365,7 +366,8 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
                            key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads);        \
         break;
     switch (nks) {
-        ATTN_BWD(1) ATTN_BWD(2) ATTN_BWD(3) ATTN_BWD(4) ATTN_BWD(5) ATTN_BWD(6) ATTN_BWD(7) ATTN_BWD(8)
+        ATTN_BWD(1) ATTN_BWD(2) ATTN_BWD(3) ATTN_BWD(4) ATTN_BWD(5) ATTN_BWD(6) ATTN_BWD(7) ATTN_BWD(8) ATTN_BWD(9)
+        ATTN_BWD(10)
         default: return FEDDAT_EINVAL;
     }
 #undef ATTN_BWD

@@ -63,21 +63,21 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
     }
 }
 
-// pixels [B,C,R,R] fp32 -> patches [B*gh*gw, C*P*P] bf16; one thread = 4 consecutive px of one patch row
+// pixels [B,C,Hi,Wi] fp32 -> patches [B*gh*gw, C*P*P] bf16; one thread = 4 consecutive px of one patch row
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ px, bf16* __restrict__ out, int B,
-                                                     int C, int R, int P) {
-    const int gw = R / P;
-    const long total = (long)B * C * R * R / 4;
+                                                     int C, int Hi, int Wi, int P) {
+    const int gw = Wi / P, gh = Hi / P;
+    const long total = (long)B * C * Hi * Wi / 4;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long e = i * 4;              // linear index into pixels
-    const int x = (int)(e % R);
-    const int y = (int)((e / R) % R);
-    const int c = (int)((e / ((long)R * R)) % C);
-    const int b = (int)(e / ((long)R * R * C));
+    const int x = (int)(e % Wi);
+    const int y = (int)((e / Wi) % Hi);
+    const int c = (int)((e / ((long)Hi * Wi)) % C);
+    const int b = (int)(e / ((long)Hi * Wi * C));
     const f32x4 v = *reinterpret_cast<const f32x4*>(px + e);
     const int py = y / P, iy = y - py * P, pxi = x / P, ix = x - pxi * P;
-    const size_t row = ((size_t)b * gw + py) * gw + pxi;
+    const size_t row = ((size_t)b * gh + py) * gw + pxi;
     const size_t col = ((size_t)c * P + iy) * P + ix;
     *reinterpret_cast<bf16x4*>(out + row * ((size_t)C * P * P) + col) = cvt4(v);
 }
@@ -197,12 +197,13 @@ extern "C" int feddat_text_embed(const int64_t* input_ids, const int64_t* token_
     FD_LAUNCH_RET();
 }
 
-extern "C" int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C, int R, int P,
+extern "C" int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C, int Hi, int Wi, int P,
                                      hipStream_t stream) {
-    FD_CHECK_ARG(pixels && patches_bf16 && B > 0 && C > 0 && R > 0 && P > 0 && R % P == 0 && P % 4 == 0);
-    const long total = (long)B * C * R * R / 4;
+    FD_CHECK_ARG(pixels && patches_bf16 && B > 0 && C > 0 && Hi > 0 && Wi > 0 && P > 0);
+    FD_CHECK_ARG(Hi % P == 0 && Wi % P == 0 && P % 4 == 0);
+    const long total = (long)B * C * Hi * Wi / 4;
     hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pixels,
-                       (bf16*)patches_bf16, B, C, R, P);
+                       (bf16*)patches_bf16, B, C, Hi, Wi, P);
     FD_LAUNCH_RET();
 }
 

@@ -69,11 +69,12 @@ class ViltDatEngine:
         L.load()
         self.dev = torch.device(device)
         self.tasks = list(tasks)
-        self.B, self.res, self.Lt, self.nl = batch, res, text_len, layers
+        self.B, self.Lt, self.nl = batch, text_len, layers
+        self.res = (res, res) if isinstance(res, int) else tuple(res)      # (height, width), multiples of 32
         self.H, self.I, self.heads, self.r, self.C = 768, 3072, 12, 48, num_labels
         self.P = 32
-        self.grid = res // self.P
-        self.np = self.grid * self.grid
+        self.gh, self.gw = self.res[0] // self.P, self.res[1] // self.P
+        self.np = self.gh * self.gw
         self.S = text_len + 1 + self.np
         self.R = batch * self.S
         self.lr, self.wd, self.eps = lr, weight_decay, adam_eps
@@ -108,7 +109,7 @@ class ViltDatEngine:
         self.pos0 = pos[0].contiguous()
         self.pos_img = torch.empty(self.np, H, device=dev)
         g0 = int(round(math.sqrt(pos.shape[0] - 1)))
-        L.pos_embed_resize(pos[1:].contiguous(), self.pos_img, g0, self.grid, self.grid, H)
+        L.pos_embed_resize(pos[1:].contiguous(), self.pos_img, g0, self.gh, self.gw, H)
         self.w_patch = bf16_of(P(e + "patch_embeddings.projection.weight").reshape(H, 3 * self.P * self.P))
         self.layers: List[dict] = []
         for i in range(layers):
@@ -155,7 +156,7 @@ class ViltDatEngine:
 
         def b16(*s):
             return torch.empty(*s, dtype=torch.bfloat16, device=dev)
-        self.inp = dict(pixel_values=f32(B, 3, res, res), input_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
+        self.inp = dict(pixel_values=f32(B, 3, self.res[0], self.res[1]), input_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
                         token_type_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
                         target=f32(B, num_labels), key_mask=torch.ones(B, self.S, dtype=torch.uint8, device=dev))
         self.use_mask = False
@@ -279,7 +280,7 @@ class ViltDatEngine:
                      e["text_embeddings.position_embeddings.weight"], e["text_embeddings.token_type_embeddings.weight"],
                      e["text_embeddings.LayerNorm.weight"], e["text_embeddings.LayerNorm.bias"], self.ln_eps,
                      self.mod0, self.h0, B, Lt, S, H)
-        L.im2col_patches(self.inp["pixel_values"], self.patches, B, 3, self.res, self.P)
+        L.im2col_patches(self.inp["pixel_values"], self.patches, B, 3, self.res[0], self.res[1], self.P)
         L.gemm_bf16_nt(self.patches, self.w_patch, L.EPI_F32, bias=e["patch_embeddings.projection.bias"],
                        out_f32=self.proj)
         L.image_embed_assemble(self.proj, self.cls, self.pos0, self.pos_img, self.mod1, self.h0, B, Lt, self.np, S, H)

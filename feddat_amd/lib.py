@@ -49,7 +49,7 @@ _SIGS = {
     "feddat_adamw_flat": [vp, vp, vp, vp, i64, vp, vp, i32, vp, f32, i32, i32, f32, f32, f32, vp],
     "feddat_step_tick": [vp, i32, i32, vp],
     "feddat_text_embed": [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, vp],
-    "feddat_im2col_patches": [vp, vp, i32, i32, i32, i32, vp],
+    "feddat_im2col_patches": [vp, vp, i32, i32, i32, i32, i32, vp],
     "feddat_image_embed_assemble": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "feddat_pos_embed_resize": [vp, vp, i32, i32, i32, i32, vp],
     "feddat_cvt_f32_bf16": [vp, vp, i64, vp],
@@ -259,9 +259,9 @@ def text_embed(ids, tts, word, pos, typ, ln_g, ln_b, eps, mod0, h, B, Lt, S, H):
                                   _p(h), B, Lt, S, H, _stream()), "feddat_text_embed")
 
 
-def im2col_patches(pixels, patches, B, Cc, R, P):
+def im2col_patches(pixels, patches, B, Cc, Hi, Wi, P):
     _dev(pixels, patches)
-    _chk(load().feddat_im2col_patches(_p(pixels), _p(patches), B, Cc, R, P, _stream()), "feddat_im2col_patches")
+    _chk(load().feddat_im2col_patches(_p(pixels), _p(patches), B, Cc, Hi, Wi, P, _stream()), "feddat_im2col_patches")
 
 
 def image_embed_assemble(proj, cls, pos0, pos_img, mod1, h, B, Lt, npatch, S, H):

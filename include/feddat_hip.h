@@ -52,7 +52,7 @@ int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, i
  * qkv: bf16 [B*S, 3*H] rows = tokens, columns = [Q | K | V], head h at columns h*64.. of each part.
  * key_mask: optional uint8 [B,S] (1 = attend, 0 = masked; text padding, vilt.py:98) or NULL.
  * ctx: bf16 [B*S, H]; lse: fp32 [B, heads, S] (log-sum-exp of the scaled scores, saved for backward).
- * Requirements: head_dim == 64, S <= 256.
+ * Requirements: head_dim == 64, S <= 320 (ViLT: 40 text + 1 + up to 12 x 20 patches of a 384 x 640 image = 281).
  * ------------------------------------------------------------------------------------------- */
 int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
                     hipStream_t stream);
@@ -170,8 +170,9 @@ int feddat_step_tick(int* state, int d_sched, int d_adam, hipStream_t stream);
 int feddat_text_embed(const int64_t* input_ids, const int64_t* token_type_ids, const float* word, const float* pos,
                       const float* type, const float* ln_g, const float* ln_b, float eps, const float* modality0,
                       float* h, int B, int Lt, int S, int H, hipStream_t stream);
-/* pixels fp32 [B,3,R,R] -> bf16 patches [B*gh*gw, 3*P*P] (k = c*P*P + py*P + px, Conv2d weight order) */
-int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C, int R, int P, hipStream_t stream);
+/* pixels fp32 [B,3,Hi,Wi] -> bf16 patches [B*gh*gw, 3*P*P] (k = c*P*P + py*P + px, Conv2d weight order) */
+int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C, int Hi, int Wi, int P,
+                          hipStream_t stream);
 /* image rows: h[b, Lt, :] = cls + pos[0] + modality[1]; h[b, Lt+1+p, :] = proj[b*np+p] + pos_img[p] + modality[1] */
 int feddat_image_embed_assemble(const float* proj, const float* cls, const float* pos0, const float* pos_img,
                                 const float* modality1, float* h, int B, int Lt, int np, int S, int H,

@@ -158,3 +158,26 @@ def test_full_12_layer_vs_reference_golden(eng_mod, golden_dir):
         worst = max(worst, dd)
         assert dd < 1e-3, (k, dd)
     print("12-layer worst adapter diff after 4 steps:", worst)
+
+
+def test_non_square_image_384x640(eng_mod):
+    """ViLT's processor yields up to 384 x 640 inputs: 12 x 20 patches, S = 40 + 1 + 240 = 281 tokens (> 256)."""
+    d = O.ViltDims(layers=2)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=2, res=(384, 640), layers=2)
+    g = torch.Generator().manual_seed(3)
+    b = O.synthetic_batch(2, 384, 21)
+    b["pixel_values"] = torch.randn(2, 3, 384, 640, generator=g)
+    b["pixel_mask"] = torch.ones(2, 384, 640, dtype=torch.long)
+    pooled, logits = eng.forward(_to_dev(b), "gating", "art")
+    with torch.no_grad():
+        rp, rl = O.vilt_forward(P, d, b, "gating", "art")
+    assert (pooled.cpu() - rp).abs().max() < 3e-2 and (logits.cpu() - rl).abs().max() < 3e-2
+    client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=2)
+    eng.begin_local_update("art", steps_per_epoch=2)
+    ref = float(client.train_step(b)[0])
+    out = eng.train_step(_to_dev(b))
+    assert abs(float(out[0]) - ref) < 2e-3 * abs(ref) + 2e-3
+    sd = eng.state_dict()
+    for n in O.trainable_names(P, "art", 0):
+        assert (sd[n].cpu() - P[n]).abs().max() < 1e-3, n

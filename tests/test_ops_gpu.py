@@ -386,7 +386,7 @@ def _attn_ref(qkv, B, S, heads, mask=None):
 
 
 @pytest.mark.parametrize("B,S,heads,masked", [(2, 185, 12, False), (3, 90, 12, True), (1, 33, 2, True),
-                                              (64, 185, 12, False)])
+                                              (64, 185, 12, False), (2, 281, 12, True), (1, 320, 3, False)])
 def test_attention_fwd_bwd(L, B, S, heads, masked):
     g = torch.Generator().manual_seed(S)
     H = heads * 64
@@ -436,7 +436,7 @@ def test_embeddings_vs_oracle(L, res):
     gsz = res // 32
     npatch = gsz * gsz
     patches = torch.empty(B * npatch, 3072, dtype=torch.bfloat16, device=DEV)
-    L.im2col_patches(batch["pixel_values"].to(DEV), patches, B, 3, res, 32)
+    L.im2col_patches(batch["pixel_values"].to(DEV), patches, B, 3, res, res, 32)
     ref_patches = F.unfold(batch["pixel_values"], 32, stride=32).transpose(1, 2).reshape(B * npatch, 3072)
     assert torch.equal(patches.cpu(), bf(ref_patches))
     wp = bf(dev[e + "patch_embeddings.projection.weight"].reshape(768, 3072))
