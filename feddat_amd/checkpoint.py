@@ -32,3 +32,33 @@ def load_round(model, out_dir: str, task_key: str) -> Dict[str, torch.Tensor]:
         sd.update(load_file(p))
     model.load_state_dict(sd)
     return sd
+
+
+def save_federation(out_dir: str, comm: Dict[str, torch.Tensor], personal: Dict[str, Dict[str, torch.Tensor]],
+                    comm_round: int, write_server: bool = True, server_flags=None) -> None:
+    """State of a whole federation after `comm_round`: the averaged adapter_1 tensors (written by one rank) and each
+    local client's personal tensors (written by the rank that owns the client).  round.json is written last, so a
+    directory with a round.json is complete."""
+    import json
+    os.makedirs(out_dir, exist_ok=True)
+    cpu = lambda d: {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in d.items()}
+    for task_key, sd in personal.items():
+        save_file(cpu(sd), os.path.join(out_dir, f"personal_{task_key}.safetensors"))
+    if write_server:
+        save_file(cpu(comm), os.path.join(out_dir, "server_adapter.safetensors"))
+        with open(os.path.join(out_dir, "round.json"), "w") as f:
+            json.dump({"comm_round": int(comm_round),
+                       "server_adapter_requires_grad": {str(k): bool(v) for k, v in (server_flags or {}).items()}}, f)
+
+
+def load_federation(out_dir: str, tasks):
+    """-> (comm dict, {task: personal dict}, last finished round, server requires_grad flags {adapter index: bool}).
+    Raises FileNotFoundError on an incomplete dir."""
+    import json
+    with open(os.path.join(out_dir, "round.json")) as f:
+        meta = json.load(f)
+    comm_round = int(meta["comm_round"])
+    flags = {int(k): bool(v) for k, v in meta.get("server_adapter_requires_grad", {}).items()}
+    comm = dict(load_file(os.path.join(out_dir, "server_adapter.safetensors")))
+    personal = {t: dict(load_file(os.path.join(out_dir, f"personal_{t}.safetensors"))) for t in tasks}
+    return comm, personal, comm_round, flags

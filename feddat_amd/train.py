@@ -179,6 +179,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--image_size", type=int, default=384)
     p.add_argument("--num_layers", type=int, default=12)
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
+    p.add_argument("--save_every", type=int, default=0,
+                   help="write <output_dir>/round state every N rounds (0 = never, like the reference); "
+                        "--checkpoint <dir> resumes from it")
     return p
 
 
@@ -203,6 +206,8 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     tasks = TASK_SETS.get(args.ordered_cl_tasks, args.ordered_cl_tasks.split(","))
     my_tasks = tasks[rank::world]                       # client -> GPU mapping
+    if not my_tasks:
+        raise L.FeddatHipError(f"rank {rank} of {world} has no client: use at most {len(tasks)} processes")
     dev = torch.device("cuda", local)
     params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)    # stand-in for from_pretrained
     model = create_vilt_continual_learner_model(params, tasks, dev, args.batch_size, args.image_size,
@@ -215,12 +220,28 @@ def main(argv=None):
     data = {t: [vilt_spec.synthetic_batch(args.batch_size, args.image_size, args.seed + 1000 * ti + s, device=dev)
                 for s in range(args.synthetic_steps)] for ti, t in enumerate(tasks) if t in my_tasks}
     server_flat = eng.comm_flat().clone()
-    acc = torch.empty_like(server_flat)
-    for comm_round in range(args.comm_rounds):
+    acc = torch.zeros_like(server_flat)
+    comm_names = model.comm_state_dict_names
+    first_round = 0
+    # requires_grad flags of the SERVER model.  Clients train on deepcopy(server) (main.py:472), so whatever train_step
+    # toggles stays on the copy; only eval(server) (main.py:546) changes the server's flags -- it ends in the
+    # adapter_1 state, after which fresh client optimizers no longer hold adapter_0 (reference behaviour, golden G3q).
+    server_flags = dict(model.adapter_requires_grad)
+    if args.checkpoint:                                   # resume: averaged adapter + this rank's personal tensors
+        from . import checkpoint
+        comm, pers, last, flags = checkpoint.load_federation(args.checkpoint, my_tasks)
+        server_flags.update(flags)
+        model.load_state_dict(comm)
+        server_flat.copy_(eng.comm_flat())
+        for t in my_tasks:
+            personal_params[t].update({k: v.to(dev) for k, v in pers[t].items()})
+        first_round = last + 1
+    for comm_round in range(first_round, args.comm_rounds):
         for k, task_key in enumerate(my_tasks):
             eng.comm_flat().copy_(server_flat)                      # main.py:472 deepcopy(server)
             eng.repack_adapter(1)
             model.load_state_dict(personal_params[task_key])        # main.py:473-478
+            model.adapter_requires_grad = dict(server_flags)
             trainer = TaskTrainer(args, task_key, data[task_key], data[task_key][:2], log)
             trainer.train(model, comm_round)
             personal_params[task_key] = personal(model.state_dict())     # main.py:493-497
@@ -229,13 +250,30 @@ def main(argv=None):
         if world > 1:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         server_flat.copy_(acc)
+        if args.save_every and ((comm_round + 1) % args.save_every == 0 or comm_round == args.comm_rounds - 1):
+            from . import checkpoint
+            eng.comm_flat().copy_(server_flat)
+            sd = model.state_dict()
+            checkpoint.save_federation(args.output_dir, {}, personal_params, comm_round, write_server=False)
+            if world > 1:
+                dist.barrier()          # every rank's personal files are on disk before round.json appears
+            if rank == 0:
+                flags_after = dict(server_flags)
+                if comm_round % 5 == 0 or comm_round == args.comm_rounds - 1:
+                    flags_after.update({0: False, 1: True})         # the eval below leaves the server in this state
+                checkpoint.save_federation(args.output_dir, {n: sd[n] for n in comm_names}, {}, comm_round,
+                                           server_flags=flags_after)
         if comm_round % 5 == 0 or comm_round == args.comm_rounds - 1:   # main.py:520
             for task_key in my_tasks:
                 eng.comm_flat().copy_(server_flat)
                 model.load_state_dict(personal_params[task_key])
                 model.after_load()
+                model.adapter_requires_grad = dict(server_flags)
                 scores = TaskTrainer(args, task_key, data[task_key], data[task_key][:2], log).eval(model)
+                server_flags = dict(model.adapter_requires_grad)
                 log.info("round %d %s test score server = %s", comm_round, task_key, scores)
+    eng.comm_flat().copy_(server_flat)
+    eng.repack_adapter(1)
     if world > 1:
         dist.destroy_process_group()
     return model

@@ -119,3 +119,47 @@ def test_checkpoint_roundtrip_uses_reference_key_names(api, tmp_path):
     checkpoint.load_round(m, str(tmp_path), "art")
     for k, v in m.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+def test_eval_three_way_scores_match_oracle(api):
+    """task_trainer.py:230-244: [gated (adapter_0 + adapter_2), adapter_0, adapter_1] VQA scores of one loader."""
+    d = O.ViltDims(layers=2)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    m = api.modeling.create_vilt_continual_learner_model(P, ["art"], DEV, batch_size=4, image_size=224, num_layers=2)
+    args = types.SimpleNamespace(local_epochs=1, num_epochs=15, lr=1e-4, optimizer_mode="dat", debug=0, hip_graph=False)
+    loader = [O.synthetic_batch(4, 224, 900 + s) for s in range(3)]
+    got = api.train.TaskTrainer(args, "art", [], [_dev(b) for b in loader]).eval(m)
+    want, margins = [], []
+    for mode in ("gating", "adapter_0", "adapter_1"):
+        sc = 0.0
+        for b in loader:
+            with torch.no_grad():
+                _, lg = O.vilt_forward(P, d, b, mode, "art")
+            top2 = lg.topk(2, dim=1).values
+            margins.append(float((top2[:, 0] - top2[:, 1]).min()))
+            sc += float(b["target_scores"].gather(1, lg.argmax(1, keepdim=True)).sum())
+        want.append(100.0 * sc / 12)
+    if min(margins) > 6e-2:          # arg-max is only comparable when no row is a near-tie at the logit tolerance
+        assert got == pytest.approx(want, abs=1e-4)
+    assert len(got) == 3 and all(0.0 <= s <= 100.0 for s in got)
+
+
+def test_main_rounds_and_resume(api, tmp_path):
+    """feddat_amd.train.main: 2 clients x 2 rounds on one GPU, then the same run split as 1 round + resume from the
+    round state on disk -- identical averaged adapter and personal tensors (bit-exact: same kernels, same order)."""
+    common = ["--ordered_cl_tasks", "art,gqa", "--num_layers", "2", "--image_size", "224", "--batch_size", "2",
+              "--synthetic_steps", "2", "--no_hip_graph", "--save_every", "1"]
+    a = api.train.main(common + ["--comm_rounds", "2", "--output_dir", str(tmp_path / "a")])
+    sd_a = {k: v.clone() for k, v in a.state_dict().items()}
+    api.train.main(common + ["--comm_rounds", "1", "--output_dir", str(tmp_path / "b")])
+    b = api.train.main(common + ["--comm_rounds", "2", "--output_dir", str(tmp_path / "b2"),
+                                 "--checkpoint", str(tmp_path / "b")])
+    sd_b = b.state_dict()
+    for n in a.comm_state_dict_names:
+        assert torch.isfinite(sd_a[n]).all()
+        assert torch.equal(sd_a[n], sd_b[n]), n
+    from safetensors.torch import load_file
+    for t in ("art", "gqa"):
+        pa = load_file(str(tmp_path / "a" / f"personal_{t}.safetensors"))
+        pb = load_file(str(tmp_path / "b2" / f"personal_{t}.safetensors"))
+        assert pa.keys() == pb.keys() and all(torch.equal(pa[k], pb[k]) for k in pa), t
