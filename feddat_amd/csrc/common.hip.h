@@ -64,6 +64,46 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
     return 0.5f * (1.0f + er) + u * 0.39894228040143268f * ex;
 }
 
+// Packed-math GELU / GELU' for the GEMM epilogues (bf16 outputs).  The A-S form above costs two quarter-rate
+// transcendentals + ~12 scalar fp32 ops per element, which made the FFN1 epilogue VALU-bound (as long as its k-loop).
+// Here: t = clamp(u / 4.5, -1, 1);  erf(u / sqrt 2) ~ t * P(t^2),  gelu'(u) - 1/2 ~ t * Q(t^2), 9 coefficients each
+// (weighted-LSQ minimax fits, scratch fit script; fp32 Horner max abs error 5.3e-5 resp. 3.2e-4 over all u, i.e.
+// 10-60x below the bf16 rounding of the value that is stored), evaluated two elements per v_pk_fma_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 odd_poly9_pk(f32x2 t, const float (&c)[9]) {
+    const f32x2 t2 = t * t;
+    f32x2 p = f32x2{c[8], c[8]};
+#pragma unroll
+    for (int k = 7; k >= 0; --k) p = p * t2 + f32x2{c[k], c[k]};
+    return p * t;
+}
+__device__ __forceinline__ f32x2 clamp_unit_pk(f32x2 u) {
+    f32x2 t = u * f32x2{1.0f / 4.5f, 1.0f / 4.5f};
+    t[0] = __builtin_amdgcn_fmed3f(t[0], -1.0f, 1.0f);
+    t[1] = __builtin_amdgcn_fmed3f(t[1], -1.0f, 1.0f);
+    return t;
+}
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 u) {
+    constexpr float C[9] = {3.589798371e+00f, -1.207231863e+01f, 3.590728051e+01f, -8.046883329e+01f, 1.320808609e+02f,
+                            -1.519935397e+02f, 1.145676310e+02f, -5.029529085e+01f, 9.684438904e+00f};
+    const f32x2 e = odd_poly9_pk(clamp_unit_pk(u), C);
+    const f32x2 h = u * f32x2{0.5f, 0.5f};
+    return h * e + h;
+}
+__device__ __forceinline__ f32x2 gelu_grad_pk(f32x2 u) {
+    constexpr float C[9] = {3.586068066e+00f, -2.393606056e+01f, 1.043871964e+02f, -2.983035769e+02f, 5.731157980e+02f,
+                            -7.304086803e+02f, 5.886747112e+02f, -2.703110568e+02f, 5.369588787e+01f};
+    return odd_poly9_pk(clamp_unit_pk(u), C) + f32x2{0.5f, 0.5f};
+}
+__device__ __forceinline__ f32x4 gelu4_pk(f32x4 u) {
+    const f32x2 a = gelu_pk(f32x2{u[0], u[1]}), b = gelu_pk(f32x2{u[2], u[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
+}
+__device__ __forceinline__ f32x4 gelu_grad4_pk(f32x4 u) {
+    const f32x2 a = gelu_grad_pk(f32x2{u[0], u[1]}), b = gelu_grad_pk(f32x2{u[2], u[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
+}
+
 __device__ __forceinline__ bf16x8 cvt8(const f32x4 a, const f32x4 b) {
     bf16x8 r;
     r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];

@@ -94,12 +94,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NI
             } else if (EPI == FEDDAT_EPI_GELU) {
                 if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(v);
                 f32x4 a;
-                a[0] = gelu_f(v[0]); a[1] = gelu_f(v[1]); a[2] = gelu_f(v[2]); a[3] = gelu_f(v[3]);
+                a = gelu4_pk(v);
                 *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
             } else if (EPI == FEDDAT_EPI_MUL_DGELU) {
                 f32x4 a;
-                a[0] = v[0] * gelu_grad_f((float)uu[i][0]); a[1] = v[1] * gelu_grad_f((float)uu[i][1]);
-                a[2] = v[2] * gelu_grad_f((float)uu[i][2]); a[3] = v[3] * gelu_grad_f((float)uu[i][3]);
+                a = v * gelu_grad4_pk(f32x4{(float)uu[i][0], (float)uu[i][1], (float)uu[i][2], (float)uu[i][3]});
                 *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
             } else {
                 *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v;
@@ -247,6 +246,9 @@ __device__ __forceinline__ void v2_piece_ptrs(const GemmArgs& g, int m0, int m_l
 template <int EPI>
 __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[3][6], char* stg, int mbase, int nbase,
                                             int m_end, int lane) {
+    // keep the per-lane index math of the (several, inlined) epilogue sites out of the main loop's live ranges:
+    // an opaque copy of the lane id cannot be hoisted across the k-loop
+    asm volatile("" : "+v"(lane));
     const int frow = lane & 15, fg = lane >> 4;
     f32x4 bias4[6];
 #pragma unroll
@@ -260,18 +262,29 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[3][6
         srow[p] = idx / 12;
         sc4[p] = idx - srow[p] * 12;
     }
-    f32x4 rr[2][3];
-    bf16x4 uu[2][3];
-    auto prefetch = [&](int c, f32x4 (&r)[3], bf16x4 (&u)[3]) {
+    // residual / aux operands of the whole wave tile are requested up front (18 loads per lane in flight: one exposed
+    // HBM latency per tile instead of one per chunk); the fragment registers of the k-loop are dead here
+    // residual / aux operands: three of the six chunks are in flight at any time (uniform base + 32-bit per-lane byte
+    // offsets; FD_CHECK_ARG bounds the operand below 4 GiB)
+    f32x4 rr[6][3];
+    bf16x4 uu[6][3];
+    const char* rbase = reinterpret_cast<const char*>(EPI == FEDDAT_EPI_RESID_F32 ? (const void*)(g.resid + nbase)
+                                                                                  : (const void*)(g.aux + nbase));
+    const unsigned esz = EPI == FEDDAT_EPI_RESID_F32 ? 4u : 2u;
+    const unsigned ld_b = (EPI == FEDDAT_EPI_RESID_F32 ? (unsigned)g.ldr : (unsigned)g.ldaux) * esz;
+    auto prefetch = [&](int c) {
         const int i = c >> 1, half = c & 1;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const int mc = min(mbase + i * 16 + srow[p], m_end - 1);
-            const int n = nbase + half * 48 + sc4[p] * 4;
-            if (EPI == FEDDAT_EPI_RESID_F32) r[p] = *reinterpret_cast<const f32x4*>(g.resid + (size_t)mc * g.ldr + n);
-            if (EPI == FEDDAT_EPI_MUL_DGELU) u[p] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)mc * g.ldaux + n);
+            const unsigned mc = (unsigned)min(mbase + i * 16 + srow[p], m_end - 1);
+            const unsigned off = mc * ld_b + ((unsigned)sc4[p] * 4u + half * 48) * esz;
+            if (EPI == FEDDAT_EPI_RESID_F32) rr[c][p] = *reinterpret_cast<const f32x4*>(rbase + off);
+            if (EPI == FEDDAT_EPI_MUL_DGELU) uu[c][p] = *reinterpret_cast<const bf16x4*>(rbase + off);
         }
     };
+    if (EPI == FEDDAT_EPI_RESID_F32 || EPI == FEDDAT_EPI_MUL_DGELU) {
+        prefetch(0); prefetch(1); prefetch(2);
+    }
     auto chunk = [&](int c, f32x4 (&r)[3], bf16x4 (&u)[3]) {
         const int i = c >> 1, half = c & 1;
 #pragma unroll
@@ -292,29 +305,23 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[3][6
             } else if (EPI == FEDDAT_EPI_RESID_F32) {
                 if (ok) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = x + r[p];
             } else if (EPI == FEDDAT_EPI_GELU) {
-                f32x4 a;
-                a[0] = gelu_f(x[0]); a[1] = gelu_f(x[1]); a[2] = gelu_f(x[2]); a[3] = gelu_f(x[3]);
+                const f32x4 a = gelu4_pk(x);
                 if (ok) {
                     if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(x);
                     *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
                 }
             } else if (EPI == FEDDAT_EPI_MUL_DGELU) {
-                f32x4 a;
-                a[0] = x[0] * gelu_grad_f((float)u[p][0]); a[1] = x[1] * gelu_grad_f((float)u[p][1]);
-                a[2] = x[2] * gelu_grad_f((float)u[p][2]); a[3] = x[3] * gelu_grad_f((float)u[p][3]);
+                const f32x4 a = x * gelu_grad4_pk(f32x4{(float)u[p][0], (float)u[p][1], (float)u[p][2], (float)u[p][3]});
                 if (ok) *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(a);
             } else {
                 if (ok) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = x;
             }
         }
     };
-    prefetch(0, rr[0], uu[0]);
 #pragma unroll
-    for (int c = 0; c < 6; c += 2) {
-        prefetch(c + 1, rr[1], uu[1]);
-        chunk(c, rr[0], uu[0]);
-        if (c + 2 < 6) prefetch(c + 2, rr[0], uu[0]);
-        chunk(c + 1, rr[1], uu[1]);
+    for (int c = 0; c < 6; ++c) {
+        chunk(c, rr[c], uu[c]);
+        if ((EPI == FEDDAT_EPI_RESID_F32 || EPI == FEDDAT_EPI_MUL_DGELU) && c + 3 < 6) prefetch(c + 3);
     }
 }
 
@@ -324,6 +331,7 @@ struct V2State {
     int l_tile, l_kt;     // tile index / k-tile of the next staging load
 };
 
+template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmArgs& g = a.g;
@@ -386,6 +394,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     const int frow = lane & 15, fg = lane >> 4;
     char* stg = smem + V2_EPI_OFF + wave * V2_EPI_WAVE;
     int kt = 0, c_tile = 0, st = 0;
+    bool pend = false;                  // a finished tile whose epilogue has not run yet
+    int pm0 = 0, pn0 = 0, pml = 0;
+    auto run_epilogue = [&](int em0, int en0, int eml) {
+        const int mb = em0 + wm * 48, nb = en0 + wn * 96, me = eml + 1;
+        if (!(a.dbg & 8)) v2_epilogue<EPI>(g, acc, stg, mb, nb, me, lane);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
     // prologue: k-tile 0 -> stage 0, k-tile 1 in flight to registers
     gload();
@@ -402,17 +420,45 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
         const char* ta = smem + st * V2_STAGE;
         const char* tb = ta + V2_TILE;
         bf16x8 fa[2][3], fb[2][6];
+        auto read_frags = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) fb[ks][j] = read_frag(tb, wn * 96 + j * 16 + frow, ks * 4 + fg);
+                for (int j = 0; j < 6; ++j) fb[ks][j] = read_frag(tb, wn * 96 + j * 16 + frow, ks * 4 + fg);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) fa[ks][i] = read_frag(ta, wm * 48 + i * 16 + frow, ks * 4 + fg);
+                for (int i = 0; i < 3; ++i) fa[ks][i] = read_frag(ta, wm * 48 + i * 16 + frow, ks * 4 + fg);
+            }
+        };
+        // Tile boundary: both wave groups run the epilogue of the finished tile in the SAME barrier slot (8 waves
+        // hide each other's LDS / store latency; staggered, each group's epilogue was exposed on its own).
+        //   group 0:  C(last) | staging of L(next 0) | EPILOGUE, fragment reads of L(next 0) | C(next 0) | ...
+        //   group 1:  L(last) | C(last)              | EPILOGUE                              | L(next 0) | ...
+        // No fragment registers are live while the epilogue runs.
+        auto staging = [&]() {
+            if (!(a.dbg & 1)) {
+                if (it + 1 < total_it) lwrite(st ^ 1);   // k-tile it+1: registers -> the other LDS stage
+                gload();                                  // k-tile it+2 -> registers
+            }
+        };
+        const bool boundary = pend;
+        if (boundary && grp == 0) {
+            staging();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(a.dbg & 1)) {
-        if (it + 1 < total_it) lwrite(st ^ 1);   // k-tile it+1: registers -> the other LDS stage
-        gload();                                  // k-tile it+2 -> registers
+        if (boundary) {
+            run_epilogue(pm0, pn0, pml);
+            pend = false;
+            if (grp == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        read_frags();
+        if (!(boundary && grp == 0)) staging();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -430,20 +476,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
         __builtin_amdgcn_s_setprio(0);
         st ^= 1;
         if (++kt == nk) {
-            const int mb = m0 + wm * 48, nb = n0 + wn * 96, me = m_last + 1;
-            if (!(a.dbg & 8))
-            switch (g.epi) {
-                case FEDDAT_EPI_BF16: v2_epilogue<FEDDAT_EPI_BF16>(g, acc, stg, mb, nb, me, lane); break;
-                case FEDDAT_EPI_RESID_F32: v2_epilogue<FEDDAT_EPI_RESID_F32>(g, acc, stg, mb, nb, me, lane); break;
-                case FEDDAT_EPI_GELU: v2_epilogue<FEDDAT_EPI_GELU>(g, acc, stg, mb, nb, me, lane); break;
-                case FEDDAT_EPI_MUL_DGELU: v2_epilogue<FEDDAT_EPI_MUL_DGELU>(g, acc, stg, mb, nb, me, lane); break;
-                default: v2_epilogue<FEDDAT_EPI_F32>(g, acc, stg, mb, nb, me, lane); break;
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             kt = 0;
+            pend = true; pm0 = m0; pn0 = n0; pml = m_last;      // epilogue: next iteration's boundary slot / after the loop
             if (++c_tile < my_tiles) v2_tile_coords(a, bid + c_tile * grid, total, m0, n0, m_last);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -451,6 +485,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+    __builtin_amdgcn_sched_barrier(0);
+    if (pend) run_epilogue(pm0, pn0, pml);        // last tile, both groups concurrently (A/B: not slower than staggered)
 }
 
 }  // namespace
@@ -465,9 +501,13 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     FD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K);
     switch (epi) {
         case FEDDAT_EPI_BF16: FD_CHECK_ARG(out_bf16 && ldo16 % 4 == 0); break;
-        case FEDDAT_EPI_RESID_F32: FD_CHECK_ARG(out_f32 && resid && ldr % 4 == 0 && ldo32 % 4 == 0); break;
+        case FEDDAT_EPI_RESID_F32:
+            FD_CHECK_ARG(out_f32 && resid && ldr % 4 == 0 && ldo32 % 4 == 0 && (size_t)M * ldr * 4 < (1ull << 32));
+            break;
         case FEDDAT_EPI_GELU: FD_CHECK_ARG(out_bf16 && ldo16 % 4 == 0 && (!out2_bf16 || ldo2 % 4 == 0)); break;
-        case FEDDAT_EPI_MUL_DGELU: FD_CHECK_ARG(out_bf16 && aux && ldaux % 4 == 0 && ldo16 % 4 == 0); break;
+        case FEDDAT_EPI_MUL_DGELU:
+            FD_CHECK_ARG(out_bf16 && aux && ldaux % 4 == 0 && ldo16 % 4 == 0 && (size_t)M * ldaux * 2 < (1ull << 32));
+            break;
         case FEDDAT_EPI_F32: FD_CHECK_ARG(out_f32 && ldo32 % 4 == 0); break;
         default: return FEDDAT_EINVAL;
     }
@@ -487,10 +527,14 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("FEDDAT_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
         a2.dbg = dbg;
+        using KernelFn = void (*)(GemmArgsV2);
+        static const KernelFn kernels[5] = {gemm_nt_v2_kernel<FEDDAT_EPI_BF16>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32>,
+                                            gemm_nt_v2_kernel<FEDDAT_EPI_GELU>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU>,
+                                            gemm_nt_v2_kernel<FEDDAT_EPI_F32>};
         static bool attr2 = false;
         if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      V2_LDS);
+            for (KernelFn k : kernels)
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
             attr2 = true;
         }
         static int n_cu = 0;
@@ -501,8 +545,9 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         const int total = a2.tiles_m * (N / V2_BN);
-        hipLaunchKernelGGL(gemm_nt_v2_kernel, dim3(total < n_cu ? total : n_cu), dim3(512), V2_LDS, stream,
-                           a2);
+        int grid = total < n_cu ? total : n_cu;
+        if ((dbg >> 8) > 0 && (dbg >> 8) < grid) grid = dbg >> 8;      // ablation: cap the number of persistent blocks
+        hipLaunchKernelGGL(kernels[epi], dim3(grid), dim3(512), V2_LDS, stream, a2);
         FD_LAUNCH_RET();
     }
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
