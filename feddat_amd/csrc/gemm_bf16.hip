@@ -213,7 +213,7 @@ struct GemmArgsV2 {
     GemmArgs g;
     int bm;        // rows per M tile (<= 192)
     int tiles_m;
-    int dbg;       // FEDDAT_GEMM_DEBUG ablation flags: 8 = skip epilogue, 2 = skip MFMA, 1 = skip staging
+    int dbg;       // FEDDAT_GEMM_DEBUG ablation flags: 8 = skip epilogue; bits 8.. = cap on the number of blocks
 };
 
 __device__ __forceinline__ void v2_tile_coords(const GemmArgsV2& a, int tile_id, int total, int& m0, int& n0,
@@ -358,37 +358,45 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     v2_piece_ptrs(g, m0, m_last, n0, wave, lane, L.pa, L.pb);
     L.l_tile = 0;
     L.l_kt = 0;
-    int issued = 0;                     // k-tiles whose staging loads have been issued
+    int issued = 0;                     // k-tiles whose staging loads have been issued (may run past total_it)
     // LDS byte offset of this lane inside a piece: row (lane >> 3), chunk (lane & 7) ^ (row & 7); piece p at p * 1024
     const int lds_lane = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 3)) & 7) << 4);
     const int lds_wave = wave * 3 * 1024;
 
-    u32x4 ra[3], rb[3];     // staging registers: k-tile it+2 is in flight here while k-tile it+1 sits in LDS
-
-    auto gload = [&]() {
-        if (issued < total_it) {
-            const int koff = L.l_kt * BK;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) ra[i] = *reinterpret_cast<const u32x4*>(L.pa[i] + koff);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) rb[i] = *reinterpret_cast<const u32x4*>(L.pb[i] + koff);
-            ++issued;
+    // Staging registers (one set): the k-tile this wave writes to LDS next.  The stream position (pointers, l_kt)
+    // always addresses k-tile min(issued, total_it - 1), so loads past the end of the stream re-read the last k-tile
+    // and the k-loop needs no branches around its staging instructions.
+    u32x4 rs[6];            // pieces 0..2 = A rows, 3..5 = B rows
+    int written = 0;        // k-tiles of the stream this wave has written to LDS
+    auto gload_piece = [&](int p) {
+        const int koff = L.l_kt * BK;
+        rs[p] = *reinterpret_cast<const u32x4*>((p < 3 ? L.pa[p] : L.pb[p - 3]) + koff);
+    };
+    auto stream_advance = [&]() {
+        if (issued + 1 < total_it) {
             if (++L.l_kt == nk) {
                 L.l_kt = 0;
-                if (++L.l_tile < my_tiles) {
-                    int lm0, ln0, lml;
-                    v2_tile_coords(a, bid + L.l_tile * grid, total, lm0, ln0, lml);
-                    v2_piece_ptrs(g, lm0, lml, ln0, wave, lane, L.pa, L.pb);
-                }
+                ++L.l_tile;
+                int lm0, ln0, lml;
+                v2_tile_coords(a, bid + L.l_tile * grid, total, lm0, ln0, lml);
+                v2_piece_ptrs(g, lm0, lml, ln0, wave, lane, L.pa, L.pb);
             }
         }
+        ++issued;
+    };
+    auto lwrite_piece = [&](int p, int stage) {
+        char* sb = smem + stage * V2_STAGE + lds_wave + lds_lane + (p < 3 ? p * 1024 : V2_TILE + (p - 3) * 1024);
+        *reinterpret_cast<u32x4*>(sb) = rs[p];
+    };
+    auto gload = [&]() {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) gload_piece(p);
+        stream_advance();
     };
     auto lwrite = [&](int stage) {
-        char* sb = smem + stage * V2_STAGE + lds_wave + lds_lane;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(sb + i * 1024) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(sb + V2_TILE + i * 1024) = rb[i];
+        for (int p = 0; p < 6; ++p) lwrite_piece(p, stage);
+        ++written;
     };
 
     const int frow = lane & 15, fg = lane >> 4;
@@ -405,10 +413,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
             for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    // prologue: k-tile 0 -> stage 0, k-tile 1 in flight to registers
+    // Staging runs in the shadow of the MFMAs: in its C phase of k-tile j a wave of group 0 writes its pieces of
+    // k-tile j+1 (read by group 0 in the very next barrier slot), a wave of group 1 -- one slot behind -- its pieces
+    // of k-tile j+2; each piece's register is refilled from global memory right after it has been written.
+    //   slot:      2j        2j+1       2j+2       2j+3       2j+4
+    //   group 0:   L(j)      C(j) w j+1 L(j+1)     C(j+1) w j+2  L(j+2)
+    //   group 1:   C(j-1) w j+1   L(j)  C(j) w j+2 L(j+1)     C(j+1) w j+3
+    // A stage is rewritten only after both groups' reads of it have retired (lgkmcnt(0) before a barrier they passed).
+    // prologue: k-tile 0 (group 1: also k-tile 1) -> LDS, the next one in flight to registers
     gload();
     lwrite(0);
     gload();
+    if (grp == 1) {
+        lwrite(1);
+        gload();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -434,16 +453,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
         //   group 0:  C(last) | staging of L(next 0) | EPILOGUE, fragment reads of L(next 0) | C(next 0) | ...
         //   group 1:  L(last) | C(last)              | EPILOGUE                              | L(next 0) | ...
         // No fragment registers are live while the epilogue runs.
-        auto staging = [&]() {
-            if (!(a.dbg & 1)) {
-                if (it + 1 < total_it) lwrite(st ^ 1);   // k-tile it+1: registers -> the other LDS stage
-                gload();                                  // k-tile it+2 -> registers
-            }
-        };
         const bool boundary = pend;
-        if (boundary && grp == 0) {
-            staging();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (boundary && grp == 0) {      // group 0 idles one slot (group 1 finishes its last C phase)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -458,22 +469,29 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
             }
         }
         read_frags();
-        if (!(boundary && grp == 0)) staging();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ------------------------------ C phase ------------------------------
+        // 6 groups of 6 MFMAs; after group p: ds_write of staging piece p, then its global reload
+        const int wstage = written & 1;
         __builtin_amdgcn_s_setprio(1);
-        if (!(a.dbg & 2)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc[i][j] = mfma16x32(fb[ks][j], fa[ks][i], acc[i][j]);
-        }
+                __builtin_amdgcn_sched_barrier(0);     // MFMAs first: the write's lgkmcnt must not gate them
+                lwrite_piece(ks * 3 + i, wstage);      // straight-line code: the compiler's vmcnt / lgkmcnt counts
+                gload_piece(ks * 3 + i);               // stay exact (any branch here degrades them to waits for 0)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         __builtin_amdgcn_s_setprio(0);
+        ++written;
+        stream_advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's ds_writes, before the barrier below
         st ^= 1;
         if (++kt == nk) {
             kt = 0;
