@@ -400,6 +400,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     };
 
     const int frow = lane & 15, fg = lane >> 4;
+    // fragment read of row r (a multiple of 16 + frow), k-half ks: 16-byte chunk (4 ks + fg) ^ (frow & 7) of the row
+    const int frag_off[2] = {frow * 128 + (((0 + fg) ^ (frow & 7)) << 4), frow * 128 + (((4 + fg) ^ (frow & 7)) << 4)};
     char* stg = smem + V2_EPI_OFF + wave * V2_EPI_WAVE;
     int kt = 0, c_tile = 0, st = 0;
     bool pend = false;                  // a finished tile whose epilogue has not run yet
@@ -436,16 +438,20 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 
     for (int it = 0; it < total_it; ++it) {
         // ------------------------------ L phase ------------------------------
-        const char* ta = smem + st * V2_STAGE;
-        const char* tb = ta + V2_TILE;
         bf16x8 fa[2][3], fb[2][6];
         auto read_frags = [&]() {
+            // address = per-lane swizzled offset (loop invariant, one per k-half) + wave-uniform tile base + immediate
+            const int a_base = st * V2_STAGE + wm * (48 * 128);
+            const int b_base = st * V2_STAGE + V2_TILE + wn * (96 * 128);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                const char* pb_ = smem + (frag_off[ks] + b_base);
+                const char* pa_ = smem + (frag_off[ks] + a_base);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) fb[ks][j] = read_frag(tb, wn * 96 + j * 16 + frow, ks * 4 + fg);
+                for (int j = 0; j < 6; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(pb_ + j * 2048);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) fa[ks][i] = read_frag(ta, wm * 48 + i * 16 + frow, ks * 4 + fg);
+                for (int i = 0; i < 3; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(pa_ + i * 2048);
+                __builtin_amdgcn_sched_barrier(0);      // keep the k-half-0 reads first in the LDS queue
             }
         };
         // Tile boundary: both wave groups run the epilogue of the finished tile in the SAME barrier slot (8 waves
@@ -469,7 +475,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
             }
         }
         read_frags();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // no wait here: the compiler waits (counted) for each fragment right before the MFMA group that uses it, so
+        // the k-half-1 fragments land under the k-half-0 MFMAs; every fragment has been waited for by the end of
+        // the C phase, whose lgkmcnt(0) + barrier is what a later overwrite of this stage is ordered against
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
