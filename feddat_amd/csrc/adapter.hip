@@ -234,7 +234,7 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
     }
 }
 
-__global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dx, bf16* __restrict__ dx16,
                                                           float* __restrict__ z_out, float* __restrict__ dz_out,
                                                           AdapterLaunch L) {
@@ -250,7 +250,12 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
                                                            bf16* __restrict__ wd16, bf16* __restrict__ wdT16,
-                                                           bf16* __restrict__ wu16, bf16* __restrict__ wuT16) {
+                                                           bf16* __restrict__ wu16, bf16* __restrict__ wuT16,
+                                                           long stride32, long stride16) {
+    // blockIdx.y = adapter module (layer) of a strided batch
+    wd += blockIdx.y * stride32; wu += blockIdx.y * stride32;
+    wd16 += blockIdx.y * stride16; wdT16 += blockIdx.y * stride16;
+    wu16 += blockIdx.y * stride16; wuT16 += blockIdx.y * stride16;
     // wd [R,H] -> wd16 [R,H] slot-permuted along H, wdT16 [H,R];  wu [H,R] -> wu16 [H,R], wuT16 [R,H] slot-permuted.
     // permutation of a feature index c (see down_proj): q = c / 32, half = (c % 32) / 16, g = (c % 16) / 4, j = c % 4
     //   -> position 32 q + 8 g + 4 half + j
@@ -327,6 +332,16 @@ extern "C" int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf
                                    void* wuT_bf16, int Hd, int r, hipStream_t stream) {
     FD_CHECK_ARG(wd && wu && wd_bf16 && wdT_bf16 && wu_bf16 && wuT_bf16 && Hd == H && r == R);
     hipLaunchKernelGGL(adapter_pack_kernel, dim3((R * H + 255) / 256), dim3(256), 0, stream, wd, wu, (bf16*)wd_bf16,
-                       (bf16*)wdT_bf16, (bf16*)wu_bf16, (bf16*)wuT_bf16);
+                       (bf16*)wdT_bf16, (bf16*)wu_bf16, (bf16*)wuT_bf16, 0L, 0L);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adapter_pack_strided(const float* wd, const float* wu, long stride_f32, void* wd_bf16,
+                                           void* wdT_bf16, void* wu_bf16, void* wuT_bf16, long stride_bf16, int n,
+                                           int Hd, int r, hipStream_t stream) {
+    FD_CHECK_ARG(wd && wu && wd_bf16 && wdT_bf16 && wu_bf16 && wuT_bf16 && Hd == H && r == R);
+    FD_CHECK_ARG(n > 0 && n <= 65535 && stride_f32 >= 0 && stride_bf16 >= 0);
+    hipLaunchKernelGGL(adapter_pack_kernel, dim3((R * H + 255) / 256, n), dim3(256), 0, stream, wd, wu, (bf16*)wd_bf16,
+                       (bf16*)wdT_bf16, (bf16*)wu_bf16, (bf16*)wuT_bf16, stride_f32, stride_bf16);
     FD_LAUNCH_RET();
 }

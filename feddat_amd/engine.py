@@ -144,6 +144,7 @@ class ViltDatEngine:
             for n in grp.names:
                 grp.view(n).copy_(params[n].to(dev, torch.float32))
         # bf16 operand copies of the adapters: [a][layer] -> dict(wd, wdT, wu, wuT, bd, bu)
+        self._pack16 = {}
         self.ad16 = [[self._alloc_pack(a, i) for i in range(layers)] for a in range(3)]
         for a in range(3):
             self.repack_adapter(a)
@@ -209,19 +210,31 @@ class ViltDatEngine:
 
     # ------------------------------------------------------------------------------------------ adapters
     def _alloc_pack(self, a, i):
-        H, r, dev = self.H, self.r, self.dev
+        H, r = self.H, self.r
         base = ENC + f"encoder.layer.{i}.output.adapter.adapter_{a}_"
-
-        def b16(*s):
-            return torch.empty(*s, dtype=torch.bfloat16, device=dev)
-        return dict(wd=b16(r, H), wdT=b16(H, r), wu=b16(H, r), wuT=b16(r, H),
+        if a not in self._pack16:       # bf16 operand copies of all layers of adapter a: [layer][wd | wdT | wu | wuT]
+            self._pack16[a] = torch.empty(self.nl, 4, r * H, dtype=torch.bfloat16, device=self.dev)
+        c = self._pack16[a][i]
+        return dict(wd=c[0].view(r, H), wdT=c[1].view(H, r), wu=c[2].view(H, r), wuT=c[3].view(r, H),
                     bd=self.ad[a].view(base + "down.bias"), bu=self.ad[a].view(base + "up.bias"),
                     wd32=self.ad[a].view(base + "down.weight"), wu32=self.ad[a].view(base + "up.weight"))
 
     def repack_adapter(self, a: int):
-        """fp32 masters -> bf16 MFMA operand copies (after every optimizer step / load / FedAvg)."""
-        for p in self.ad16[a]:
-            L.adapter_pack(p["wd32"], p["wu32"], p["wd"], p["wdT"], p["wu"], p["wuT"])
+        """fp32 masters -> bf16 MFMA operand copies (after every optimizer step / load / FedAvg): one launch for all
+        layers when the flat fp32 layout is regular (it is: four tensors per layer, fixed order)."""
+        packs = self.ad16[a]
+        offs = [p["wd32"].data_ptr() for p in packs]
+        stride = (offs[1] - offs[0]) // 4 if len(offs) > 1 else 0
+        regular = all(offs[i] - offs[0] == 4 * stride * i for i in range(len(offs))) and all(
+            p["wu32"].data_ptr() - p["wd32"].data_ptr() == packs[0]["wu32"].data_ptr() - packs[0]["wd32"].data_ptr()
+            for p in packs)
+        if regular:
+            p0 = packs[0]
+            L.adapter_pack_strided(p0["wd32"], p0["wu32"], stride, p0["wd"], p0["wdT"], p0["wu"], p0["wuT"],
+                                   4 * self.r * self.H, len(packs))
+        else:
+            for p in packs:
+                L.adapter_pack(p["wd32"], p["wu32"], p["wd"], p["wdT"], p["wu"], p["wuT"])
 
     def copy_global_to_teacher(self):
         """adapter_1 -> adapter_2 at the start of every local update (task_trainer.py:36-41)."""

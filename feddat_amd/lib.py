@@ -41,6 +41,7 @@ _SIGS = {
     "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_pack": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "feddat_adapter_pack_strided": [vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "feddat_adapter_wgrad_workspace_elems": [i32],
     "feddat_adapter_wgrad": [C.POINTER(WgradSeg), i32, vp, i64, i32, i32, vp],
     "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
@@ -212,6 +213,12 @@ def adapter_wgrad(segs_arr, partials, H=768, r=48):
     _dev(partials)
     _chk(load().feddat_adapter_wgrad(segs_arr, len(segs_arr), _p(partials), partials.numel(), H, r, _stream()),
          "feddat_adapter_wgrad")
+
+
+def adapter_pack_strided(wd, wu, stride32, wd16, wdT16, wu16, wuT16, stride16, n, H=768, r=48):
+    _dev(wd, wu, wd16)
+    _chk(load().feddat_adapter_pack_strided(_p(wd), _p(wu), stride32, _p(wd16), _p(wdT16), _p(wu16), _p(wuT16), stride16,
+                                            n, H, r, _stream()), "feddat_adapter_pack_strided")
 
 
 def adapter_pack(wd, wu, wd16, wdT16, wu16, wuT16, H=768, r=48):

@@ -128,6 +128,12 @@ int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials
 int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* wdT_bf16, void* wu_bf16,
                         void* wuT_bf16, int H, int r, hipStream_t stream);
 
+/* The same for n adapter modules in one launch (all layers of adapter_a after an optimizer step): module l reads
+ * wd + l * stride_f32 / wu + l * stride_f32 (floats) and writes each bf16 copy at + l * stride_bf16 (elements). */
+int feddat_adapter_pack_strided(const float* wd, const float* wu, long stride_f32, void* wd_bf16, void* wdT_bf16,
+                                void* wu_bf16, void* wuT_bf16, long stride_bf16, int n, int H, int r,
+                                hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Small exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 with arbitrary strides and split-K partial sums:
  *   for split s: D_s[i][j] = alpha * sum_{k in chunk s} A[i*sa_i + k*sa_k] * B[k*sb_k + j*sb_j]
