@@ -51,15 +51,21 @@ __device__ __forceinline__ void load_head(const bf16* __restrict__ src, long ld,
     }
 }
 
+// row fragment of a [S][64] bf16 slice straight from global memory (zero beyond S)
+__device__ __forceinline__ bf16x8 gload_frag(const bf16* base, long ld, int row, int S, int chunk) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < S) v = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + chunk * 8);
+    return v;
+}
+
 template <int NKS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask,
                                                        bf16* __restrict__ ctx, float* __restrict__ lse, int S,
                                                        int heads) {
     constexpr int S_pad = NKS * 32, NKT = NKS * 2, NQT = NKS * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qs = smem;
-    char* Ks = Qs + S_pad * ROWB;
-    char* Vs = Ks + S_pad * ROWB;
+    char* Ks = smem;                 // K and V of the head live in LDS (3 blocks per CU at S <= 192); the two Q row
+    char* Vs = Ks + S_pad * ROWB;    // fragments of a query tile are read once, straight from HBM
     float* mask_add = reinterpret_cast<float*>(Vs + S_pad * ROWB);  // 0 or -inf per key
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,7 +73,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const int H = heads * D;
     const long ld = 3L * H;
     const bf16* base = qkv + (size_t)b * S * ld + h * D;
-    load_head(base, ld, S, S_pad, Qs, tid);
     load_head(base + H, ld, S, S_pad, Ks, tid);
     load_head(base + 2 * H, ld, S, S_pad, Vs, tid);
     for (int k = tid; k < S_pad; k += 256) {
@@ -80,8 +85,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     for (int qt = wave; qt < NQT; qt += 4) {
         if (qt * 16 >= S) break;
         bf16x8 qf[2];
-        qf[0] = row_frag(Qs, qt * 16 + i16, g);
-        qf[1] = row_frag(Qs, qt * 16 + i16, 4 + g);
+        qf[0] = gload_frag(base, ld, qt * 16 + i16, S, g);
+        qf[1] = gload_frag(base, ld, qt * 16 + i16, S, 4 + g);
         // S^T tiles: rows = keys kt*16 + 4g + r, col = query i16
         f32x4 s[NKT];
         float mx = -INFINITY;
@@ -144,11 +149,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 //                    fragments come straight from HBM into registers; scores in [q rows, key col] orientation.
 //   role 1 (dQ):     waves own 16-query tiles; K and V live in LDS, the tile's Q / dO fragments, LSE and
 //                    D = rowsum(dO * O) come from HBM; scores in [key rows, q col] orientation.
-__device__ __forceinline__ bf16x8 gload_frag(const bf16* base, long ld, int row, int S, int chunk) {
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < S) v = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + chunk * 8);
-    return v;
-}
 
 template <int NKS>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask,
@@ -334,9 +334,9 @@ extern "C" int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* c
                                int heads, hipStream_t stream) {
     FD_CHECK_ARG(qkv && ctx && B > 0 && S > 0 && S <= 320 && heads > 0);
     const int nks = (S + 31) / 32;
-    const int lds = nks * 32 * ROWB * 3 + nks * 32 * 4;
+    const int lds = nks * 32 * ROWB * 2 + nks * 32 * 4;
     static bool fdone[11] = {false};
-#define NKS_MAX_LDS_F(N) ((N) * 32 * ROWB * 3 + (N) * 32 * 4)
+#define NKS_MAX_LDS_F(N) ((N) * 32 * ROWB * 2 + (N) * 32 * 4)
 #define ATTN_FWD(N)                                                                                           \
     case N:                                                                                                   \
         if (set_lds(attn_fwd_kernel<N>, NKS_MAX_LDS_F(N), fdone[N])) return FEDDAT_ELAUNCH;                                        \
