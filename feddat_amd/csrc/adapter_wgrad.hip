@@ -24,9 +24,10 @@ struct WgradLaunch {
     int nseg;
 };
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradLaunch L) {
+__global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradLaunch L) {   // 3 blocks per CU: all 768 blocks resident
     __shared__ __attribute__((aligned(16))) float red[3][64][NRT * 4 * 4 + 4];  // waves 1..3 -> wave 0
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the token loop must not be divergent
     const int g = lane >> 4, i16 = lane & 15;
     const int chunk = blockIdx.x, blk = blockIdx.y;
     const int prob = blockIdx.z;            // 2 * seg + which (0: dW_down = dz^T x, 1: dW_up^T = z^T dy)
@@ -49,26 +50,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradLaunch L) {
         for (int v = 0; v < 4; ++v) acc[rt][v] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     float ssum[NRT] = {0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int t0 = t_begin; t0 < t_end; t0 += 4) {
-        const int t = t0 + g;
-        const bool ok = t < t_end;
-        const int tc = ok ? t : t_begin;
-        f32x4 b4 = *reinterpret_cast<const f32x4*>(big + (size_t)tc * H + c0 + 4 * i16);
-        float s[NRT];
+    // U groups of 4 tokens per round, all loads of a round issued before its MFMAs: 8 x (16 + 3 x 4) bytes per lane in
+    // flight (with one group per iteration the loop ran at HBM latency, 1.5 TB/s)
+    constexpr int U = 4;
+    for (int t0 = t_begin; t0 < t_end; t0 += 4 * U) {
+        f32x4 b4[U];
+        float s[U][NRT];
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) s[rt] = sm[(size_t)tc * R + rt * 16 + i16];
-        if (!ok) {
-            b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 4 * u + g;
+            const int tc = t < t_end ? t : t_begin;
+            b4[u] = *reinterpret_cast<const f32x4*>(big + (size_t)tc * H + c0 + 4 * i16);
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) s[rt] = 0.f;
+            for (int rt = 0; rt < NRT; ++rt) s[u][rt] = sm[(size_t)tc * R + rt * 16 + i16];
         }
-        bsum = bsum + b4;
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) {
-            ssum[rt] += s[rt];
+        for (int u = 0; u < U; ++u) {
+            const bool ok = t0 + 4 * u + g < t_end;
+            if (!ok) {
+                b4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[rt][v] = mfma16x4_f32(s[rt], b4[v], acc[rt][v]);
+                for (int rt = 0; rt < NRT; ++rt) s[u][rt] = 0.f;
+            }
+            bsum = bsum + b4[u];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                ssum[rt] += s[u][rt];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[rt][v] = mfma16x4_f32(s[u][rt], b4[u][v], acc[rt][v]);
+            }
         }
     }
     // column sums: reduce over the 4 token slots (g) of the wave
