@@ -50,7 +50,7 @@ __device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const 
         for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w[a] + (size_t)(nt * 16 + i16) * H + q * 32 + g * 8);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w[a] + ((nt * KS + q) * 64 + lane) * 8);
                 z[a][nt] = mfma16x32(wf, xf, z[a][nt]);
             }
     }
@@ -61,12 +61,10 @@ __device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const 
 // Both products use the K=32 instruction: chaining v_mfma_f32_16x16x32_bf16 -> v_mfma_f32_16x16x16_bf16 on one
 // accumulator returned stale values in accumulator registers 0-1 on gfx950 / ROCm 7.2 (measured), so the K=16
 // form is not used anywhere.
-__device__ __forceinline__ void load_w48(const bf16* w, int row, int g, bf16x8& w01, bf16x8& w2) {
-    const bf16* p = w + (size_t)row * R + 4 * g;
-    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
-    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 16);
-    const bf16x4 c = *reinterpret_cast<const bf16x4*>(p + 32);
-    w01 = bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+__device__ __forceinline__ void load_w48(const bf16* w, int ct, int lane, bf16x8& w01, bf16x8& w2) {
+    // fragment-major copy written by adapter_pack: [ct][lane][8] (r = 4g+j, 16+4g+j) then [ct][lane][4] (r = 32+4g+j)
+    w01 = *reinterpret_cast<const bf16x8*>(w + (ct * 64 + lane) * 8);
+    const bf16x4 c = *reinterpret_cast<const bf16x4*>(w + CT * 64 * 8 + (ct * 64 + lane) * 4);
     w2 = bf16x8{c[0], c[1], c[2], c[3], 0, 0, 0, 0};
 }
 __device__ __forceinline__ bf16x8 pad8(const f32x4 a) {
@@ -134,7 +132,7 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             bf16x8 w01, w2;
-            load_w48((const bf16*)sg.wu[a], ct * 16 + i16, g, w01, w2);
+            load_w48((const bf16*)sg.wu[a], ct, lane, w01, w2);
             f32x4 y = mfma16x32(w01, zb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
             y = mfma16x32(w2, zb2[a], y);
             const f32x4 bu4 = *reinterpret_cast<const f32x4*>(sg.bu[a] + c);
@@ -222,7 +220,7 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             bf16x8 w01, w2;
-            load_w48((const bf16*)sg.wdT[a], ct * 16 + i16, g, w01, w2);
+            load_w48((const bf16*)sg.wdT[a], ct, lane, w01, w2);
             f32x4 y = mfma16x32(w01, dzb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
             y = mfma16x32(w2, dzb2[a], y);
             o = o + y;
@@ -259,21 +257,35 @@ __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restri
     // wd [R,H] -> wd16 [R,H] slot-permuted along H, wdT16 [H,R];  wu [H,R] -> wu16 [H,R], wuT16 [R,H] slot-permuted.
     // permutation of a feature index c (see down_proj): q = c / 32, half = (c % 32) / 16, g = (c % 16) / 4, j = c % 4
     //   -> position 32 q + 8 g + 4 half + j
+    // Both operand copies are FRAGMENT-MAJOR: the 64 lanes of a wave read 64 consecutive 16-byte (8-byte) pieces, so
+    // every weight load of the adapter kernels is one contiguous 1 KiB (512 B) burst.
+    //   "down-type" copy of a [R][H] matrix (wd, wuT): piece ((nt * KS + q) * 64 + g * 16 + i16) = row nt * 16 + i16,
+    //       permuted positions 32 q + 8 g + (0..7)
+    //   "up-type" copy of a [H][R] matrix (wu, wdT): piece (ct * 64 + g * 16 + i16) of 8 = row ct * 16 + i16, columns
+    //       4g..4g+3, 16+4g..16+4g+3; after CT * 64 of those, pieces of 4 = columns 32+4g..32+4g+3
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R * H) return;
+    auto down_idx = [](int r, int c) {
+        const int pc = (c & ~31) + (((c & 15) >> 2) << 3) + (((c >> 4) & 1) << 2) + (c & 3);
+        const int q = pc >> 5, g = (pc & 31) >> 3, j = pc & 7;
+        return ((((r >> 4) * KS + q) * 64 + g * 16 + (r & 15)) << 3) + j;
+    };
+    auto up_idx = [](int c, int r) {
+        const int ct = c >> 4, i16 = c & 15, seg = r >> 4, g = (r & 15) >> 2, e = r & 3;
+        const int lane = g * 16 + i16;
+        return seg < 2 ? ((ct * 64 + lane) << 3) + seg * 4 + e : CT * 64 * 8 + ((ct * 64 + lane) << 2) + e;
+    };
     {
         const int r = i / H, c = i - r * H;
-        const int pc = (c & ~31) + (((c & 15) >> 2) << 3) + (((c >> 4) & 1) << 2) + (c & 3);
         const bf16 v = (bf16)wd[i];
-        wd16[(size_t)r * H + pc] = v;
-        wdT16[(size_t)c * R + r] = v;
+        wd16[down_idx(r, c)] = v;
+        wdT16[up_idx(c, r)] = v;
     }
     {
         const int c = i / R, r = i - c * R;
-        const int pc = (c & ~31) + (((c & 15) >> 2) << 3) + (((c >> 4) & 1) << 2) + (c & 3);
         const bf16 v = (bf16)wu[i];
-        wu16[i] = v;
-        wuT16[(size_t)r * H + pc] = v;
+        wu16[up_idx(c, r)] = v;
+        wuT16[down_idx(r, c)] = v;
     }
 }
 

@@ -122,9 +122,11 @@ typedef struct {
 long feddat_adapter_wgrad_workspace_elems(int nseg);
 int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int H, int r,
                          hipStream_t stream);
-/* fp32 masters -> bf16 MFMA operand copies.  wdT [H,r] and wu [H,r] are plain casts/transposes; wd [r,H] and wuT [r,H]
- * are stored slot-permuted along H (feature c at 32*(c/32) + 8*((c%16)/4) + 4*((c%32)/16) + c%4) so that the fused
- * kernels' contraction slots coincide with their 16-byte residual columns; treat all four as opaque operands. */
+/* fp32 masters -> bf16 MFMA operand copies (r*H elements each).  All four are stored FRAGMENT-MAJOR -- the 64 lanes of
+ * a wave read 64 consecutive 16-byte pieces, i.e. one contiguous 1 KiB burst per weight load -- with the contraction
+ * slots of wd / wuT permuted along H (feature c at 32*(c/32) + 8*((c%16)/4) + 4*((c%32)/16) + c%4) so that they coincide
+ * with the kernels' 16-byte residual columns (exact index maps: adapter_pack_kernel in csrc/adapter.hip, checked by
+ * tests/test_ops_gpu.py::test_adapter_pack).  Treat them as opaque operands of feddat_adapter_fwd/bwd. */
 int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* wdT_bf16, void* wu_bf16,
                         void* wuT_bf16, int H, int r, hipStream_t stream);
 

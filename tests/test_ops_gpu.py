@@ -163,15 +163,20 @@ def _golden_adapter(L, golden_dir):
 
 
 def test_adapter_pack(L, golden_dir):
+    """Fragment-major operand copies (documented in feddat_hip.h / adapter.hip): every wave load is one contiguous burst."""
     g, par = _golden_adapter(L, golden_dir)
-    c = torch.arange(768)
-    perm = (c // 32) * 32 + ((c % 16) // 4) * 8 + ((c % 32) // 16) * 4 + c % 4     # documented in feddat_hip.h
-    inv = torch.empty_like(perm)
-    inv[perm] = c
-    assert torch.equal(par[0]["wd"][:, perm.to(DEV)], bf(par[0]["wd32"]))
-    assert torch.equal(par[0]["wdT"], bf(par[0]["wd32"]).t().contiguous())
-    assert torch.equal(par[0]["wu"], bf(par[0]["wu32"]))
-    assert torch.equal(par[0]["wuT"][:, perm.to(DEV)], bf(par[0]["wu32"]).t().contiguous())
+    r, c = torch.meshgrid(torch.arange(48), torch.arange(768), indexing="ij")
+    pc = (c // 32) * 32 + ((c % 16) // 4) * 8 + ((c % 32) // 16) * 4 + c % 4
+    q, gg, j = pc // 32, (pc % 32) // 8, pc % 8
+    down_idx = ((((r // 16) * 24 + q) * 64 + gg * 16 + r % 16) * 8 + j).reshape(-1).to(DEV)
+    ct, i16, seg, g4, e = c // 16, c % 16, r // 16, (r % 16) // 4, r % 4
+    lane = g4 * 16 + i16
+    up_idx = torch.where(seg < 2, (ct * 64 + lane) * 8 + seg * 4 + e, 48 * 64 * 8 + (ct * 64 + lane) * 4 + e).reshape(-1).to(DEV)
+    wd, wu = bf(par[0]["wd32"]), bf(par[0]["wu32"])          # [48,768], [768,48]
+    assert torch.equal(par[0]["wd"].reshape(-1)[down_idx], wd.reshape(-1))
+    assert torch.equal(par[0]["wdT"].reshape(-1)[up_idx], wd.reshape(-1))
+    assert torch.equal(par[0]["wuT"].reshape(-1)[down_idx], wu.t().contiguous().reshape(-1))
+    assert torch.equal(par[0]["wu"].reshape(-1)[up_idx], wu.t().contiguous().reshape(-1))
 
 
 def test_adapter_fwd_bwd_vs_reference_golden(L, golden_dir):
