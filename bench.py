@@ -98,11 +98,16 @@ def profiled_traffic(kernel_substr="gemm_nt_v2_kernel"):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
     if not files:
         return None
+    tot, n = 0.0, 0        # the kernel is templated on its epilogue: dispatch-weighted mean over all instantiations
     for r in csv.DictReader(open(files[-1])):
         if kernel_substr in r["kernel"] and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
-            return {"bytes_per_launch": round((2 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024),
-                    "source": os.path.basename(files[-1]), "note": "average over the launches of one step (all shapes)"}
-    return None
+            k = int(r["dispatches"])
+            tot += k * (2 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024
+            n += k
+    if not n:
+        return None
+    return {"bytes_per_launch": round(tot / n), "source": os.path.basename(files[-1]),
+            "note": "mean over the launches of one step (all shapes and epilogues)"}
 
 
 def cpu_baseline(params_cpu, B, res, task, budget_s=20.0):

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void image_assemble_kernel(const float* __rest
                                                              const float* __restrict__ pos0,
                                                              const float* __restrict__ pos_img,
                                                              const float* __restrict__ mod1, float* __restrict__ h,
-                                                             int B, int Lt, int np, int S, int H) {
+                                                             int B, int Lt, int np, int S, int H, long pos_bstride) {
     const int nc = H >> 2;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)B * (np + 1) * nc;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void image_assemble_kernel(const float* __rest
     } else {
         const int p = t - 1;
         o = (*reinterpret_cast<const f32x4*>(proj + ((size_t)b * np + p) * H + c * 4) +
-             *reinterpret_cast<const f32x4*>(pos_img + (size_t)p * H + c * 4)) + m4;
+             *reinterpret_cast<const f32x4*>(pos_img + (size_t)b * pos_bstride + (size_t)p * H + c * 4)) + m4;
     }
     *reinterpret_cast<f32x4*>(h + ((size_t)b * S + Lt + t) * H + c * 4) = o;
 }
@@ -124,6 +124,56 @@ __global__ __launch_bounds__(256) void pos_resize_kernel(const float* __restrict
     const float v00 = grid[((size_t)y0 * g + x0) * H + c], v01 = grid[((size_t)y0 * g + x1) * H + c];
     const float v10 = grid[((size_t)y1 * g + x0) * H + c], v11 = grid[((size_t)y1 * g + x1) * H + c];
     out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+// HF ViltEmbeddings.visual_embed for padded images: per sample the valid patch rectangle is h = #valid rows of patch
+// column 0, w = #valid columns of patch row 0 of the pixel mask sampled at the patch origins (F.interpolate 'nearest');
+// the g x g grid is resized to h x w (bilinear, align_corners=True), placed top-left, zero elsewhere.
+__global__ __launch_bounds__(256) void pos_resize_masked_kernel(const float* __restrict__ grid,
+                                                                const long* __restrict__ pmask,
+                                                                float* __restrict__ out, int g, int Hi, int Wi, int P,
+                                                                int H) {
+    const int gh = Hi / P, gw = Wi / P;
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)gh * gw * H) return;
+    const long* pm = pmask + (size_t)b * Hi * Wi;
+    int vh = 0, vw = 0;
+    for (int y = 0; y < gh; ++y) vh += pm[(size_t)y * P * Wi] != 0;
+    for (int x = 0; x < gw; ++x) vw += pm[(size_t)x * P] != 0;
+    const int c = (int)(i % H);
+    const int x = (int)((i / H) % gw);
+    const int y = (int)(i / ((long)H * gw));
+    float v = 0.f;
+    if (y < vh && x < vw) {
+        const float sy = vh > 1 ? ((float)(g - 1) / (float)(vh - 1)) * (float)y : 0.f;
+        const float sx = vw > 1 ? ((float)(g - 1) / (float)(vw - 1)) * (float)x : 0.f;
+        const int y0 = min((int)sy, g - 1), x0 = min((int)sx, g - 1);
+        const int y1 = min(y0 + 1, g - 1), x1 = min(x0 + 1, g - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float v00 = grid[((size_t)y0 * g + x0) * H + c], v01 = grid[((size_t)y0 * g + x1) * H + c];
+        const float v10 = grid[((size_t)y1 * g + x0) * H + c], v11 = grid[((size_t)y1 * g + x1) * H + c];
+        v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+    out[(size_t)b * gh * gw * H + i] = v;
+}
+
+// attention key mask of the [text | CLS | patches] sequence, written nrep times (rows b + rep * B)
+__global__ __launch_bounds__(256) void key_mask_kernel(const long* __restrict__ amask, const long* __restrict__ pmask,
+                                                       uint8_t* __restrict__ out, int B, int Lt, int Hi, int Wi, int P,
+                                                       int S, int nrep) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * S) return;
+    const int b = i / S, t = i - b * S;
+    const int gw = Wi / P;
+    uint8_t v = 1;
+    if (t < Lt) {
+        if (amask) v = amask[(size_t)b * Lt + t] != 0;
+    } else if (t > Lt && pmask) {
+        const int p = t - Lt - 1;
+        v = pmask[(size_t)b * Hi * Wi + (size_t)(p / gw) * P * Wi + (size_t)(p % gw) * P] != 0;
+    }
+    for (int r = 0; r < nrep; ++r) out[(size_t)(b + r * B) * S + t] = v;
 }
 
 __global__ __launch_bounds__(256) void cvt_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
@@ -208,13 +258,14 @@ extern "C" int feddat_im2col_patches(const float* pixels, void* patches_bf16, in
 }
 
 extern "C" int feddat_image_embed_assemble(const float* proj, const float* cls, const float* pos0,
-                                           const float* pos_img, const float* modality1, float* h, int B, int Lt,
-                                           int np, int S, int H, hipStream_t stream) {
+                                           const float* pos_img, long pos_batch_stride, const float* modality1,
+                                           float* h, int B, int Lt, int np, int S, int H, hipStream_t stream) {
     FD_CHECK_ARG(proj && cls && pos0 && pos_img && modality1 && h && B > 0 && np > 0 && S == Lt + 1 + np);
+    FD_CHECK_ARG(pos_batch_stride == 0 || pos_batch_stride >= (long)np * H);
     FD_CHECK_ARG(H % 4 == 0);
     const long total = (long)B * (np + 1) * (H / 4);
     hipLaunchKernelGGL(image_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, proj, cls,
-                       pos0, pos_img, modality1, h, B, Lt, np, S, H);
+                       pos0, pos_img, modality1, h, B, Lt, np, S, H, pos_batch_stride);
     FD_LAUNCH_RET();
 }
 
@@ -224,6 +275,25 @@ extern "C" int feddat_pos_embed_resize(const float* pos_grid, float* out, int g,
     const long total = (long)gh * gw * H;
     hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pos_grid, out,
                        g, gh, gw, H);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_pos_embed_resize_masked(const float* pos_grid, const long* pixel_mask, float* out, int g, int B,
+                                              int Hi, int Wi, int P, int H, hipStream_t stream) {
+    FD_CHECK_ARG(pos_grid && pixel_mask && out && g > 0 && B > 0 && Hi > 0 && Wi > 0 && P > 0 && H > 0);
+    FD_CHECK_ARG(Hi % P == 0 && Wi % P == 0 && B <= 65535);
+    const long total = (long)(Hi / P) * (Wi / P) * H;
+    hipLaunchKernelGGL(pos_resize_masked_kernel, dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, stream,
+                       pos_grid, pixel_mask, out, g, Hi, Wi, P, H);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_vilt_key_mask(const long* attention_mask, const long* pixel_mask, uint8_t* key_mask, int B, int Lt,
+                                    int Hi, int Wi, int P, int nrep, hipStream_t stream) {
+    FD_CHECK_ARG(key_mask && B > 0 && Lt >= 0 && Hi > 0 && Wi > 0 && P > 0 && Hi % P == 0 && Wi % P == 0 && nrep >= 1);
+    const int S = Lt + 1 + (Hi / P) * (Wi / P);
+    hipLaunchKernelGGL(key_mask_kernel, dim3((B * S + 255) / 256), dim3(256), 0, stream, attention_mask, pixel_mask,
+                       key_mask, B, Lt, Hi, Wi, P, S, nrep);
     FD_LAUNCH_RET();
 }
 

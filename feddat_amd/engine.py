@@ -107,9 +107,10 @@ class ViltDatEngine:
         self.cls = P(e + "cls_token").reshape(H).contiguous()
         pos = P(e + "position_embeddings")[0]
         self.pos0 = pos[0].contiguous()
-        self.pos_img = torch.empty(self.np, H, device=dev)
-        g0 = int(round(math.sqrt(pos.shape[0] - 1)))
-        L.pos_embed_resize(pos[1:].contiguous(), self.pos_img, g0, self.gh, self.gw, H)
+        # per-sample position grids: the 12 x 12 table resized to each sample's valid patch rectangle (pixel_mask)
+        self.pos_grid = pos[1:].contiguous()
+        self.g0 = int(round(math.sqrt(pos.shape[0] - 1)))
+        self.pos_img = torch.empty(batch, self.np, H, device=dev)
         self.w_patch = bf16_of(P(e + "patch_embeddings.projection.weight").reshape(H, 3 * self.P * self.P))
         self.layers: List[dict] = []
         for i in range(layers):
@@ -159,8 +160,11 @@ class ViltDatEngine:
             return torch.empty(*s, dtype=torch.bfloat16, device=dev)
         self.inp = dict(pixel_values=f32(B, 3, self.res[0], self.res[1]), input_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
                         token_type_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
-                        target=f32(B, num_labels), key_mask=torch.ones(B, self.S, dtype=torch.uint8, device=dev))
-        self.use_mask = False
+                        target=f32(B, num_labels),
+                        attention_mask=torch.ones(B, text_len, dtype=torch.int64, device=dev),
+                        pixel_mask=torch.ones(B, self.res[0], self.res[1], dtype=torch.int64, device=dev))
+        # attention key masks of the [text | CLS | patches] sequence, derived on the device from the two HF masks
+        # inside the step (no host sync, valid for every batch under one captured graph); rows [B, 2B) repeat [0, B)
         self.key_mask2 = torch.ones(2 * B, self.S, dtype=torch.uint8, device=dev)
         self.patches = b16(B * self.np, 3 * self.P * self.P)
         self.proj = f32(B * self.np, H)
@@ -269,21 +273,16 @@ class ViltDatEngine:
         if tuple(px.shape) != tuple(self.inp["pixel_values"].shape):
             raise L.FeddatHipError(f"engine built for pixel_values {tuple(self.inp['pixel_values'].shape)}, got "
                                    f"{tuple(px.shape)}")
-        if "pixel_mask" in batch and not bool(batch["pixel_mask"].all()):
-            raise L.FeddatHipError("padded images (pixel_mask with zeros) are not supported yet")
         self.inp["pixel_values"].copy_(px, non_blocking=True)
         self.inp["input_ids"].copy_(batch["input_ids"], non_blocking=True)
         self.inp["token_type_ids"].copy_(batch["token_type_ids"], non_blocking=True)
         if "target_scores" in batch:
             self.inp["target"].copy_(batch["target_scores"], non_blocking=True)
-        am = batch.get("attention_mask")
-        if am is not None and not bool(am.all()):
-            self.use_mask = True
-            self.inp["key_mask"][:, :self.Lt].copy_(am.to(torch.uint8))
-            self.key_mask2[:self.B].copy_(self.inp["key_mask"])
-            self.key_mask2[self.B:].copy_(self.inp["key_mask"])
-        elif self.use_mask:
-            self.use_mask = False
+        for k in ("attention_mask", "pixel_mask"):      # absent = all valid
+            if batch.get(k) is not None:
+                self.inp[k].copy_(batch[k], non_blocking=True)
+            else:
+                self.inp[k].fill_(1)
 
     # ------------------------------------------------------------------------------------------ forward
     def _embed(self):
@@ -296,7 +295,12 @@ class ViltDatEngine:
         L.im2col_patches(self.inp["pixel_values"], self.patches, B, 3, self.res[0], self.res[1], self.P)
         L.gemm_bf16_nt(self.patches, self.w_patch, L.EPI_F32, bias=e["patch_embeddings.projection.bias"],
                        out_f32=self.proj)
-        L.image_embed_assemble(self.proj, self.cls, self.pos0, self.pos_img, self.mod1, self.h0, B, Lt, self.np, S, H)
+        L.vilt_key_mask(self.inp["attention_mask"], self.inp["pixel_mask"], self.key_mask2, B, Lt, self.res[0],
+                        self.res[1], self.P, nrep=2)
+        L.pos_embed_resize_masked(self.pos_grid, self.inp["pixel_mask"], self.pos_img, self.g0, B, self.res[0],
+                                  self.res[1], self.P, H)
+        L.image_embed_assemble(self.proj, self.cls, self.pos0, self.pos_img, self.mod1, self.h0, B, Lt, self.np, S, H,
+                               pos_batch_stride=self.np * H)
 
     def _layer_body(self, i: int, h_in, rows: int, nb: int, qkv, ctx, lse, h2, h3, st1=None, st2=None, u=None,
                     mask=None):
@@ -317,8 +321,8 @@ class ViltDatEngine:
         R, R2, B = self.R, 2 * self.R, self.B
         self._embed()
         l0 = self.l0
-        m1 = self.inp["key_mask"] if self.use_mask else None
-        m2 = self.key_mask2 if self.use_mask else None
+        m1 = self.key_mask2[:self.B]
+        m2 = self.key_mask2
         self._layer_body(0, self.h0, R, B, l0["qkv"], l0["ctx"], l0["lse"], l0["h2"], l0["h3"], st1=self.st0,
                          st2=self.st0, mask=m1)
         nxt = self.act[1]["h_in"] if self.nl > 1 else self.h_out
@@ -445,7 +449,7 @@ class ViltDatEngine:
         L.layernorm_bwd_dx(self._pool_src, self.cls_st, self.lnf_g, nb, H, dy_f32=self.dcls_ln,
                            x_stride=self._pool_stride, out_f32=self.dcls)
         cur, oth = self.dh
-        m2 = self.key_mask2 if self.use_mask else None
+        m2 = self.key_mask2
         top = self.nl - 1 if self.nl > 1 else 0
         if self.nl > 1:
             self._top_layer_bwd(cur, oth, m2)      # leaves d(h_in of the top layer) in `oth`
@@ -617,7 +621,7 @@ class ViltDatEngine:
         R, B = self.R, self.B
         self._embed()
         l0 = self.l0
-        m1 = self.inp["key_mask"] if self.use_mask else None
+        m1 = self.key_mask2[:self.B]
         h = self.h0
         for i in range(self.nl):
             self._layer_body(i, h, R, B, l0["qkv"], l0["ctx"], l0["lse"], l0["h2"], l0["h3"], st1=self.st0,

@@ -51,7 +51,9 @@ _SIGS = {
     "feddat_step_tick": [vp, i32, i32, vp],
     "feddat_text_embed": [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, vp],
     "feddat_im2col_patches": [vp, vp, i32, i32, i32, i32, i32, vp],
-    "feddat_image_embed_assemble": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "feddat_image_embed_assemble": [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp],
+    "feddat_pos_embed_resize_masked": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "feddat_vilt_key_mask": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "feddat_pos_embed_resize": [vp, vp, i32, i32, i32, i32, vp],
     "feddat_cvt_f32_bf16": [vp, vp, i64, vp],
     "feddat_transpose_f32_bf16": [vp, vp, i32, i32, vp],
@@ -271,10 +273,27 @@ def im2col_patches(pixels, patches, B, Cc, Hi, Wi, P):
     _chk(load().feddat_im2col_patches(_p(pixels), _p(patches), B, Cc, Hi, Wi, P, _stream()), "feddat_im2col_patches")
 
 
-def image_embed_assemble(proj, cls, pos0, pos_img, mod1, h, B, Lt, npatch, S, H):
+def image_embed_assemble(proj, cls, pos0, pos_img, mod1, h, B, Lt, npatch, S, H, pos_batch_stride=0):
     _dev(proj, h)
-    _chk(load().feddat_image_embed_assemble(_p(proj), _p(cls), _p(pos0), _p(pos_img), _p(mod1), _p(h), B, Lt, npatch,
-                                            S, H, _stream()), "feddat_image_embed_assemble")
+    _chk(load().feddat_image_embed_assemble(_p(proj), _p(cls), _p(pos0), _p(pos_img), pos_batch_stride, _p(mod1), _p(h),
+                                            B, Lt, npatch, S, H, _stream()), "feddat_image_embed_assemble")
+
+
+def pos_embed_resize_masked(grid, pixel_mask, out, g, B, Hi, Wi, P, H):
+    _dev(grid, pixel_mask, out)
+    if pixel_mask.dtype != torch.int64:
+        raise FeddatHipError("pixel_mask must be int64 (HF processor output)")
+    _chk(load().feddat_pos_embed_resize_masked(_p(grid), _p(pixel_mask), _p(out), g, B, Hi, Wi, P, H, _stream()),
+         "feddat_pos_embed_resize_masked")
+
+
+def vilt_key_mask(attention_mask, pixel_mask, key_mask, B, Lt, Hi, Wi, P, nrep=1):
+    _dev(key_mask)
+    for m in (attention_mask, pixel_mask):
+        if m is not None and (m.dtype != torch.int64 or not m.is_cuda):
+            raise FeddatHipError("masks must be int64 device tensors (HF processor output)")
+    _chk(load().feddat_vilt_key_mask(_p(attention_mask), _p(pixel_mask), _p(key_mask), B, Lt, Hi, Wi, P, nrep,
+                                     _stream()), "feddat_vilt_key_mask")
 
 
 def pos_embed_resize(grid, out, g, gh, gw, H):

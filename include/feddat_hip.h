@@ -181,12 +181,25 @@ int feddat_text_embed(const int64_t* input_ids, const int64_t* token_type_ids, c
 /* pixels fp32 [B,3,Hi,Wi] -> bf16 patches [B*gh*gw, 3*P*P] (k = c*P*P + py*P + px, Conv2d weight order) */
 int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C, int Hi, int Wi, int P,
                           hipStream_t stream);
-/* image rows: h[b, Lt, :] = cls + pos[0] + modality[1]; h[b, Lt+1+p, :] = proj[b*np+p] + pos_img[p] + modality[1] */
+/* image rows: h[b, Lt, :] = cls + pos[0] + modality[1];
+ * h[b, Lt+1+p, :] = proj[b*np+p] + pos_img[b * pos_batch_stride + p*H ..] + modality[1]
+ * (pos_batch_stride = 0: one resized grid shared by all samples; np*H: per-sample grids of padded images) */
 int feddat_image_embed_assemble(const float* proj, const float* cls, const float* pos0, const float* pos_img,
-                                const float* modality1, float* h, int B, int Lt, int np, int S, int H,
-                                hipStream_t stream);
+                                long pos_batch_stride, const float* modality1, float* h, int B, int Lt, int np, int S,
+                                int H, hipStream_t stream);
 /* bilinear(align_corners=True) resize of the [g,g,H] position grid to [gh,gw,H] (HF visual_embed) */
 int feddat_pos_embed_resize(const float* pos_grid, float* out, int g, int gh, int gw, int H, hipStream_t stream);
+/* Padded images (HF ViltEmbeddings.visual_embed, transformers modeling_vilt.py, called from vilt.py:127): pixel_mask is
+ * the int64 [B,Hi,Wi] mask of the HF processor.  Sample b's valid patch rectangle is vh x vw (valid patch rows of patch
+ * column 0 / columns of patch row 0, mask sampled at the patch origins); out[b] = the g x g grid resized to vh x vw,
+ * placed top-left in the (Hi/P) x (Wi/P) grid, zero elsewhere.  out: fp32 [B, (Hi/P)*(Wi/P), H]. */
+int feddat_pos_embed_resize_masked(const float* pos_grid, const long* pixel_mask, float* out, int g, int B, int Hi,
+                                   int Wi, int P, int H, hipStream_t stream);
+/* Attention key mask of the [text(Lt) | CLS | patches] sequence: text keys from attention_mask (int64 [B,Lt], NULL = all
+ * valid), CLS valid, patch keys from pixel_mask at the patch origins (NULL = all valid); written nrep times
+ * (rows b + rep*B of key_mask, uint8 [nrep*B, S], S = Lt + 1 + (Hi/P)*(Wi/P)). */
+int feddat_vilt_key_mask(const long* attention_mask, const long* pixel_mask, uint8_t* key_mask, int B, int Lt, int Hi,
+                         int Wi, int P, int nrep, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * misc element-wise helpers

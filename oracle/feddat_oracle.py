@@ -158,6 +158,22 @@ def synthetic_batch(B: int, res: int, seed: int, text_len: int = 40, num_labels:
         "target_scores": target,
     }
 
+def pad_batch(batch, valid_hw, text_lens=None):
+    """Turn a synthetic batch into what the HF ViLT processor yields for images of different sizes: sample b keeps
+    the top-left valid_hw[b] = (h, w) pixels (multiples of the patch size), the rest is zero-padded with
+    pixel_mask = 0; optionally questions are padded ([PAD] = 0, attention_mask = 0) beyond text_lens[b] tokens."""
+    b = {k: v.clone() for k, v in batch.items()}
+    for i, (h, w) in enumerate(valid_hw):
+        b["pixel_mask"][i] = 0
+        b["pixel_mask"][i, :h, :w] = 1
+        b["pixel_values"][i] *= b["pixel_mask"][i][None].to(b["pixel_values"].dtype)
+    if text_lens is not None:
+        for i, n in enumerate(text_lens):
+            b["attention_mask"][i, n:] = 0
+            b["input_ids"][i, n:] = 0
+    return b
+
+
 
 # ----------------------------------------------------------------------------------------
 # DAT module (adapter.py:124-163)
@@ -203,10 +219,23 @@ def interp_pos_embed(P: Params, d: ViltDims, gh: int, gw: int):
     return spatial.flatten(2).transpose(1, 2)  # [1, gh*gw, H]
 
 
+def patch_mask(batch, d: ViltDims) -> torch.Tensor:
+    """HF ViltEmbeddings.visual_embed: pixel_mask -> patch-level mask by nearest interpolation to the patch grid
+    (F.interpolate default mode: source index = dst * patch) -> bool [B, gh, gw]."""
+    pm = batch["pixel_mask"]
+    return pm[:, ::d.patch, ::d.patch].bool()
+
+
 def vilt_embed(P: Params, d: ViltDims, batch) -> torch.Tensor:
-    """HF ViltEmbeddings.forward for full pixel masks: [text | CLS, patches] -> [B,S,H].
-    Patches are kept in raster order (HF permutes them with torch.multinomial; the pooled
-    output is permutation invariant)."""
+    """HF ViltEmbeddings.forward: [text | CLS, patches] -> [B,S,H].
+
+    All gh*gw patch tokens are kept, in raster order, the padded ones masked as attention keys (key_mask below).  HF
+    instead (a) permutes the valid patches with torch.multinomial and (b) truncates every sample to the largest valid
+    patch count of the batch, filling shorter samples with randomly drawn padding patches that are masked as well;
+    masked tokens never reach a valid token's output, so the pooled [CLS] feature -- the only thing the FedDAT path
+    reads (vilt.py:127) -- is the same up to fp32 re-association (pinned by tests/golden/g6_padded.npz).
+    Position embeddings: per sample, the 12x12 grid is resized (bilinear, align_corners=True) to that sample's valid
+    h x w patches, placed top-left and zero-padded, exactly as visual_embed does."""
     e = ENC + "embeddings."
     ids, tt = batch["input_ids"], batch["token_type_ids"]
     B, Lt = ids.shape
@@ -219,7 +248,19 @@ def vilt_embed(P: Params, d: ViltDims, batch) -> torch.Tensor:
     x = F.conv2d(px, P[e + "patch_embeddings.projection.weight"],
                  P[e + "patch_embeddings.projection.bias"], stride=d.patch)
     gh, gw = x.shape[2], x.shape[3]
-    x = x.flatten(2).transpose(1, 2) + interp_pos_embed(P, d, gh, gw)
+    x = x.flatten(2).transpose(1, 2)
+    pmask = patch_mask(batch, d) if "pixel_mask" in batch else torch.ones(B, gh, gw, dtype=torch.bool)
+    if bool(pmask.all()):
+        x = x + interp_pos_embed(P, d, gh, gw)
+    else:
+        x_h = pmask[:, :, 0].sum(1)          # valid rows / cols of the top-left aligned valid rectangle
+        x_w = pmask[:, 0, :].sum(1)
+        pos = []
+        for h, w in zip(x_h.tolist(), x_w.tolist()):
+            pe = interp_pos_embed(P, d, h, w).transpose(1, 2).reshape(1, d.hidden, h, w)
+            pe = F.pad(pe, (0, gw - w, 0, gh - h))
+            pos.append(pe.flatten(2).transpose(1, 2))
+        x = x + torch.cat(pos, 0)
     cls = P[e + "cls_token"].expand(B, -1, -1) + P[e + "position_embeddings"][:, :1, :]
     ie = torch.cat([cls, x], dim=1)
     tok = P[e + "token_type_embeddings.weight"]
@@ -228,9 +269,12 @@ def vilt_embed(P: Params, d: ViltDims, batch) -> torch.Tensor:
     return torch.cat([te, ie], dim=1)
 
 
-def key_mask(batch, n_img_tokens: int) -> torch.Tensor:
+def key_mask(batch, n_img_tokens: int, d: ViltDims = None) -> torch.Tensor:
     B = batch["attention_mask"].shape[0]
-    return torch.cat([batch["attention_mask"].bool(), torch.ones(B, n_img_tokens, dtype=torch.bool)], dim=1)
+    img = torch.ones(B, n_img_tokens, dtype=torch.bool)
+    if d is not None and "pixel_mask" in batch:
+        img[:, 1:] = patch_mask(batch, d).flatten(1)
+    return torch.cat([batch["attention_mask"].bool(), img], dim=1)
 
 
 def vilt_layer_body(P: Params, d: ViltDims, i: int, h, kmask=None):
@@ -260,7 +304,7 @@ def vilt_pooled(P: Params, d: ViltDims, batch, mode: str) -> torch.Tensor:
     """ViltModel(**encodings).pooler_output with Adaptered_ViltOutput in every layer
     (vilt.py:127,356-361)."""
     h = vilt_embed(P, d, batch)
-    km = key_mask(batch, h.shape[1] - batch["input_ids"].shape[1])
+    km = key_mask(batch, h.shape[1] - batch["input_ids"].shape[1], d)
     if bool(km.all()):
         km = None
     for i in range(d.layers):

@@ -208,10 +208,47 @@ def put(rec, key, t):
         rec["norm::" + key] = np_(flat.norm())
 
 
+G6_VALID = [(384, 384), (256, 384), (384, 224), (160, 320)]
+G6_TEXT = [40, 31, 40, 12]
+
+
+def golden_g6(out):
+    """G6: padded images (pixel_mask with zeros, per-sample resized position embeddings) + padded questions, through
+    the reference's ViltContinualLearner around HF ViltModel (visual_embed as installed): forward features for the
+    gated and adapter_1 passes, then 2 train_steps."""
+    d = O.ViltDims(layers=2)
+    model = build_reference_model(d, ["art"], bias_std=0.02)
+    batches = [O.pad_batch(O.synthetic_batch(4, 384, 6000 + s), G6_VALID, G6_TEXT) for s in range(2)]
+    rec = {}
+    with torch.no_grad():
+        for mode in ("gating", "adapter_1"):
+            if mode == "gating":
+                model.activate_gating()
+            else:
+                model.deactivate_gating()
+                model.set_active_adapter(mode)
+            pooled, lg = model(task_key="art", images=_enc_only(batches[0]), texts=None)
+            rec[f"fwd.{mode}.pooled"] = np_(pooled)
+            rec[f"fwd.{mode}.logits"] = np_(lg)
+    for n, p in model.named_parameters():
+        if "adapter" in n:
+            p.requires_grad = True
+    losses, opt = ref_local_update(model, "art", batches, lr=1e-4)
+    rec["losses"] = np.array(losses, np.float32)
+    for k, v in model.state_dict().items():
+        if ".layer.1." in k and ("adapter_0" in k or "adapter_1" in k):
+            put(rec, "after2." + k, v)
+    np.savez_compressed(os.path.join(out, "g6_padded.npz"), **rec)
+    print("G6 losses", losses)
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     torch.manual_seed(0)
+    if "--only-g6" in sys.argv:          # the other fixtures are unchanged; regenerate just this one
+        golden_g6(out)
+        return
 
     # ---------------- G1: Adapter module (adapter.py:124-163) ----------------
     ad = Adapter(["adapter_0", "adapter_1", "adapter_2"], "cpu")
@@ -375,6 +412,7 @@ def main():
             rec["norm::" + k] = np_(flat.norm())
             rec["samp256::" + k] = np_(flat[idx])
     np.savez_compressed(os.path.join(out, "g4_vilt12_384.npz"), **rec)
+    golden_g6(out)
     print("G4 losses", losses)
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)) // 1024, "KiB")

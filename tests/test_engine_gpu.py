@@ -181,3 +181,33 @@ def test_non_square_image_384x640(eng_mod):
     sd = eng.state_dict()
     for n in O.trainable_names(P, "art", 0):
         assert (sd[n].cpu() - P[n]).abs().max() < 1e-3, n
+
+
+G6_VALID = [(384, 384), (256, 384), (384, 224), (160, 320)]
+G6_TEXT = [40, 31, 40, 12]
+
+
+def test_padded_images_vs_reference_golden(eng_mod, golden_dir):
+    """G6: pixel_mask with zeros + padded questions (HF visual_embed semantics) against the reference's numbers, eager
+    and through a hipGraph that was captured on a batch WITHOUT padding (the masks are device-side inputs)."""
+    g = load(golden_dir, "g6_padded.npz")
+    d = O.ViltDims(layers=2)
+    batches = [O.pad_batch(O.synthetic_batch(4, 384, 6000 + s), G6_VALID, G6_TEXT) for s in range(2)]
+    for use_graph in (False, True):
+        P = O.make_params(d, ["art"], bias_std=0.02)
+        eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=4, res=384, layers=2)
+        for mode in ("gating", "adapter_1"):
+            pooled, logits = eng.forward(_to_dev(batches[0]), mode, "art")
+            assert (pooled.cpu() - torch.from_numpy(g[f"fwd.{mode}.pooled"])).abs().max() < 3e-2
+            assert (logits.cpu() - torch.from_numpy(g[f"fwd.{mode}.logits"])).abs().max() < 3e-2
+        eng.begin_local_update("art", steps_per_epoch=2)
+        if use_graph:          # capture on an unpadded batch; capturing does not advance training
+            eng.set_batch(_to_dev(O.synthetic_batch(4, 384, 1)))
+            eng._capture()
+        for s, b in enumerate(batches):
+            out = eng.train_step(_to_dev(b), use_graph=use_graph)
+            ref = float(g["losses"][s])
+            assert abs(float(out[0]) - ref) < 2e-3 * ref + 2e-3, (use_graph, s, float(out[0]), ref)
+        sd = eng.state_dict()
+        for k in [k[len("after2."):] for k in g if k.startswith("after2.")]:
+            assert max_abs_diff_vs_golden(g, "after2." + k, sd[k]) < 1e-3, k

@@ -499,3 +499,25 @@ def test_misc_elementwise_and_fedavg(L, golden_dir):
         for i in range(5):
             L.fedavg_accumulate(acc, torch.from_numpy(gd[f"c{i}.{k}"]).to(DEV), nums[i], sum(nums), i == 0)
         assert torch.equal(acc.cpu(), torch.from_numpy(gd["avg." + k])), k
+
+
+def test_padded_image_masks_and_position_grids(L):
+    """feddat_vilt_key_mask / feddat_pos_embed_resize_masked vs the oracle's restatement of HF visual_embed."""
+    d = O.ViltDims(layers=1)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    b = O.pad_batch(O.synthetic_batch(4, 384, 5), [(384, 384), (256, 384), (384, 224), (32, 64)], [40, 31, 40, 1])
+    B, Lt, S = 4, 40, 40 + 1 + 144
+    km = torch.zeros(2 * B, S, dtype=torch.uint8, device=DEV)
+    L.vilt_key_mask(b["attention_mask"].to(DEV), b["pixel_mask"].to(DEV), km, B, Lt, 384, 384, 32, nrep=2)
+    want = O.key_mask(b, 145, d)
+    assert torch.equal(km[:B].bool().cpu(), want) and torch.equal(km[B:].bool().cpu(), want)
+    km1 = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
+    L.vilt_key_mask(None, None, km1, B, Lt, 384, 384, 32)
+    assert bool(km1.all())
+    pos = P[O.ENC + "embeddings.position_embeddings"][0, 1:].contiguous().to(DEV)
+    out = torch.empty(B, 144, 768, device=DEV)
+    L.pos_embed_resize_masked(pos, b["pixel_mask"].to(DEV), out, 12, B, 384, 384, 32, 768)
+    for i, (h, w) in enumerate([(12, 12), (8, 12), (12, 7), (1, 2)]):
+        ref = torch.nn.functional.pad(O.interp_pos_embed(P, d, h, w).transpose(1, 2).reshape(1, 768, h, w),
+                                      (0, 12 - w, 0, 12 - h)).flatten(2).transpose(1, 2)[0]
+        assert (out[i].cpu() - ref).abs().max() < 2e-6, i

@@ -135,3 +135,27 @@ def test_g4_full_12_layer(golden_dir):
     assert np.allclose(losses, g["losses"], rtol=5e-5, atol=2e-4), (losses, g["losses"])
     for k in [k.split("::", 1)[1] for k in g if k.startswith("samp256::")]:
         assert max_abs_diff_vs_golden(g, k, P[k]) < TOL_W, k
+
+
+G6_VALID = [(384, 384), (256, 384), (384, 224), (160, 320)]
+G6_TEXT = [40, 31, 40, 12]
+
+
+def test_g6_padded_images_and_questions(golden_dir):
+    """pixel_mask with zeros: per-sample resized position embeddings + masked patch / text keys.  The reference (HF
+    visual_embed) drops / re-draws masked patch tokens at random; the oracle keeps all of them, masked -- same
+    pooled feature up to fp32 re-association."""
+    g = load(golden_dir, "g6_padded.npz")
+    d = O.ViltDims(layers=2)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    batches = [O.pad_batch(O.synthetic_batch(4, 384, 6000 + s), G6_VALID, G6_TEXT) for s in range(2)]
+    with torch.no_grad():
+        for mode in ("gating", "adapter_1"):
+            pooled, lg = O.vilt_forward(P, d, batches[0], mode, "art")
+            assert (pooled - T(g[f"fwd.{mode}.pooled"])).abs().max() < 5e-6
+            assert (lg - T(g[f"fwd.{mode}.logits"])).abs().max() < 5e-5
+    client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=2)
+    losses = [float(client.train_step(b)[0]) for b in batches]
+    assert np.allclose(losses, g["losses"], rtol=2e-5, atol=1e-4), (losses, g["losses"])
+    for k in [k[len("after2."):] for k in g if k.startswith("after2.")]:
+        assert max_abs_diff_vs_golden(g, "after2." + k, P[k]) < TOL_W, k
