@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                 dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll 2
+#pragma unroll
             for (int qs = 0; qs < NKS; ++qs) {
                 if (qs * 32 >= S) break;
                 f32x4 p[2], ds[2];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
             f32x4 dq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 if (ks * 32 >= S) break;
                 f32x4 ds[2];
