@@ -232,7 +232,7 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
     }
 }
 
-__global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 2) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dx, bf16* __restrict__ dx16,
                                                           float* __restrict__ z_out, float* __restrict__ dz_out,
                                                           AdapterLaunch L) {
