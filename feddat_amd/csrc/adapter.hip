@@ -93,9 +93,18 @@ __device__ __forceinline__ void ksplit_reduce(f32x4* part, int wave, int lane, f
 // One block (4 waves) = 16 tokens.  Each wave contracts a quarter of the 768 features in the down-projection
 // (partials summed through LDS, fixed order) and then owns a quarter of the 768 output columns of the
 // up-projection: 4x shorter dependent chain per wave and 4x more waves in flight than one-wave-per-tile.
+struct LnFuse {            // optional LayerNorm of the adapter output (the next layer's layernorm_before), fused
+    const float* gamma;    // null = off
+    const float* beta;
+    bf16* y16;             // [T, H] bf16: LN(out)
+    float* stats;          // [T, 2]: mean, rstd (for the LN backward)
+    float eps;
+};
+
 template <int NA>
 __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __restrict__ out,
-                                         const feddat_adapter_seg& sg, int row0, f32x4* part) {
+                                         const feddat_adapter_seg& sg, int row0, f32x4* part, const LnFuse& ln,
+                                         float* lnred) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int row = row0 + i16;
@@ -124,6 +133,7 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
         zb01[a] = cvt8(z[a][0], z[a][1]);
         zb2[a] = pad8(z[a][2]);
     }
+    f32x4 oo[CT / 4];                          // this lane's 48 outputs of its token (kept only when LN is fused)
 #pragma unroll
     for (int k = 0; k < CT / 4; ++k) {
         const int ct = wave * (CT / 4) + k;
@@ -141,19 +151,61 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
             for (int e = 0; e < 4; ++e) o[e] += sc * (y[e] + bu4[e]);
         }
         if (valid) *reinterpret_cast<f32x4*>(out + (size_t)row * H + c) = o;
+        oo[k] = o;
+    }
+    if (!ln.gamma) return;                     // uniform over the launch
+    // LayerNorm over the 768 outputs of each token: 48 per lane -> 4 lane groups (shuffles) -> 4 waves (LDS, fixed
+    // order); two passes (mean, then centred second moment) like the stand-alone LN kernel
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) s1 += (oo[k][0] + oo[k][1]) + (oo[k][2] + oo[k][3]);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    if (g == 0) lnred[wave * 16 + i16] = s1;
+    __syncthreads();
+    const float mean = ((lnred[i16] + lnred[16 + i16]) + (lnred[32 + i16] + lnred[48 + i16])) * (1.0f / H);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = oo[k][e] - mean;
+            s2 += d * d;
+        }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (g == 0) lnred[64 + wave * 16 + i16] = s2;
+    __syncthreads();
+    const float var = ((lnred[64 + i16] + lnred[80 + i16]) + (lnred[96 + i16] + lnred[112 + i16])) * (1.0f / H);
+    const float rstd = rsqrtf(var + ln.eps);
+    if (!valid) return;
+    if (wave == 0 && g == 0 && ln.stats) {
+        ln.stats[2 * (size_t)row] = mean;
+        ln.stats[2 * (size_t)row + 1] = rstd;
+    }
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) {
+        const int c = (wave * (CT / 4) + k) * 16 + 4 * g;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln.gamma + c);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(ln.beta + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (oo[k][e] - mean) * rstd * g4[e] + b4[e];
+        *reinterpret_cast<bf16x4*>(ln.y16 + (size_t)row * H + c) = cvt4(y);
     }
 }
 
 __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                          AdapterLaunch L) {
+                                                          AdapterLaunch L, LnFuse ln) {
     __shared__ __attribute__((aligned(16))) f32x4 part[4 * 2 * NT * 64];
+    __shared__ float lnred[128];
     const int tile = blockIdx.x;
     const int s = tile < L.tiles0 ? 0 : 1;
     const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
     const int row0 = sg.row_begin + t * 16;
-    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, part);
-    else fwd_body<1>(x, out, sg, row0, part);
+    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, part, ln, lnred);
+    else fwd_body<1>(x, out, sg, row0, part, ln, lnred);
 }
 
 template <int NA>
@@ -321,7 +373,22 @@ extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int
     const int rc = prep_launch(segs, nseg, T, L, tiles, false);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), 0, stream, x, out, L);
+    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), 0, stream, x, out, L,
+                       LnFuse{nullptr, nullptr, nullptr, nullptr, 0.f});
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adapter_fwd_ln(const float* x, float* out, int T, int Hd, int r, const feddat_adapter_seg* segs,
+                                     int nseg, const float* ln_gamma, const float* ln_beta, float eps, void* y_bf16,
+                                     float* stats, hipStream_t stream) {
+    FD_CHECK_ARG(x && out && T > 0 && Hd == H && r == R && ln_gamma && ln_beta && y_bf16);
+    AdapterLaunch L;
+    int tiles;
+    const int rc = prep_launch(segs, nseg, T, L, tiles, false);
+    if (rc) return rc;
+    if (tiles == 0) return FEDDAT_OK;
+    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), 0, stream, x, out, L,
+                       LnFuse{ln_gamma, ln_beta, (bf16*)y_bf16, stats, eps});
     FD_LAUNCH_RET();
 }
 

@@ -303,12 +303,13 @@ class ViltDatEngine:
                                pos_batch_stride=self.np * H)
 
     def _layer_body(self, i: int, h_in, rows: int, nb: int, qkv, ctx, lse, h2, h3, st1=None, st2=None, u=None,
-                    mask=None):
+                    mask=None, ln1_done=False):
         """LN -> QKV -> attention -> out-proj(+res) -> LN -> FFN1(gelu) -> FFN2(+res): HF ViltLayer with the
         Adaptered_ViltOutput dense+residual (adaptered_output.py:74-76); returns the adapter input in h3."""
         W, H = self.layers[i], self.H
         x16, f16 = self.x16[:rows], self.f16[:rows]
-        L.layernorm_fwd(h_in, W["ln1g"], W["ln1b"], self.ln_eps, rows, H, y_bf16=x16, stats=st1)
+        if not ln1_done:     # otherwise x16 / st1 were written by the previous layer's fused adapter + LN kernel
+            L.layernorm_fwd(h_in, W["ln1g"], W["ln1b"], self.ln_eps, rows, H, y_bf16=x16, stats=st1)
         L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=qkv)
         L.attn_fwd(qkv, ctx, lse, nb, self.S, self.heads, key_mask=mask)
         L.gemm_bf16_nt(ctx, W["wo"], L.EPI_RESID_F32, bias=W["bo"], resid=h_in, out_f32=h2)
@@ -325,13 +326,21 @@ class ViltDatEngine:
         m2 = self.key_mask2
         self._layer_body(0, self.h0, R, B, l0["qkv"], l0["ctx"], l0["lse"], l0["h2"], l0["h3"], st1=self.st0,
                          st2=self.st0, mask=m1)
-        nxt = self.act[1]["h_in"] if self.nl > 1 else self.h_out
-        L.adapter_fwd(l0["h3"], nxt, self._segs(0, True, False), R2)
+        def adapter_then_ln1(x, i, first):
+            """Adapter of layer i fused with layer i+1's layernorm_before (its bf16 output and row statistics go
+            where that layer's LN kernel would have put them)."""
+            nx, Wn = self.act[i + 1], self.layers[i + 1]
+            L.adapter_fwd_ln(x, nx["h_in"], self._segs(i, first, False), R2, Wn["ln1g"], Wn["ln1b"], self.ln_eps,
+                             self.x16[:R2], nx["st1"])
+        if self.nl > 1:
+            adapter_then_ln1(l0["h3"], 0, True)
+        else:
+            L.adapter_fwd(l0["h3"], self.h_out, self._segs(0, True, False), R2)
         for i in range(1, self.nl - 1):
             a = self.act[i]
             self._layer_body(i, a["h_in"], R2, 2 * B, a["qkv"], a["ctx"], a["lse"], a["h2"], a["h3"], st1=a["st1"],
-                             st2=a["st2"], u=a["u"], mask=m2)
-            L.adapter_fwd(a["h3"], self.act[i + 1]["h_in"], self._segs(i, False, False), R2)
+                             st2=a["st2"], u=a["u"], mask=m2, ln1_done=True)
+            adapter_then_ln1(a["h3"], i, False)
         if self.nl > 1:
             self._top_layer_fwd(m2)
             self._pool(self.top["h_out"], 2 * B, x_stride=self.H)
@@ -366,8 +375,7 @@ class ViltDatEngine:
         i = self.nl - 1
         a, W, H, t = self.act[i], self.layers[i], self.H, self.top
         R2, nb = 2 * self.R, 2 * self.B
-        x16 = self.x16[:R2]
-        L.layernorm_fwd(a["h_in"], W["ln1g"], W["ln1b"], self.ln_eps, R2, H, y_bf16=x16, stats=a["st1"])
+        x16 = self.x16[:R2]       # LN1 of this layer: written by the previous layer's fused adapter + LN kernel
         L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
         L.attn_fwd(a["qkv"], a["ctx"], a["lse"], nb, self.S, self.heads, key_mask=mask)
         L.gemm_bf16_nt(self._cls_rows(a["ctx"], nb), W["wo"], L.EPI_RESID_F32, bias=W["bo"],

@@ -39,6 +39,7 @@ _SIGS = {
     "feddat_layernorm_bwd_dx": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp],
     "feddat_layernorm_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
     "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
+    "feddat_adapter_fwd_ln": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp, f32, vp, vp, vp],
     "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_pack": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "feddat_adapter_pack_strided": [vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp],
@@ -191,6 +192,13 @@ def make_segs(segs: Sequence[dict]):
 def adapter_fwd(x, out, segs_arr, T, H=768, r=48):
     _dev(x, out)
     _chk(load().feddat_adapter_fwd(_p(x), _p(out), T, H, r, segs_arr, len(segs_arr), _stream()), "feddat_adapter_fwd")
+
+
+def adapter_fwd_ln(x, out, segs_arr, T, gamma, beta, eps, y_bf16, stats=None, H=768, r=48):
+    """adapter_fwd + the next layer's LayerNorm of the output rows (bf16 y, [T,2] stats)."""
+    _dev(x, out, y_bf16)
+    _chk(load().feddat_adapter_fwd_ln(_p(x), _p(out), T, H, r, segs_arr, len(segs_arr), _p(gamma), _p(beta), eps,
+                                      _p(y_bf16), _p(stats), _stream()), "feddat_adapter_fwd_ln")
 
 
 def adapter_bwd(x, dy, dx, segs_arr, T, *, dx_bf16=None, z_out=None, dz_out=None, H=768, r=48):

@@ -99,6 +99,12 @@ typedef struct {
 
 int feddat_adapter_fwd(const float* x, float* out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg,
                        hipStream_t stream);
+/* feddat_adapter_fwd that also applies the NEXT layer's layernorm_before to its output rows (HF ViltLayer,
+ * layernorm_before -> attention): y_bf16[t] = LN(out[t]) * gamma + beta (bf16 [T,H]), stats[2t] = mean, stats[2t+1] = rstd.
+ * Saves re-reading the fp32 output (feddat_layernorm_fwd on `out` gives the same result up to fp32 summation order). */
+int feddat_adapter_fwd_ln(const float* x, float* out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg,
+                          const float* ln_gamma, const float* ln_beta, float eps, void* y_bf16, float* stats,
+                          hipStream_t stream);
 /* backward: dx = dy + sum_a W_down[a]^T (relu' .* (scale[a] * W_up[a]^T dy)); optional bf16 copy of dx;
  * dx may be NULL (only z/dz are produced: nothing trainable lies below the first adapter).
  * For the segment's train_slot the kernel also writes z = relu(W_down x + b_down) and dz = scale * relu' .* (W_up^T dy)

@@ -521,3 +521,25 @@ def test_padded_image_masks_and_position_grids(L):
         ref = torch.nn.functional.pad(O.interp_pos_embed(P, d, h, w).transpose(1, 2).reshape(1, 768, h, w),
                                       (0, 12 - w, 0, 12 - h)).flatten(2).transpose(1, 2)[0]
         assert (out[i].cpu() - ref).abs().max() < 2e-6, i
+
+
+def test_adapter_fwd_with_fused_layernorm(L, golden_dir):
+    """feddat_adapter_fwd_ln = feddat_adapter_fwd followed by feddat_layernorm_fwd on its output (incl. a ragged tail)."""
+    g, par = _golden_adapter(L, golden_dir)
+    T = 1000 + 7
+    x = torch.randn(T, 768, device=DEV)
+    h = 16 * 31 + 5
+    segs = L.make_segs([dict(row_begin=0, row_end=h, adapters=[dict(par[0], scale=0.5), dict(par[2], scale=0.5)]),
+                        dict(row_begin=h, row_end=T, adapters=[dict(par[1], scale=1.0)])])
+    gamma, beta = torch.randn(768, device=DEV), torch.randn(768, device=DEV)
+    out_a, out_b = torch.zeros_like(x), torch.zeros_like(x)
+    y_a = torch.zeros(T, 768, dtype=torch.bfloat16, device=DEV)
+    y_b = torch.zeros_like(y_a)
+    st_a, st_b = torch.zeros(T, 2, device=DEV), torch.zeros(T, 2, device=DEV)
+    L.adapter_fwd(x, out_a, segs, T)
+    L.layernorm_fwd(out_a, gamma, beta, 1e-12, T, 768, y_bf16=y_a, stats=st_a)
+    L.adapter_fwd_ln(x, out_b, segs, T, gamma, beta, 1e-12, y_b, st_b)
+    assert torch.equal(out_a, out_b)
+    assert (st_a - st_b).abs().max() < 1e-4 * st_a.abs().max()
+    assert (y_a.float() - y_b.float()).abs().max() <= 2 ** -6          # one bf16 ulp at |y| < 4 from summation order
+    assert ((y_a.float() - y_b.float()).abs() > 0).float().mean() < 0.02
