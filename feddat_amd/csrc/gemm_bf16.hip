@@ -532,6 +532,126 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     if (pend) run_epilogue(pm0, pn0, pml);        // last tile, both groups concurrently (A/B: not slower than staggered)
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Skinny GEMM (M <= 64): the top ViLT layer runs everything behind its attention on the 2B token-0 rows only
+// (engine._top_layer_fwd / _bwd).  With so few rows the product is a stream over the weight matrix, so it is split over
+// (N / 64) x ksplit blocks -- enough blocks to pull B through every CU -- into fp32 partials [ksplit][M][N]; a second
+// kernel sums them in a fixed order and applies the epilogue.  The 128 x 128 kernel put 6..24 blocks on the chip for
+// these shapes (16..47 us per launch).
+// block = 4 waves; wave w owns weight rows n0 + 16 w .. +15 (A operand) x all 64 (padded) activation rows.
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g, float* __restrict__ part, int kslice) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fg = lane >> 4, i16 = lane & 15;
+    const int n0 = blockIdx.x * 64, ks = blockIdx.y;
+    const int k0 = ks * kslice;
+    const bf16* wrow = g.B + (size_t)(n0 + wave * 16 + i16) * g.ldb + k0 + fg * 8;
+    const bf16* arow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) arow[mt] = g.A + (size_t)min(mt * 16 + i16, g.M - 1) * g.lda + k0 + fg * 8;
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < kslice; k += 64) {
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wrow + k);
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wrow + k + 32);
+        bf16x8 a0[4], a1[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            a0[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k);
+            a1[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k + 32);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            acc[mt] = mfma16x32(w0, a0[mt], acc[mt]);
+            acc[mt] = mfma16x32(w1, a1[mt], acc[mt]);
+        }
+    }
+    // lane: n = n0 + 16 wave + 4 fg + (0..3), m = 16 mt + i16
+    float* p = part + (size_t)ks * g.M * g.N + n0 + wave * 16 + fg * 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = mt * 16 + i16;
+        if (m < g.M) *reinterpret_cast<f32x4*>(p + (size_t)m * g.N) = acc[mt];
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(GemmArgs g, const float* __restrict__ part,
+                                                                   int ksplit) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nq = g.N >> 2;
+    if (i >= g.M * nq) return;
+    const int m = i / nq, n = (i - m * nq) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)m * g.N + n);
+    for (int s = 1; s < ksplit; ++s) v = v + *reinterpret_cast<const f32x4*>(part + ((size_t)s * g.M + m) * g.N + n);
+    if (g.bias) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
+    switch (g.epi) {
+        case FEDDAT_EPI_BF16:
+            *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(v);
+            break;
+        case FEDDAT_EPI_RESID_F32:
+            *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) =
+                v + *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n);
+            break;
+        case FEDDAT_EPI_GELU:
+            if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(v);
+            *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(gelu4_pk(v));
+            break;
+        case FEDDAT_EPI_MUL_DGELU: {
+            const bf16x4 u = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)m * g.ldaux + n);
+            *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) =
+                cvt4(v * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]}));
+            break;
+        }
+        default:
+            *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v;
+    }
+}
+
+// split factor: a multiple-of-64 K slice and about two blocks per CU
+int skinny_ksplit(int N, int K) {
+    const int nb = N / 64, kt = K / 64;
+    int best = 1;
+    for (int s = 1; s <= kt; ++s)
+        if (kt % s == 0 && nb * s <= 640) best = s;
+    return best;
+}
+
+}  // namespace
+
+extern "C" long feddat_gemm_skinny_workspace_elems(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64) return 0;
+    return (long)skinny_ksplit(N, K) * M * N;
+}
+
+extern "C" int feddat_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
+                                          const float* bias, const float* resid, int ldr, const void* aux, int ldaux,
+                                          float* out_f32, int ldo32, void* out_bf16, int ldo16, void* out2_bf16,
+                                          int ldo2, float* workspace, long workspace_elems, hipStream_t stream) {
+    FD_CHECK_ARG(A && B && workspace && M > 0 && M <= 64 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0);
+    FD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K);
+    switch (epi) {
+        case FEDDAT_EPI_BF16: FD_CHECK_ARG(out_bf16 && ldo16 % 4 == 0); break;
+        case FEDDAT_EPI_RESID_F32: FD_CHECK_ARG(out_f32 && resid && ldr % 4 == 0 && ldo32 % 4 == 0); break;
+        case FEDDAT_EPI_GELU: FD_CHECK_ARG(out_bf16 && ldo16 % 4 == 0 && (!out2_bf16 || ldo2 % 4 == 0)); break;
+        case FEDDAT_EPI_MUL_DGELU: FD_CHECK_ARG(out_bf16 && aux && ldaux % 4 == 0 && ldo16 % 4 == 0); break;
+        case FEDDAT_EPI_F32: FD_CHECK_ARG(out_f32 && ldo32 % 4 == 0); break;
+        default: return FEDDAT_EINVAL;
+    }
+    const int ksplit = skinny_ksplit(N, K);
+    FD_CHECK_ARG(workspace_elems >= (long)ksplit * M * N);
+    GemmArgs g;
+    g.A = (const bf16*)A; g.B = (const bf16*)B; g.bias = bias; g.resid = resid; g.aux = (const bf16*)aux;
+    g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;
+    g.ldo32 = ldo32; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(N / 64, ksplit), dim3(256), 0, stream, g, workspace, K / ksplit);
+    hipLaunchKernelGGL(gemm_skinny_epilogue_kernel, dim3((M * (N / 4) + 255) / 256), dim3(256), 0, stream, g,
+                       (const float*)workspace, ksplit);
+    FD_LAUNCH_RET();
+}
+
+namespace {
 }  // namespace
 
 extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,

@@ -379,11 +379,22 @@ class ViltDatEngine:
         L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
         L.attn_fwd(a["qkv"], a["ctx"], a["lse"], nb, self.S, self.heads, key_mask=mask)
         L.gemm_bf16_nt(self._cls_rows(a["ctx"], nb), W["wo"], L.EPI_RESID_F32, bias=W["bo"],
-                       resid=self._cls_rows(a["h_in"], nb), out_f32=t["h2"])
+                       resid=self._cls_rows(a["h_in"], nb), out_f32=t["h2"], skinny_workspace=self._skinny_ws())
         L.layernorm_fwd(t["h2"], W["ln2g"], W["ln2b"], self.ln_eps, nb, H, y_bf16=t["x16"], stats=t["st2"])
-        L.gemm_bf16_nt(t["x16"], W["w1"], L.EPI_GELU, bias=W["b1"], out_bf16=t["f16"], out2_bf16=t["u"])
-        L.gemm_bf16_nt(t["f16"], W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=t["h2"], out_f32=t["h3"])
+        L.gemm_bf16_nt(t["x16"], W["w1"], L.EPI_GELU, bias=W["b1"], out_bf16=t["f16"], out2_bf16=t["u"],
+                       skinny_workspace=self._skinny_ws())
+        L.gemm_bf16_nt(t["f16"], W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=t["h2"], out_f32=t["h3"],
+                       skinny_workspace=self._skinny_ws())
         L.adapter_fwd(t["h3"], t["h_out"], self._top_segs(False), nb)
+
+    def _skinny_ws(self):
+        """fp32 split-K partials of the top layer's 2B-row GEMMs (largest: 2B x 3072 x 768)."""
+        if getattr(self, "_skws", None) is None:
+            nb, H, I = 2 * self.B, self.H, self.I
+            n = max(L.gemm_skinny_workspace_elems(nb, I, H), L.gemm_skinny_workspace_elems(nb, H, I),
+                    L.gemm_skinny_workspace_elems(nb, H, H)) if nb <= 64 else 0
+            self._skws = torch.empty(max(n, 1), device=self.dev) if n else False
+        return self._skws if self._skws is not False else None
 
     def _top_segs(self, bwd: bool):
         key = ("top", bwd)
@@ -502,11 +513,12 @@ class ViltDatEngine:
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
         if self._segs_cache[key] is not None:
             L.adapter_wgrad(self._segs_cache[key], self.wpart)
-        L.gemm_bf16_nt(t["dh316"], W["w2T"], L.EPI_MUL_DGELU, aux=t["u"], out_bf16=t["dU"])
-        L.gemm_bf16_nt(t["dU"], W["w1T"], L.EPI_BF16, out_bf16=t["dx2"])
+        ws = self._skinny_ws()
+        L.gemm_bf16_nt(t["dh316"], W["w2T"], L.EPI_MUL_DGELU, aux=t["u"], out_bf16=t["dU"], skinny_workspace=ws)
+        L.gemm_bf16_nt(t["dU"], W["w1T"], L.EPI_BF16, out_bf16=t["dx2"], skinny_workspace=ws)
         L.layernorm_bwd_dx(t["h2"], t["st2"], W["ln2g"], nb, H, dy_bf16=t["dx2"], dres=t["dh3"], out_f32=t["dh2"],
                            out_bf16=t["dh216"])
-        L.gemm_bf16_nt(t["dh216"], W["woT"], L.EPI_F32, out_f32=t["dctx"])
+        L.gemm_bf16_nt(t["dh216"], W["woT"], L.EPI_F32, out_f32=t["dctx"], skinny_workspace=ws)
         # scatter the token-0 rows into the dense operands of the attention / LN1 backward
         L.scatter_cls_rows(t["dctx"], None, self.dctx, nb, self.S, H)
         L.scatter_cls_rows(t["dh2"], cur, None, nb, self.S, H)

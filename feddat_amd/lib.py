@@ -33,6 +33,9 @@ class WgradSeg(C.Structure):
 _SIGS = {
     "feddat_abi_version": [],
     "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
+    "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
+    "feddat_gemm_bf16_nt_skinny": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32,
+                                   vp, i64, vp],
     "feddat_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_layernorm_fwd": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp],
@@ -121,9 +124,14 @@ def _dev(*ts):
 # ---------------------------------------------------------------------------------------------------
 # thin typed wrappers (tensors in, tensors out; no arithmetic happens on the Python side)
 # ---------------------------------------------------------------------------------------------------
+def gemm_skinny_workspace_elems(M: int, N: int, K: int) -> int:
+    return int(load().feddat_gemm_skinny_workspace_elems(M, N, K))
+
+
 def gemm_bf16_nt(A, B, epi, *, bias=None, resid=None, aux=None, out_f32=None, out_bf16=None, out2_bf16=None,
-                 M=None):
-    """C[M,N] = A[M,K] @ B[N,K]^T (+ epilogue).  A, B bf16 2-D (row stride taken from the tensors)."""
+                 M=None, skinny_workspace=None):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+ epilogue).  A, B bf16 2-D (row stride taken from the tensors).
+    With M <= 64 and a fp32 `skinny_workspace` the split-K skinny kernel pair is used."""
     _dev(A, B)
     M = A.shape[0] if M is None else M
     K = A.shape[1]
@@ -131,6 +139,14 @@ def gemm_bf16_nt(A, B, epi, *, bias=None, resid=None, aux=None, out_f32=None, ou
 
     def ld(t):
         return 0 if t is None else t.stride(0)
+    if skinny_workspace is not None and M <= 64:
+        _dev(skinny_workspace)
+        rc = load().feddat_gemm_bf16_nt_skinny(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, epi, _p(bias),
+                                               _p(resid), ld(resid), _p(aux), ld(aux), _p(out_f32), ld(out_f32),
+                                               _p(out_bf16), ld(out_bf16), _p(out2_bf16), ld(out2_bf16),
+                                               _p(skinny_workspace), skinny_workspace.numel(), _stream())
+        _chk(rc, "feddat_gemm_bf16_nt_skinny")
+        return
     rc = load().feddat_gemm_bf16_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, epi, _p(bias), _p(resid),
                                     ld(resid), _p(aux), ld(aux), _p(out_f32), ld(out_f32), _p(out_bf16),
                                     ld(out_bf16), _p(out2_bf16), ld(out2_bf16), _stream())

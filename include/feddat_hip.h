@@ -46,6 +46,15 @@ int feddat_abi_version(void);
 int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
                         const float* bias, const float* resid, int ldr, const void* aux, int ldaux, float* out_f32,
                         int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream);
+/* The same product for M <= 64 rows (the top ViLT layer only needs its 2B token-0 rows behind the attention, because the
+ * pooler reads hidden_states[:, 0] only: vilt.py:127): split over (N/64) x ksplit blocks into fp32 partials in
+ * `workspace` (feddat_gemm_skinny_workspace_elems(M, N, K) floats), summed in a fixed order by a second kernel that
+ * applies the epilogue.  Requirements: N % 64 == 0, K % 64 == 0, lda/ldb % 8 == 0. */
+long feddat_gemm_skinny_workspace_elems(int M, int N, int K);
+int feddat_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
+                               const float* bias, const float* resid, int ldr, const void* aux, int ldaux,
+                               float* out_f32, int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2,
+                               float* workspace, long workspace_elems, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  fused self-attention for one ViLT layer (HF ViltSelfAttention: softmax(QK^T/8 + mask) V).

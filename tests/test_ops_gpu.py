@@ -543,3 +543,36 @@ def test_adapter_fwd_with_fused_layernorm(L, golden_dir):
     assert (st_a - st_b).abs().max() < 1e-4 * st_a.abs().max()
     assert (y_a.float() - y_b.float()).abs().max() <= 2 ** -6          # one bf16 ulp at |y| < 4 from summation order
     assert ((y_a.float() - y_b.float()).abs() > 0).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 768, 3072), (64, 3072, 768), (8, 768, 768), (37, 768, 3072)])
+def test_gemm_skinny_all_epilogues(L, M, N, K):
+    """Split-K skinny GEMM (top layer, 2B token-0 rows) against the same fp32 restatement as the big kernel, with a
+    strided A operand and residual as the engine passes them."""
+    torch.manual_seed(M + N)
+    Abig = torch.randn(M, 3, K, device=DEV).to(torch.bfloat16)
+    A = Abig[:, 0]                                   # row stride 3K
+    Bw = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV)
+    resid_big = torch.randn(M, 2, N, device=DEV)
+    resid = resid_big[:, 1]
+    aux = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    ws = torch.empty(L.gemm_skinny_workspace_elems(M, N, K), device=DEV)
+    ref = A.float() @ Bw.float().t()
+    o16 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    o2 = torch.zeros_like(o16)
+    o32 = torch.zeros(M, N, device=DEV)
+    tol = 2e-2 * ref.abs().max().item()
+    L.gemm_bf16_nt(A, Bw, L.EPI_BF16, bias=bias, out_bf16=o16, skinny_workspace=ws)
+    assert (o16.float() - (ref + bias)).abs().max() < tol
+    L.gemm_bf16_nt(A, Bw, L.EPI_RESID_F32, bias=bias, resid=resid, out_f32=o32, skinny_workspace=ws)
+    assert (o32 - (ref + bias + resid)).abs().max() < 1e-3 * ref.abs().max().item() + 1e-4
+    L.gemm_bf16_nt(A, Bw, L.EPI_GELU, bias=bias, out_bf16=o16, out2_bf16=o2, skinny_workspace=ws)
+    assert (o2.float() - (ref + bias)).abs().max() < tol
+    assert (o16.float() - F.gelu(ref + bias)).abs().max() < tol
+    L.gemm_bf16_nt(A, Bw, L.EPI_MUL_DGELU, aux=aux, out_bf16=o16, skinny_workspace=ws)
+    u = aux.float().requires_grad_(True)
+    F.gelu(u).sum().backward()
+    assert (o16.float() - ref * u.grad).abs().max() < tol
+    L.gemm_bf16_nt(A, Bw, L.EPI_F32, out_f32=o32, skinny_workspace=ws)
+    assert (o32 - ref).abs().max() < 1e-3 * ref.abs().max().item() + 1e-4
