@@ -582,8 +582,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(GemmArgs g, c
     const int nq = g.N >> 2;
     if (i >= g.M * nq) return;
     const int m = i / nq, n = (i - m * nq) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)m * g.N + n);
-    for (int s = 1; s < ksplit; ++s) v = v + *reinterpret_cast<const f32x4*>(part + ((size_t)s * g.M + m) * g.N + n);
+    // fixed summation order 0, 1, 2, ...; the loads of 6 partials are issued together (ksplit is a multiple of 6 or
+    // small for every shape the engine uses; the tail loop covers the rest)
+    const float* pp = part + (size_t)m * g.N + n;
+    const size_t ps = (size_t)g.M * g.N;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int s0 = 0;
+    for (; s0 + 6 <= ksplit; s0 += 6) {
+        f32x4 t[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (s0 + u) * ps);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) v = v + t[u];
+    }
+    for (; s0 < ksplit; ++s0) v = v + *reinterpret_cast<const f32x4*>(pp + s0 * ps);
     if (g.bias) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
     switch (g.epi) {
         case FEDDAT_EPI_BF16:

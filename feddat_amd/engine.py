@@ -162,7 +162,8 @@ class ViltDatEngine:
                         token_type_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
                         target=f32(B, num_labels),
                         attention_mask=torch.ones(B, text_len, dtype=torch.int64, device=dev),
-                        pixel_mask=torch.ones(B, self.res[0], self.res[1], dtype=torch.int64, device=dev))
+                        # pixel_mask sampled at the patch origins (all that HF's visual_embed looks at): [B, gh, gw]
+                        patch_mask=torch.ones(B, self.gh, self.gw, dtype=torch.int64, device=dev))
         # attention key masks of the [text | CLS | patches] sequence, derived on the device from the two HF masks
         # inside the step (no host sync, valid for every batch under one captured graph); rows [B, 2B) repeat [0, B)
         self.key_mask2 = torch.ones(2 * B, self.S, dtype=torch.uint8, device=dev)
@@ -278,11 +279,14 @@ class ViltDatEngine:
         self.inp["token_type_ids"].copy_(batch["token_type_ids"], non_blocking=True)
         if "target_scores" in batch:
             self.inp["target"].copy_(batch["target_scores"], non_blocking=True)
-        for k in ("attention_mask", "pixel_mask"):      # absent = all valid
-            if batch.get(k) is not None:
-                self.inp[k].copy_(batch[k], non_blocking=True)
-            else:
-                self.inp[k].fill_(1)
+        if batch.get("attention_mask") is not None:     # absent = all valid
+            self.inp["attention_mask"].copy_(batch["attention_mask"], non_blocking=True)
+        else:
+            self.inp["attention_mask"].fill_(1)
+        if batch.get("pixel_mask") is not None:
+            self.inp["patch_mask"].copy_(batch["pixel_mask"][:, ::self.P, ::self.P], non_blocking=True)
+        else:
+            self.inp["patch_mask"].fill_(1)
 
     # ------------------------------------------------------------------------------------------ forward
     def _embed(self):
@@ -295,10 +299,10 @@ class ViltDatEngine:
         L.im2col_patches(self.inp["pixel_values"], self.patches, B, 3, self.res[0], self.res[1], self.P)
         L.gemm_bf16_nt(self.patches, self.w_patch, L.EPI_F32, bias=e["patch_embeddings.projection.bias"],
                        out_f32=self.proj)
-        L.vilt_key_mask(self.inp["attention_mask"], self.inp["pixel_mask"], self.key_mask2, B, Lt, self.res[0],
-                        self.res[1], self.P, nrep=2)
-        L.pos_embed_resize_masked(self.pos_grid, self.inp["pixel_mask"], self.pos_img, self.g0, B, self.res[0],
-                                  self.res[1], self.P, H)
+        L.vilt_key_mask(self.inp["attention_mask"], self.inp["patch_mask"], self.key_mask2, B, Lt, self.gh, self.gw, 1,
+                        nrep=2)
+        L.pos_embed_resize_masked(self.pos_grid, self.inp["patch_mask"], self.pos_img, self.g0, B, self.gh, self.gw, 1,
+                                  H)
         L.image_embed_assemble(self.proj, self.cls, self.pos0, self.pos_img, self.mod1, self.h0, B, Lt, self.np, S, H,
                                pos_batch_stride=self.np * H)
 
