@@ -576,3 +576,24 @@ def test_gemm_skinny_all_epilogues(L, M, N, K):
     assert (o16.float() - ref * u.grad).abs().max() < tol
     L.gemm_bf16_nt(A, Bw, L.EPI_F32, out_f32=o32, skinny_workspace=ws)
     assert (o32 - ref).abs().max() < 1e-3 * ref.abs().max().item() + 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(11840, 3072, 768, 2), (11840, 768, 3072, 1), (5920, 2304, 768, 0)])
+def test_gemm_race_screen_bit_identical_repeats(L, M, N, K, epi):
+    """The persistent ping-pong GEMM orders its LDS stages by barrier slots only; a missed ordering shows up as rare
+    wrong tiles.  The kernel is deterministic, so 60 repeats of a multi-round launch must be bit-identical."""
+    torch.manual_seed(1)
+    A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    Bw = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
+    bias, resid = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    o2, o32 = torch.empty_like(o16), torch.empty(M, N, device=DEV)
+    kw = {0: dict(bias=bias, out_bf16=o16), 1: dict(bias=bias, resid=resid, out_f32=o32),
+          2: dict(bias=bias, out_bf16=o16, out2_bf16=o2)}[epi]
+    out = o32 if epi == 1 else o16
+    L.gemm_bf16_nt(A, Bw, epi, **kw)
+    first = out.clone()
+    for _ in range(60):
+        out.zero_()
+        L.gemm_bf16_nt(A, Bw, epi, **kw)
+        assert torch.equal(out, first)
