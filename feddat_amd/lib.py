@@ -58,6 +58,8 @@ _SIGS = {
     "feddat_image_embed_assemble": [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp],
     "feddat_pos_embed_resize_masked": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "feddat_vilt_key_mask": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "feddat_vilt_image_workspace_bytes": [vp, vp, vp, vp, i32],
+    "feddat_vilt_image_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i64, vp],
     "feddat_pos_embed_resize": [vp, vp, i32, i32, i32, i32, vp],
     "feddat_cvt_f32_bf16": [vp, vp, i64, vp],
     "feddat_transpose_f32_bf16": [vp, vp, i32, i32, vp],
@@ -93,7 +95,7 @@ def load() -> C.CDLL:
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = i64 if name.endswith("_workspace_elems") else i32
+        fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes")) else i32
     if lib.feddat_abi_version() != 1:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
     _lib = lib

@@ -217,6 +217,20 @@ int feddat_vilt_key_mask(const long* attention_mask, const long* pixel_mask, uin
                          int Wi, int P, int nrep, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input pipeline, image half: HF ViltImageProcessor as the reference calls it through
+ * ViltEncoderWrapper.process_inputs (src/modeling/vilt.py:87-100), once per batch on the device instead of three times
+ * per batch on the host.  images: device buffer of n packed [h][w][3] uint8 RGB images, image i at byte offsets[i];
+ * heights/widths/out_h/out_w/offsets are HOST arrays (out_* = the ViLT size rule: shorter edge 384, longer <= 640, floored
+ * to multiples of 32 -- feddat_amd.image_processing.resize_output_size).  Writes pixel_values fp32 [n,3,Hm,Wm] (PIL
+ * BICUBIC resize, bit-exact with Pillow's 8-bit ImagingResample; * 1/255; (v - 0.5) / 0.5; zero padding) and pixel_mask
+ * int64 [n,Hm,Wm] (may be NULL).  workspace: feddat_vilt_image_workspace_bytes(...) bytes of device memory.
+ * ------------------------------------------------------------------------------------------- */
+long feddat_vilt_image_workspace_bytes(const int* heights, const int* widths, const int* out_h, const int* out_w, int n);
+int feddat_vilt_image_preprocess(const uint8_t* images, const long* offsets, const int* heights, const int* widths,
+                                 const int* out_h, const int* out_w, int n, int Hm, int Wm, float* pixel_values,
+                                 long* pixel_mask, void* workspace, long workspace_bytes, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * misc element-wise helpers
  * ------------------------------------------------------------------------------------------- */
 int feddat_cvt_f32_bf16(const float* in, void* out_bf16, long n, hipStream_t stream);
