@@ -136,11 +136,17 @@ __global__ __launch_bounds__(256) void pos_resize_masked_kernel(const float* __r
     const int gh = Hi / P, gw = Wi / P;
     const int b = blockIdx.y;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)gh * gw * H) return;
     const long* pm = pmask + (size_t)b * Hi * Wi;
-    int vh = 0, vw = 0;
-    for (int y = 0; y < gh; ++y) vh += pm[(size_t)y * P * Wi] != 0;
-    for (int x = 0; x < gw; ++x) vw += pm[(size_t)x * P] != 0;
+    // valid rows / columns of this sample: counted once per block (threads 0..gh-1 and 64..64+gw-1), not per element
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < gh && pm[(size_t)t * P * Wi] != 0) atomicAdd(&cnt[0], 1);
+    if (t >= 64 && t - 64 < gw && pm[(size_t)(t - 64) * P] != 0) atomicAdd(&cnt[1], 1);
+    __syncthreads();
+    const int vh = cnt[0], vw = cnt[1];
+    if (i >= (long)gh * gw * H) return;
     const int c = (int)(i % H);
     const int x = (int)((i / H) % gw);
     const int y = (int)(i / ((long)H * gw));
@@ -281,7 +287,7 @@ extern "C" int feddat_pos_embed_resize(const float* pos_grid, float* out, int g,
 extern "C" int feddat_pos_embed_resize_masked(const float* pos_grid, const long* pixel_mask, float* out, int g, int B,
                                               int Hi, int Wi, int P, int H, hipStream_t stream) {
     FD_CHECK_ARG(pos_grid && pixel_mask && out && g > 0 && B > 0 && Hi > 0 && Wi > 0 && P > 0 && H > 0);
-    FD_CHECK_ARG(Hi % P == 0 && Wi % P == 0 && B <= 65535);
+    FD_CHECK_ARG(Hi % P == 0 && Wi % P == 0 && B <= 65535 && Hi / P <= 64 && Wi / P <= 64);
     const long total = (long)(Hi / P) * (Wi / P) * H;
     hipLaunchKernelGGL(pos_resize_masked_kernel, dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, stream,
                        pos_grid, pixel_mask, out, g, Hi, Wi, P, H);
