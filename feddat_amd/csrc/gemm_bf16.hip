@@ -199,22 +199,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 //   * Epilogue staged through 5 KiB of LDS per wave: accumulators go down as [16 rows][48 cols] fp32 chunks and come
 //     back row-contiguous, so residual / aux loads and the output stores are 96..192-byte runs per row instead of the
 //     32-byte segments of the accumulator layout.
-constexpr int V2_BM = 192, V2_BN = 192;
-constexpr int V2_TILE = V2_BM * BK * 2;       // 24 KiB per operand tile
-constexpr int V2_STAGE = 2 * V2_TILE;         // 48 KiB per stage
-constexpr int V2_EPI_OFF = 2 * V2_STAGE;      // 96 KiB
+// The kernel is templated on WM = 16-row MFMA tiles per wave along M: WM = 3 -> 192 x 192 block tile (48 x 96 per wave),
+// WM = 4 -> 256 x 192 (64 x 96 per wave: 48 MFMAs per 20 fragment reads instead of 36 per 18, for launches whose tile
+// count then still fills whole rounds of the 256 CUs, i.e. N = 3072 at M = 11 840: 768 tiles = 3 rounds).
+constexpr int V2_BN = 192;
+constexpr int V2_TILE_B = V2_BN * BK * 2;     // 24 KiB
 constexpr int V2_EPI_WAVE = 5120;             // staging bytes per wave
 constexpr int V2_EPI_LD = 208;                // bytes per staged row (192 + 16 pad: conflict-free ds_write_b128)
-constexpr int V2_LDS = V2_EPI_OFF + 8 * V2_EPI_WAVE;   // 136 KiB
+template <int WM> struct V2Cfg {
+    static constexpr int BM = 64 * WM;                       // 4 wave rows x 16 WM
+    static constexpr int TILE_A = BM * BK * 2;               // 24 / 32 KiB
+    static constexpr int STAGE = TILE_A + V2_TILE_B;         // 48 / 56 KiB
+    static constexpr int EPI_OFF = 2 * STAGE;
+    static constexpr int LDS = EPI_OFF + 8 * V2_EPI_WAVE;    // 136 / 152 KiB
+    static constexpr int NP = WM + 3;                        // staging pieces per wave and k-tile (A: WM, B: 3)
+};
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgsV2 {
     GemmArgs g;
-    int bm;        // rows per M tile (<= 192)
+    int bm;        // rows per M tile (<= 64 WM)
     int tiles_m;
     int nx, tm_per, tn_per;   // XCD grid (8 / nx) x nx, tiles per XCD along M / N (see v2_tile_coords)
-    int dbg;       // FEDDAT_GEMM_DEBUG ablation flags: 8 = skip epilogue; bits 8.. = cap on the number of blocks
+    int dbg;       // FEDDAT_GEMM_DEBUG ablation flags: 8 = skip epilogue; 32 / 64 = force WM 3 / 4; bits 8.. = block cap
 };
 
 // Tile id -> tile.  Consecutive workgroups land on consecutive XCDs (8 private 4 MiB L2s), so tile_id & 7 is the XCD.
@@ -246,12 +254,17 @@ __device__ __forceinline__ void v2_tile_coords(const GemmArgsV2& a, int tile_id,
 
 // per-lane source pointers (k = 0) of this wave's 6 staging pieces of a tile: A pieces 3w..3w+2, B pieces 3w..3w+2;
 // a piece = 8 rows x 128 B, lane l -> row l >> 3, 16-byte chunk l & 7 (full 128-byte lines per row)
+template <int WM>
 __device__ __forceinline__ void v2_piece_ptrs(const GemmArgs& g, int m0, int m_last, int n0, int wave, int lane,
-                                              const bf16* (&pa)[3], const bf16* (&pb)[3]) {
+                                              const bf16* (&pa)[WM], const bf16* (&pb)[3]) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int r = (wave * WM + i) * 8 + (lane >> 3);
+        pa[i] = g.A + (size_t)min(m0 + r, m_last) * g.lda + (lane & 7) * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int r = (wave * 3 + i) * 8 + (lane >> 3);
-        pa[i] = g.A + (size_t)min(m0 + r, m_last) * g.lda + (lane & 7) * 8;
         pb[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + (lane & 7) * 8;
     }
 }
@@ -260,8 +273,8 @@ __device__ __forceinline__ void v2_piece_ptrs(const GemmArgs& g, int m0, int m_l
 // the accumulator layout from registers) go down as [16 rows][48 cols] fp32 chunks and come back row-contiguous
 // (192-byte runs per row); the residual / aux operands of chunk c+1 are requested before chunk c is stored, so the
 // six chunks do not serialise on HBM latency.
-template <int EPI>
-__device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[3][6], char* stg, int mbase, int nbase,
+template <int EPI, int WM>
+__device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[WM][6], char* stg, int mbase, int nbase,
                                             int m_end, int lane) {
     // keep the per-lane index math of the (several, inlined) epilogue sites out of the main loop's live ranges:
     // an opaque copy of the lane id cannot be hoisted across the k-loop
@@ -283,8 +296,9 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[3][6
     // HBM latency per tile instead of one per chunk); the fragment registers of the k-loop are dead here
     // residual / aux operands: three of the six chunks are in flight at any time (uniform base + 32-bit per-lane byte
     // offsets; FD_CHECK_ARG bounds the operand below 4 GiB)
-    f32x4 rr[6][3];
-    bf16x4 uu[6][3];
+    constexpr int NC = 2 * WM;              // chunks of [16 rows][48 cols]
+    f32x4 rr[NC][3];
+    bf16x4 uu[NC][3];
     const char* rbase = reinterpret_cast<const char*>(EPI == FEDDAT_EPI_RESID_F32 ? (const void*)(g.resid + nbase)
                                                                                   : (const void*)(g.aux + nbase));
     const unsigned esz = EPI == FEDDAT_EPI_RESID_F32 ? 4u : 2u;
@@ -336,20 +350,23 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[3][6
         }
     };
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < NC; ++c) {
         chunk(c, rr[c], uu[c]);
-        if ((EPI == FEDDAT_EPI_RESID_F32 || EPI == FEDDAT_EPI_MUL_DGELU) && c + 3 < 6) prefetch(c + 3);
+        if ((EPI == FEDDAT_EPI_RESID_F32 || EPI == FEDDAT_EPI_MUL_DGELU) && c + 3 < NC) prefetch(c + 3);
     }
 }
 
+template <int WM>
 struct V2State {
-    const bf16* pa[3];
+    const bf16* pa[WM];
     const bf16* pb[3];
     int l_tile, l_kt;     // tile index / k-tile of the next staging load
 };
 
-template <int EPI>
+template <int EPI, int WM>
 __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
+    using Cfg = V2Cfg<WM>;
+    constexpr int NP = Cfg::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmArgs& g = a.g;
     const int tid = threadIdx.x;
@@ -363,31 +380,30 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     const int nk = g.K / BK;
     const int total_it = my_tiles * nk;
 
-    f32x4 acc[3][6];
+    f32x4 acc[WM][6];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int m0, n0, m_last;                 // tile being computed
     v2_tile_coords(a, bid, total, m0, n0, m_last);
-    V2State L;
-    v2_piece_ptrs(g, m0, m_last, n0, wave, lane, L.pa, L.pb);
+    V2State<WM> L;
+    v2_piece_ptrs<WM>(g, m0, m_last, n0, wave, lane, L.pa, L.pb);
     L.l_tile = 0;
     L.l_kt = 0;
     int issued = 0;                     // k-tiles whose staging loads have been issued (may run past total_it)
     // LDS byte offset of this lane inside a piece: row (lane >> 3), chunk (lane & 7) ^ (row & 7); piece p at p * 1024
     const int lds_lane = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 3)) & 7) << 4);
-    const int lds_wave = wave * 3 * 1024;
 
     // Staging registers (one set): the k-tile this wave writes to LDS next.  The stream position (pointers, l_kt)
     // always addresses k-tile min(issued, total_it - 1), so loads past the end of the stream re-read the last k-tile
     // and the k-loop needs no branches around its staging instructions.
-    u32x4 rs[6];            // pieces 0..2 = A rows, 3..5 = B rows
+    u32x4 rs[NP];           // pieces 0..WM-1 = A rows, WM..WM+2 = B rows
     int written = 0;        // k-tiles of the stream this wave has written to LDS
     auto gload_piece = [&](int p) {
         const int koff = L.l_kt * BK;
-        rs[p] = *reinterpret_cast<const u32x4*>((p < 3 ? L.pa[p] : L.pb[p - 3]) + koff);
+        rs[p] = *reinterpret_cast<const u32x4*>((p < WM ? L.pa[p < WM ? p : 0] : L.pb[p < WM ? 0 : p - WM]) + koff);
     };
     auto stream_advance = [&]() {
         if (issued + 1 < total_it) {
@@ -396,38 +412,39 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
                 ++L.l_tile;
                 int lm0, ln0, lml;
                 v2_tile_coords(a, bid + L.l_tile * grid, total, lm0, ln0, lml);
-                v2_piece_ptrs(g, lm0, lml, ln0, wave, lane, L.pa, L.pb);
+                v2_piece_ptrs<WM>(g, lm0, lml, ln0, wave, lane, L.pa, L.pb);
             }
         }
         ++issued;
     };
     auto lwrite_piece = [&](int p, int stage) {
-        char* sb = smem + stage * V2_STAGE + lds_wave + lds_lane + (p < 3 ? p * 1024 : V2_TILE + (p - 3) * 1024);
+        char* sb = smem + stage * Cfg::STAGE + lds_lane +
+                   (p < WM ? (wave * WM + p) * 1024 : Cfg::TILE_A + (wave * 3 + p - WM) * 1024);
         *reinterpret_cast<u32x4*>(sb) = rs[p];
     };
     auto gload = [&]() {
 #pragma unroll
-        for (int p = 0; p < 6; ++p) gload_piece(p);
+        for (int p = 0; p < NP; ++p) gload_piece(p);
         stream_advance();
     };
     auto lwrite = [&](int stage) {
 #pragma unroll
-        for (int p = 0; p < 6; ++p) lwrite_piece(p, stage);
+        for (int p = 0; p < NP; ++p) lwrite_piece(p, stage);
         ++written;
     };
 
     const int frow = lane & 15, fg = lane >> 4;
     // fragment read of row r (a multiple of 16 + frow), k-half ks: 16-byte chunk (4 ks + fg) ^ (frow & 7) of the row
     const int frag_off[2] = {frow * 128 + (((0 + fg) ^ (frow & 7)) << 4), frow * 128 + (((4 + fg) ^ (frow & 7)) << 4)};
-    char* stg = smem + V2_EPI_OFF + wave * V2_EPI_WAVE;
+    char* stg = smem + Cfg::EPI_OFF + wave * V2_EPI_WAVE;
     int kt = 0, c_tile = 0, st = 0;
     bool pend = false;                  // a finished tile whose epilogue has not run yet
     int pm0 = 0, pn0 = 0, pml = 0;
     auto run_epilogue = [&](int em0, int en0, int eml) {
-        const int mb = em0 + wm * 48, nb = en0 + wn * 96, me = eml + 1;
-        if (!(a.dbg & 8)) v2_epilogue<EPI>(g, acc, stg, mb, nb, me, lane);
+        const int mb = em0 + wm * (16 * WM), nb = en0 + wn * 96, me = eml + 1;
+        if (!(a.dbg & 8)) v2_epilogue<EPI, WM>(g, acc, stg, mb, nb, me, lane);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
@@ -455,11 +472,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 
     for (int it = 0; it < total_it; ++it) {
         // ------------------------------ L phase ------------------------------
-        bf16x8 fa[2][3], fb[2][6];
+        bf16x8 fa[2][WM], fb[2][6];
         auto read_frags = [&]() {
             // address = per-lane swizzled offset (loop invariant, one per k-half) + wave-uniform tile base + immediate
-            const int a_base = st * V2_STAGE + wm * (48 * 128);
-            const int b_base = st * V2_STAGE + V2_TILE + wn * (96 * 128);
+            const int a_base = st * Cfg::STAGE + wm * (16 * WM * 128);
+            const int b_base = st * Cfg::STAGE + Cfg::TILE_A + wn * (96 * 128);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const char* pb_ = smem + (frag_off[ks] + b_base);
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(pb_ + j * 2048);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(pa_ + i * 2048);
+                for (int i = 0; i < WM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(pa_ + i * 2048);
                 __builtin_amdgcn_sched_barrier(0);      // keep the k-half-0 reads first in the LDS queue
             }
         };
@@ -499,18 +516,20 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ------------------------------ C phase ------------------------------
-        // 6 groups of 6 MFMAs; after group p: ds_write of staging piece p, then its global reload
+        // 2 WM groups of 6 MFMAs; after group p (< NP): ds_write of staging piece p, then its global reload
         const int wstage = written & 1;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < WM; ++i) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc[i][j] = mfma16x32(fb[ks][j], fa[ks][i], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);     // MFMAs first: the write's lgkmcnt must not gate them
-                lwrite_piece(ks * 3 + i, wstage);      // straight-line code: the compiler's vmcnt / lgkmcnt counts
-                gload_piece(ks * 3 + i);               // stay exact (any branch here degrades them to waits for 0)
+                if (ks * WM + i < NP) {                // compile-time: straight-line code, so the compiler's vmcnt /
+                    lwrite_piece(ks * WM + i, wstage); // lgkmcnt counts stay exact (a runtime branch here degrades
+                    gload_piece(ks * WM + i);          // them to waits for 0)
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         __builtin_amdgcn_s_setprio(0);
@@ -694,34 +713,9 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     if (use_v2) {
         GemmArgsV2 a2;
         a2.g = g;
-        // balanced M tiles of <= 192 rows
-        int nmt = (M + V2_BM - 1) / V2_BM;
-        const int tiles_n = N / V2_BN;
-        // XCD-aware tile order: split the XCDs over N as well when B (N x K bf16) would not stay in a 4 MiB L2 and the
-        // launch takes more than one round of tiles
-        a2.nx = 1;
-        if ((size_t)N * K * 2 > (3u << 20) && tiles_n % 2 == 0 && nmt * tiles_n > 256) {
-            a2.nx = 2;
-            nmt = (nmt + 3) & ~3;                      // 4 M groups of equal size
-        }
-        int bm = (M + nmt - 1) / nmt;
-        a2.bm = bm;
-        a2.tiles_m = a2.nx == 1 ? (M + bm - 1) / bm : nmt;
-        a2.tm_per = a2.tiles_m / (8 / a2.nx);
-        a2.tn_per = tiles_n / a2.nx;
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("FEDDAT_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
         a2.dbg = dbg;
-        using KernelFn = void (*)(GemmArgsV2);
-        static const KernelFn kernels[5] = {gemm_nt_v2_kernel<FEDDAT_EPI_BF16>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32>,
-                                            gemm_nt_v2_kernel<FEDDAT_EPI_GELU>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU>,
-                                            gemm_nt_v2_kernel<FEDDAT_EPI_F32>};
-        static bool attr2 = false;
-        if (!attr2) {
-            for (KernelFn k : kernels)
-                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
-            attr2 = true;
-        }
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -729,10 +723,50 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FEDDAT_ELAUNCH;
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
+        const int tiles_n = N / V2_BN;
+        // balanced M tiles of <= BM rows; XCD-aware tile order: split the XCDs over N as well when B (N x K bf16) would
+        // not stay in a 4 MiB L2 and the launch takes more than one round of tiles
+        auto plan = [&](int BMx, GemmArgsV2& o) {
+            int nmt = (M + BMx - 1) / BMx;
+            o.nx = 1;
+            if ((size_t)N * K * 2 > (3u << 20) && tiles_n % 2 == 0 && nmt * tiles_n > n_cu) {
+                o.nx = 2;
+                nmt = (nmt + 3) & ~3;                      // 4 M groups of equal size
+            }
+            const int bm = (M + nmt - 1) / nmt;
+            o.bm = bm;
+            o.tiles_m = o.nx == 1 ? (M + bm - 1) / bm : nmt;
+            o.tm_per = o.tiles_m / (8 / o.nx);
+            o.tn_per = tiles_n / o.nx;
+            return (o.tiles_m * tiles_n + n_cu - 1) / n_cu;     // rounds of the persistent grid
+        };
+        GemmArgsV2 a3 = a2, a4 = a2;
+        const int rounds3 = plan(192, a3), rounds4 = plan(256, a4);
+        // a 256-row tile costs about 1.2x a 192-row tile (48 vs 36 MFMAs per k-tile and wave, L phase 20 vs 18 reads)
+        bool wm4 = rounds4 * 12 < rounds3 * 10;
+        if (dbg & 32) wm4 = false;
+        if (dbg & 64) wm4 = true;
+        a2 = wm4 ? a4 : a3;
+        using KernelFn = void (*)(GemmArgsV2);
+        static const KernelFn kernels[2][5] = {
+            {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 3>,
+             gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3>,
+             gemm_nt_v2_kernel<FEDDAT_EPI_F32, 3>},
+            {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 4>,
+             gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 4>,
+             gemm_nt_v2_kernel<FEDDAT_EPI_F32, 4>}};
+        static bool attr2 = false;
+        if (!attr2) {
+            for (int w = 0; w < 2; ++w)
+                for (KernelFn k : kernels[w])
+                    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS);
+            attr2 = true;
+        }
         const int total = a2.tiles_m * (N / V2_BN);
         int grid = total < n_cu ? total : n_cu;
         if ((dbg >> 8) > 0 && (dbg >> 8) < grid) grid = dbg >> 8;      // ablation: cap the number of persistent blocks
-        hipLaunchKernelGGL(kernels[epi], dim3(grid), dim3(512), V2_LDS, stream, a2);
+        hipLaunchKernelGGL(kernels[wm4 ? 1 : 0][epi], dim3(grid), dim3(512), wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS, stream, a2);
         FD_LAUNCH_RET();
     }
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
