@@ -211,3 +211,24 @@ def test_padded_images_vs_reference_golden(eng_mod, golden_dir):
         sd = eng.state_dict()
         for k in [k[len("after2."):] for k in g if k.startswith("after2.")]:
             assert max_abs_diff_vs_golden(g, "after2." + k, sd[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("B,res,layers,text_len,graph", [(1, 224, 2, 40, False), (3, 224, 3, 40, True),
+                                                         (5, 384, 2, 16, False), (33, 224, 2, 40, False),
+                                                         (2, 224, 1, 40, False)])
+def test_unusual_shapes_train_steps(eng_mod, B, res, layers, text_len, graph):
+    """Batch 1 / odd batches / short questions / 2B > 64 (no skinny top-layer path) / a single layer: two train_steps
+    against the oracle."""
+    d = O.ViltDims(layers=layers)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=B, res=res, layers=layers, text_len=text_len)
+    bs = [O.synthetic_batch(B, res, 100 + s, text_len=text_len) for s in range(2)]
+    client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=2)
+    eng.begin_local_update("art", steps_per_epoch=2)
+    for b in bs:
+        ref = float(client.train_step(b)[0])
+        out = eng.train_step(_to_dev(b), use_graph=graph)
+        assert abs(float(out[0]) - ref) < 3e-3 * abs(ref)
+    sd = eng.state_dict()
+    for n in O.trainable_names(P, "art", 0):
+        assert (sd[n].cpu() - P[n]).abs().max() < 1e-3, n
