@@ -18,6 +18,7 @@ namespace {
 
 constexpr int D = 64;
 constexpr int ROWB = D * 2;  // 128 bytes per LDS row
+constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             const f32x4 ma = *reinterpret_cast<const f32x4*>(mask_add + kt * 16 + 4 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a[e] = a[e] * 0.125f + ma[e];
+                a[e] = a[e] * (0.125f * LOG2E) + ma[e];      // log2-domain scores: softmax via exp2
                 mx = fmaxf(mx, a[e]);
             }
             s[kt] = a;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s[kt][e] = __expf(s[kt][e] - mx);
+                s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - mx);
                 sum += s[kt][e];
             }
         sum += __shfl_xor(sum, 16, 64);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
                 v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
                 *reinterpret_cast<bf16x4*>(out + dt * 16 + 4 * g) = cvt4(v);
             }
-            if (g == 0 && lse) lse[((size_t)b * heads + h) * S + q] = mx + __logf(sum);
+            if (g == 0 && lse) lse[((size_t)b * heads + h) * S + q] = mx * (1.0f / LOG2E) + __logf(sum);
         }
     }
 }
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     const int g = lane >> 4, i16 = lane & 15;
     bf16* dq_base = dqkv + (size_t)b * S * ld + h * D;
     for (int k = tid; k < S_pad; k += 256) {
-        Ls[k] = k < S ? lse[((size_t)b * heads + h) * S + k] : 0.f;
+        Ls[k] = k < S ? lse[((size_t)b * heads + h) * S + k] * LOG2E : 0.f;   // exp(x - lse) = exp2(x log2e - Ls)
         kvalid[k] = (k < S && (!kmask || kmask[(size_t)b * S + k])) ? 1.f : 0.f;
     }
 
@@ -228,9 +229,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + qrow + 4 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float pe = kv * __expf(sc[e] * 0.125f - l4[e]);
+                        const float pe = kv * __builtin_amdgcn_exp2f(sc[e] * (0.125f * LOG2E) - l4[e]);
                         p[t][e] = pe;
-                        ds[t][e] = pe * (dp[e] - d4[e]) * 0.125f;
+                        ds[t][e] = pe * (dp[e] - d4[e]);          // the 1/8 of dS is applied to dK at the end
                     }
                 }
                 const bf16x8 pb = cvt8(p[0], p[1]);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                 bf16* ov = dq_base + (size_t)key * ld + 2 * H;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    *reinterpret_cast<bf16x4*>(ok + dt * 16 + 4 * g) = cvt4(dk[dt]);
+                    *reinterpret_cast<bf16x4*>(ok + dt * 16 + 4 * g) = cvt4(dk[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
                     *reinterpret_cast<bf16x4*>(ov + dt * 16 + 4 * g) = cvt4(dv[dt]);
                 }
             }
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                     const f32x4 kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float pe = kv4[e] * __expf(sc[e] * 0.125f - lq);
-                        ds[t][e] = pe * (dp[e] - dq_) * 0.125f;
+                        const float pe = kv4[e] * __builtin_amdgcn_exp2f(sc[e] * (0.125f * LOG2E) - lq);
+                        ds[t][e] = pe * (dp[e] - dq_);            // the 1/8 of dS is applied to dQ at the end
                     }
                 }
                 const bf16x8 dsb = cvt8(ds[0], ds[1]);
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
             if (q < S) {
                 bf16* oq = dq_base + (size_t)q * ld;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt]);
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
             }
         }
     }
