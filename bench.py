@@ -141,8 +141,8 @@ def cpu_baseline(params_cpu, B, res, task, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--res", type=int, default=384)
     ap.add_argument("--no-graph", action="store_true")
