@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-input", action="store_true",
+                    help="also time the same steps with batches starting in pinned HOST memory (PCIe-inclusive rate, "
+                         "uploads overlapped by feddat_amd.data.DevicePrefetcher); reported as extra fields")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,6 +203,22 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     loss = float(eng.loss_buf["p2"][0])
+    host_ms = None
+    if args.host_input and world == 1:
+        from feddat_amd.data import DevicePrefetcher, pin_batch
+        host = [pin_batch({k: v.cpu() for k, v in b.items()}) for b in batches]
+        up = lambda b: {k: v.to(dev, non_blocking=True) for k, v in b.items()}
+        res_ms = {}
+        for mode in ("sync", "prefetch"):
+            src = (host[i % nb] for i in range(args.steps))
+            it = DevicePrefetcher(src, up, dev) if mode == "prefetch" else (up(b) for b in src)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for b in it:
+                eng.train_step(b, use_graph=use_graph)
+            torch.cuda.synchronize()
+            res_ms[mode] = (time.perf_counter() - t1) / args.steps * 1e3
+        host_ms = res_ms
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -212,6 +231,9 @@ def main():
         S = eng.S
         gemms, gemm_flops, exec_flops = flops_tables(B, S)
         sps = world * B * args.steps / dt
+        extra_host = {} if host_ms is None else {
+            "host_input_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()},
+            "host_input_samples_per_sec": {k: round(B * 1e3 / v, 1) for k, v in host_ms.items()}}
         out = {
             "metric": "VQA samples/sec, ViLT-B/32 dual-adapter local step", "value": round(sps, 2),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -226,6 +248,7 @@ def main():
             "mfma_frac_executed_flops": round(exec_flops * args.steps / dt / PEAK_BF16, 4),
             "mfma_frac_reference_flops": round(sps / world * REF_FLOPS_PER_SAMPLE / PEAK_BF16, 4),
         }
+        out.update(extra_host)
         if not args.no_roofline:
             ach, tsum, rows = measure_gemms(L, gemms)
             tr = profiled_traffic()

@@ -100,8 +100,15 @@ class TaskTrainer:
                                opt_adapters=optimizer.adapters)
         model.adapter_requires_grad[2] = False
         loss = None
+        dev = model.device
+        upload = lambda b: {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
         for epoch in range(self.local_epochs):
-            for step, batch in enumerate(self.vqa_train_dataloader):
+            # host batches cross PCIe on a side stream while the previous step computes (device batches pass through)
+            loader = self.vqa_train_dataloader
+            if getattr(self.args, "prefetch", True):
+                from .data import DevicePrefetcher
+                loader = DevicePrefetcher(loader, upload, dev)
+            for step, batch in enumerate(loader):
                 if self.args.debug > 0 and step > self.args.debug:     # task_trainer.py:82-83
                     break
                 loss = self.train_step(model, step, batch, optimizer, scheduler, hooks=None, epoch=epoch)

@@ -163,3 +163,34 @@ def test_main_rounds_and_resume(api, tmp_path):
         pa = load_file(str(tmp_path / "a" / f"personal_{t}.safetensors"))
         pb = load_file(str(tmp_path / "b2" / f"personal_{t}.safetensors"))
         assert pa.keys() == pb.keys() and all(torch.equal(pa[k], pb[k]) for k in pa), t
+
+
+def test_device_prefetcher_matches_synchronous_upload(api):
+    """feddat_amd.data.DevicePrefetcher: same batches, same order, same training result as uploading synchronously;
+    worker exceptions surface in the consumer."""
+    from feddat_amd.data import DevicePrefetcher, pin_batch
+    d = O.ViltDims(layers=2)
+    host = [pin_batch(O.synthetic_batch(2, 224, 40 + s)) for s in range(5)]
+    up = lambda b: {k: v.to(DEV, non_blocking=True) for k, v in b.items()}
+    finals = []
+    for mode in ("sync", "prefetch"):
+        P = O.make_params(d, ["art"], bias_std=0.02)
+        m = api.modeling.create_vilt_continual_learner_model(P, ["art"], DEV, batch_size=2, image_size=224, num_layers=2)
+        m.engine.begin_local_update("art", steps_per_epoch=5)
+        it = DevicePrefetcher(host, up, DEV, depth=2) if mode == "prefetch" else (up(b) for b in host)
+        n = 0
+        for i, b in enumerate(it):
+            assert torch.equal(b["input_ids"].cpu(), host[i]["input_ids"])
+            m.engine.train_step(b)
+            n += 1
+        assert n == 5
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in m.state_dict().items() if "adapter_1" in k})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+    def boom(b):
+        raise ValueError("bad batch")
+    with pytest.raises(ValueError):
+        for _ in DevicePrefetcher(host, boom, DEV):
+            pass
