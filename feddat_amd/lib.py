@@ -96,7 +96,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes")) else i32
-    if lib.feddat_abi_version() != 1:
+    if lib.feddat_abi_version() != 2:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -28,7 +28,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_EINVAL 1
 #define FEDDAT_ELAUNCH 2
 
-#define FEDDAT_ABI_VERSION 1
+#define FEDDAT_ABI_VERSION 2   /* 2: Hi/Wi in im2col, pos_batch_stride in image_embed_assemble, new entry points */
 int feddat_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -36,7 +36,9 @@ int feddat_abi_version(void);
  * Replaces the frozen nn.Linear calls inside HF ViltLayer (reference call site src/modeling/vilt.py:127;
  * FFN-out dense+residual: src/modeling/adaptered_output.py:74-76) and, with B = W^T, their dX-only
  * backward (autograd through frozen weights, src/train/visionlanguage_tasks/task_trainer.py:302,323).
- * Requirements: N % 128 == 0, K % 64 == 0, lda/ldb % 8 == 0.
+ * Requirements: K % 64 == 0, lda/ldb % 8 == 0, and N % 192 == 0 with M >= 1024 (persistent ping-pong kernel, 192 x 192 or
+ * 256 x 192 tiles chosen per shape) or else N % 128 == 0 (128 x 128 kernel).  Row strides (lda, ldr, ldo*) are in elements
+ * and may exceed the row length (strided operands).
  * ------------------------------------------------------------------------------------------- */
 #define FEDDAT_EPI_BF16 0       /* out_bf16 = acc + bias                                    */
 #define FEDDAT_EPI_RESID_F32 1  /* out_f32  = acc + bias + resid(fp32)                      */
