@@ -509,9 +509,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
             }
         }
         read_frags();
-        // no wait here: the compiler waits (counted) for each fragment right before the MFMA group that uses it, so
-        // the k-half-1 fragments land under the k-half-0 MFMAs; every fragment has been waited for by the end of
-        // the C phase, whose lgkmcnt(0) + barrier is what a later overwrite of this stage is ordered against
+        // Group 1 overwrites the stage it has just read (k-tile j+2 -> stage j & 1) in the very next slot, so the
+        // fragment reads are retired BEFORE the barrier (a restage one phase after the last read needs the reads
+        // retired by an lgkmcnt in front of the reading phase's barrier; group 0 restages two phases later and would
+        // not need it -- measured cost of waiting in both groups: none).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
