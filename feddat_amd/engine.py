@@ -188,8 +188,13 @@ class ViltDatEngine:
         self.cls_ln = f32(2 * B, H)
         self.cls_st = f32(2 * B, 2)
         self.pooled = f32(2 * B, H)
-        self.hd = {k: dict(a0=f32(B, 2 * H), n0=f32(B, 2 * H), st=f32(B, 2), g0=f32(B, 2 * H),
-                           logits=f32(B, num_labels)) for k in ("all", "p1", "p2")}
+        # task-head activations.  P0 (gated rows, old head) and P1 (adapter_1 rows, same old head) run as ONE 2B-row
+        # pass ("all" = rows [0,B), "p1" = rows [B,2B) of the "both" buffers); P2 uses the updated head.
+        both = dict(a0=f32(2 * B, 2 * H), n0=f32(2 * B, 2 * H), st=f32(2 * B, 2), g0=f32(2 * B, 2 * H),
+                    logits=f32(2 * B, num_labels))
+        self.hd = {"both": both, "all": {k: v[:B] for k, v in both.items()}, "p1": {k: v[B:] for k, v in both.items()},
+                   "p2": dict(a0=f32(B, 2 * H), n0=f32(B, 2 * H), st=f32(B, 2), g0=f32(B, 2 * H),
+                              logits=f32(B, num_labels))}
         self.dlogits = f32(B, num_labels)
         self.loss_buf = {k: f32(4 + 2 * B) for k in ("p1", "p2")}
         self.dg0, self.dn0, self.da0 = f32(B, 2 * H), f32(B, 2 * H), f32(B, 2 * H)
@@ -422,8 +427,9 @@ class ViltDatEngine:
         L.tanh_fwd(self.pooled[:nb])
 
     def _head_fwd(self, pooled, slot: str, task: str):
-        """vilt.py:202-209: fc0 -> LayerNorm(1536, eps 1e-5) -> GELU -> fc1 on B rows."""
-        B, H, C = self.B, self.H, self.C
+        """vilt.py:202-209: fc0 -> LayerNorm(1536, eps 1e-5) -> GELU -> fc1 on the rows of `pooled` (B, or 2B for the
+        joint P0 + P1 pass)."""
+        B, H, C = pooled.shape[0], self.H, self.C
         hp, s = self.head[task], self.hd[slot]
         pre = f"task_layer.{task}."
         self._sg(pooled, H, 1, hp.view(pre + "clf_fc0.weight"), 1, H, B, 2 * H, H, s["a0"], ksplit=4,
@@ -572,9 +578,10 @@ class ViltDatEngine:
         self._forward_dual()
         pooled_g, pooled_s = self.pooled[:B], self.pooled[B:]
         # P0: logits of the gated pass with the current head (no grad)          task_trainer.py:283-287
-        logits_all = self._head_fwd(pooled_g, "all", task)
         # P1: adapter_1 pass, KL to P0                                           task_trainer.py:290-308
-        logits_1 = self._head_fwd(pooled_s, "p1", task)
+        # same head weights for both -> one 2B-row pass over [pooled_g; pooled_s]
+        logits_both = self._head_fwd(self.pooled[:2 * B], "both", task)
+        logits_all, logits_1 = logits_both[:B], logits_both[B:]
         L.dat_loss_fwd_bwd(logits_1, logits_all, self.inp["target"], self.dlogits, self.loss_buf["p1"])
         self._head_bwd(pooled_s, "p1", task, self.dpooled[B:])
         self._adamw(hp)
