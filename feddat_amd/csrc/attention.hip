@@ -310,11 +310,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
 }
 
 template <typename K>
-int set_lds(K kern, int bytes, bool& done) {
-    if (done) return 0;
-    done = true;
-    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
-               ? 0 : 1;
+int set_lds(K kern, int bytes) {
+    return fd_set_max_lds((const void*)kern, bytes) == FEDDAT_OK ? 0 : 1;
 }
 
 // hardware-semantics probe for tests: returns, per lane, tr_frag8(rows 4g.., rows 16+4g.., col block 16) of a
@@ -337,11 +334,10 @@ extern "C" int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* c
     FD_CHECK_ARG(qkv && ctx && B > 0 && S > 0 && S <= 320 && heads > 0);
     const int nks = (S + 31) / 32;
     const int lds = nks * 32 * ROWB * 2 + nks * 32 * 4;
-    static bool fdone[11] = {false};
 #define NKS_MAX_LDS_F(N) ((N) * 32 * ROWB * 2 + (N) * 32 * 4)
 #define ATTN_FWD(N)                                                                                           \
     case N:                                                                                                   \
-        if (set_lds(attn_fwd_kernel<N>, NKS_MAX_LDS_F(N), fdone[N])) return FEDDAT_ELAUNCH;                                        \
+        if (set_lds(attn_fwd_kernel<N>, NKS_MAX_LDS_F(N))) return FEDDAT_ELAUNCH;                                        \
         hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * heads), dim3(256), lds, stream, (const bf16*)qkv,     \
                            key_mask, (bf16*)ctx, lse, S, heads);                                              \
         break;
@@ -359,11 +355,10 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
     FD_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && B > 0 && S > 0 && S <= 320 && heads > 0);
     const int nks = (S + 31) / 32;
     const int lds = nks * 32 * ROWB * 2 + nks * 32 * 4 * 3;
-    static bool bdone[11] = {false};
 #define NKS_MAX_LDS_B(N) ((N) * 32 * ROWB * 2 + (N) * 32 * 4 * 3)
 #define ATTN_BWD(N)                                                                                           \
     case N:                                                                                                   \
-        if (set_lds(attn_bwd_kernel<N>, NKS_MAX_LDS_B(N), bdone[N])) return FEDDAT_ELAUNCH;                                        \
+        if (set_lds(attn_bwd_kernel<N>, NKS_MAX_LDS_B(N))) return FEDDAT_ELAUNCH;                                        \
         hipLaunchKernelGGL(attn_bwd_kernel<N>, dim3(B * heads, 2), dim3(256), lds, stream, (const bf16*)qkv,     \
                            key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads);        \
         break;
@@ -374,6 +369,15 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
     }
 #undef ATTN_BWD
     FD_LAUNCH_RET();
+}
+
+int fd_prepare_attn_kernels() {
+#define PREP(N)                                                                          \
+    if (set_lds(attn_fwd_kernel<N>, (N) * 32 * ROWB * 2 + (N) * 32 * 4)) return FEDDAT_ELAUNCH; \
+    if (set_lds(attn_bwd_kernel<N>, (N) * 32 * ROWB * 2 + (N) * 32 * 4 * 3)) return FEDDAT_ELAUNCH;
+    PREP(1) PREP(2) PREP(3) PREP(4) PREP(5) PREP(6) PREP(7) PREP(8) PREP(9) PREP(10)
+#undef PREP
+    return FEDDAT_OK;
 }
 
 extern "C" int feddat_probe_tr16(const void* in_bf16_64x64, void* out_bf16_64x8, hipStream_t stream) {

@@ -26,6 +26,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
         return e__ == hipSuccess ? FEDDAT_OK : FEDDAT_ELAUNCH; \
     } while (0)
 
+// host side, device_state.hip: per-device caches (thread-safe, keyed by the calling thread's current HIP device)
+int fd_device_cus(int* n_cu);                          // compute units of the current device
+int fd_set_max_lds(const void* kernel, int bytes);     // hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel)
+int fd_debug_flags();                                  // ablation flags (feddat_set_debug_flags), 0 in production
+int fd_prepare_all_kernels();                          // sets every kernel's LDS attribute on the current device
+int fd_prepare_gemm_kernels();
+int fd_prepare_attn_kernels();
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 

@@ -1,0 +1,83 @@
+// K7, collective half: FedAvg of the shared adapter as ONE RCCL all-reduce over xGMI (replaces get_average_net's
+// host-driven K x 48 tensor loop, src/train/main.py:50-65; call site main.py:510).
+//
+// RCCL is bound at run time (dlopen of the librccl the process already has -- PyTorch-ROCm ships one -- or the system
+// one), so libfeddat_hip.so carries no link-time dependency on it and the single-GPU path never touches it.
+#include <dlfcn.h>
+#include <mutex>
+
+#include "common.hip.h"
+
+namespace {
+// the slice of rccl.h this file uses (opaque handles; enum values are fixed by the NCCL ABI)
+struct ncclUniqueId_ { char internal[128]; };
+typedef int (*GetUniqueIdFn)(ncclUniqueId_*);
+typedef int (*CommInitRankFn)(void**, int, ncclUniqueId_, int);
+typedef int (*CommDestroyFn)(void*);
+typedef int (*AllReduceFn)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, void*, hipStream_t);
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;
+
+struct Rccl {
+    void* h = nullptr;
+    GetUniqueIdFn get_id = nullptr;
+    CommInitRankFn init_rank = nullptr;
+    CommDestroyFn destroy = nullptr;
+    AllReduceFn all_reduce = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::once_flag g_once;
+
+const Rccl& rccl() {
+    std::call_once(g_once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.h) break;
+        }
+        if (!g_rccl.h) return;
+        g_rccl.get_id = (GetUniqueIdFn)dlsym(g_rccl.h, "ncclGetUniqueId");
+        g_rccl.init_rank = (CommInitRankFn)dlsym(g_rccl.h, "ncclCommInitRank");
+        g_rccl.destroy = (CommDestroyFn)dlsym(g_rccl.h, "ncclCommDestroy");
+        g_rccl.all_reduce = (AllReduceFn)dlsym(g_rccl.h, "ncclAllReduce");
+        g_rccl.ok = g_rccl.get_id && g_rccl.init_rank && g_rccl.destroy && g_rccl.all_reduce;
+    });
+    return g_rccl;
+}
+}  // namespace
+
+extern "C" int feddat_comm_unique_id(void* id_128_bytes) {
+    FD_CHECK_ARG(id_128_bytes);
+    const Rccl& r = rccl();
+    if (!r.ok) return FEDDAT_ELAUNCH;
+    return r.get_id((ncclUniqueId_*)id_128_bytes) == 0 ? FEDDAT_OK : FEDDAT_ELAUNCH;
+}
+
+extern "C" int feddat_comm_create(const void* id_128_bytes, int world, int rank, void** comm_out) {
+    FD_CHECK_ARG(id_128_bytes && comm_out && world > 0 && rank >= 0 && rank < world);
+    const Rccl& r = rccl();
+    if (!r.ok) return FEDDAT_ELAUNCH;
+    ncclUniqueId_ id;
+    __builtin_memcpy(&id, id_128_bytes, sizeof(id));
+    return r.init_rank(comm_out, world, id, rank) == 0 ? FEDDAT_OK : FEDDAT_ELAUNCH;
+}
+
+extern "C" int feddat_comm_destroy(void* comm) {
+    if (!comm) return FEDDAT_OK;
+    const Rccl& r = rccl();
+    if (!r.ok) return FEDDAT_ELAUNCH;
+    return r.destroy(comm) == 0 ? FEDDAT_OK : FEDDAT_ELAUNCH;
+}
+
+extern "C" int feddat_fedavg_allreduce(void* comm, float* flat, float* scratch, long n, float num, float total,
+                                       hipStream_t stream) {
+    FD_CHECK_ARG(comm && flat && scratch && n > 0 && total > 0.f);
+    const Rccl& r = rccl();
+    if (!r.ok) return FEDDAT_ELAUNCH;
+    // scratch = flat * num / total in the reference's operation order (main.py:62), SUM over the clients, write back
+    int rc = feddat_fedavg_accumulate(scratch, flat, n, num, total, 1, stream);
+    if (rc != FEDDAT_OK) return rc;
+    if (r.all_reduce(scratch, scratch, (size_t)n, kNcclFloat32, kNcclSum, comm, stream) != 0) return FEDDAT_ELAUNCH;
+    if (hipMemcpyAsync(flat, scratch, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        return FEDDAT_ELAUNCH;
+    return FEDDAT_OK;
+}

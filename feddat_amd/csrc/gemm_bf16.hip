@@ -687,6 +687,26 @@ extern "C" int feddat_gemm_bf16_nt_skinny(const void* A, int lda, const void* B,
 namespace {
 }  // namespace
 
+using V2Kernel = void (*)(GemmArgsV2);
+static const V2Kernel (*v2_kernel_table())[5] {
+    static const V2Kernel kernels[2][5] = {
+        {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 3>,
+         gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3>,
+         gemm_nt_v2_kernel<FEDDAT_EPI_F32, 3>},
+        {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 4>,
+         gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 4>,
+         gemm_nt_v2_kernel<FEDDAT_EPI_F32, 4>}};
+    return kernels;
+}
+
+int fd_prepare_gemm_kernels() {
+    for (int w = 0; w < 2; ++w)
+        for (int e = 0; e < 5; ++e)
+            if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
+                return FEDDAT_ELAUNCH;
+    return fd_set_max_lds((const void*)gemm_nt_kernel, 4 * TILE_BYTES);
+}
+
 extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
                                    const float* bias, const float* resid, int ldr, const void* aux, int ldaux,
                                    float* out_f32, int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2,
@@ -715,16 +735,10 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     if (use_v2) {
         GemmArgsV2 a2;
         a2.g = g;
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("FEDDAT_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+        const int dbg = fd_debug_flags();      // tools/ ablations only (feddat_set_debug_flags); 0 in production
         a2.dbg = dbg;
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FEDDAT_ELAUNCH;
-            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
+        int n_cu = 0;
+        if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
         const int tiles_n = N / V2_BN;
         // balanced M tiles of <= BM rows; XCD-aware tile order: split the XCDs over N as well when B (N x K bf16) would
         // not stay in a 4 MiB L2 and the launch takes more than one round of tiles
@@ -749,34 +763,17 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         if (dbg & 32) wm4 = false;
         if (dbg & 64) wm4 = true;
         a2 = wm4 ? a4 : a3;
-        using KernelFn = void (*)(GemmArgsV2);
-        static const KernelFn kernels[2][5] = {
-            {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 3>,
-             gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3>,
-             gemm_nt_v2_kernel<FEDDAT_EPI_F32, 3>},
-            {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 4>,
-             gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 4>,
-             gemm_nt_v2_kernel<FEDDAT_EPI_F32, 4>}};
-        static bool attr2 = false;
-        if (!attr2) {
-            for (int w = 0; w < 2; ++w)
-                for (KernelFn k : kernels[w])
-                    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS);
-            attr2 = true;
-        }
+        const V2Kernel kern = v2_kernel_table()[wm4 ? 1 : 0][epi];
+        const int lds_bytes = wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS;
+        if (fd_set_max_lds((const void*)kern, lds_bytes) != FEDDAT_OK) return FEDDAT_ELAUNCH;
         const int total = a2.tiles_m * (N / V2_BN);
         int grid = total < n_cu ? total : n_cu;
         if ((dbg >> 8) > 0 && (dbg >> 8) < grid) grid = dbg >> 8;      // ablation: cap the number of persistent blocks
-        hipLaunchKernelGGL(kernels[wm4 ? 1 : 0][epi], dim3(grid), dim3(512), wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS, stream, a2);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, a2);
         FD_LAUNCH_RET();
     }
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-        attr_set = true;
-    }
+    if (fd_set_max_lds((const void*)gemm_nt_kernel, 4 * TILE_BYTES) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, stream, g);
     FD_LAUNCH_RET();
 }

@@ -616,6 +616,12 @@ class ViltDatEngine:
             self.graph.replay()
         return self.loss_buf["p2"]
 
+    def ensure_captured(self):
+        """Capture the step graph now if it is not there yet (TaskTrainer.train calls this before it starts the upload
+        worker, so no capture ever overlaps a prefetch)."""
+        if self.graph is None:
+            self._capture()
+
     def _capture(self):
         """Capture the whole step into one hipGraph (all launches are on static buffers; the LR schedule and Adam
         step counts live on the device).  The optimizer state is saved/restored around the warm-up + capture
@@ -629,7 +635,10 @@ class ViltDatEngine:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: other host threads (feddat_amd.data.DevicePrefetcher's upload worker) may allocate and copy on their
+        # own streams while this thread captures; the default global mode would turn their hipMalloc / hipMemcpy into
+        # hipErrorStreamCaptureUnsupported
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._step_kernels()
         torch.cuda.synchronize()
         for g, (p, m, v, st) in zip(groups, saved):

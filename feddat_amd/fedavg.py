@@ -19,7 +19,7 @@ from . import lib as L
 
 def get_average_net(server, c_models: List[Dict[str, torch.Tensor]], nums: Sequence[float], ordered_tasks=None,
                     device=None):
-    """server: object with .comm_state_dict_names and .state_dict() (e.g. feddat_amd.vilt.ViltContinualLearner)
+    """server: object with .comm_state_dict_names and .state_dict() (e.g. feddat_amd.modeling.ViltContinualLearner)
     or a plain dict name -> device tensor.  Keys containing 'clf' are skipped (main.py:54)."""
     sd = server if isinstance(server, dict) else server.state_dict()
     names = list(sd.keys()) if isinstance(server, dict) else list(server.comm_state_dict_names)
@@ -37,21 +37,51 @@ def get_average_net(server, c_models: List[Dict[str, torch.Tensor]], nums: Seque
     return server
 
 
+def all_reduce_sum(t: torch.Tensor):
+    """In-place SUM over all ranks.  Backend "nccl" (== RCCL): on the device buffer, over xGMI.  Any other backend (gloo:
+    the single-GPU / CPU test rigs) is staged through the host when the tensor lives on the device."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" or not t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    else:
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+    return t
+
+
 def allreduce_flat(flat: torch.Tensor, buf: torch.Tensor, num: float, total: float, prescale=None):
     """buf = flat * num / total (device kernel, reference operation order) ; all_reduce(SUM) ; flat <- buf.
     `prescale(acc, x, num, total)` defaults to the HIP kernel; the world_size-2 gloo test on CPU injects a host
     stand-in so that rendezvous, collective and write-back are exercised without a GPU."""
-    import torch.distributed as dist
     (prescale or (lambda acc, x, n, t: L.fedavg_accumulate(acc, x, n, t, True)))(buf, flat, num, total)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    all_reduce_sum(buf)
     flat.copy_(buf)
     return flat
 
 
-def allreduce_average(engine, world: int, num: float = 1.0, total: float = None):
+def make_rccl_comm(world: int, rank: int):
+    """RCCL communicator through the C ABI (feddat_comm_*); the unique id travels over the already-initialised
+    torch.distributed group (any backend) as a host object."""
+    import torch.distributed as dist
+
+    def exchange(ident: bytes) -> bytes:
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    return L.RcclComm(world, rank, exchange)
+
+
+def allreduce_average(engine, world: int, num: float = 1.0, total: float = None, comm=None):
+    """One client per GPU: adapter_1 <- sum_k adapter_1[k] * num_k / total.  With `comm` (L.RcclComm) the whole exchange is
+    the C-ABI call feddat_fedavg_allreduce; otherwise torch.distributed issues the all-reduce (backend "nccl" == RCCL)."""
     flat = engine.comm_flat()
     if not hasattr(engine, "_fedavg_buf"):
         engine._fedavg_buf = torch.empty_like(flat)
-    allreduce_flat(flat, engine._fedavg_buf, num, float(world) if total is None else float(total))
+    total = float(world) if total is None else float(total)
+    if comm is not None:
+        comm.fedavg_allreduce(flat, engine._fedavg_buf, num, total)
+    else:
+        allreduce_flat(flat, engine._fedavg_buf, num, total)
     engine.repack_adapter(1)
     return flat

@@ -32,6 +32,14 @@ class WgradSeg(C.Structure):
 
 _SIGS = {
     "feddat_abi_version": [],
+    "feddat_ctx_create": [i32, C.POINTER(vp)],
+    "feddat_ctx_destroy": [vp],
+    "feddat_ctx_device": [vp, C.POINTER(i32), C.POINTER(i32)],
+    "feddat_set_debug_flags": [i32],
+    "feddat_comm_unique_id": [vp],
+    "feddat_comm_create": [vp, i32, i32, C.POINTER(vp)],
+    "feddat_comm_destroy": [vp],
+    "feddat_fedavg_allreduce": [vp, vp, vp, i64, f32, f32, vp],
     "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
     "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
     "feddat_gemm_bf16_nt_skinny": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32,
@@ -96,10 +104,60 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes")) else i32
-    if lib.feddat_abi_version() != 2:
+    if lib.feddat_abi_version() != 3:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
+    if os.environ.get("FEDDAT_GEMM_DEBUG"):       # tools/ ablations: the env var is read HERE, never by the library
+        lib.feddat_set_debug_flags(int(os.environ["FEDDAT_GEMM_DEBUG"]))
     _lib = lib
     return lib
+
+
+class Context:
+    """feddat_ctx: explicit per-device handle (sets every kernel's launch attributes on that device at creation)."""
+
+    def __init__(self, device: int):
+        self._h = vp()
+        _chk(load().feddat_ctx_create(int(device), C.byref(self._h)), "feddat_ctx_create")
+
+    def info(self):
+        d, cu = i32(), i32()
+        _chk(load().feddat_ctx_device(self._h, C.byref(d), C.byref(cu)), "feddat_ctx_device")
+        return d.value, cu.value
+
+    def close(self):
+        if self._h:
+            load().feddat_ctx_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RcclComm:
+    """ncclComm_t made through the C ABI (feddat_comm_*): rank 0 draws the unique id, `exchange(id_bytes) -> id_bytes`
+    ships it to the other ranks over any host channel (torch.distributed object broadcast, a TCPStore, MPI, a file)."""
+
+    def __init__(self, world: int, rank: int, exchange):
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _chk(load().feddat_comm_unique_id(buf), "feddat_comm_unique_id")
+        ident = exchange(bytes(buf.raw))
+        self._h = vp()
+        _chk(load().feddat_comm_create(C.c_char_p(ident), world, rank, C.byref(self._h)), "feddat_comm_create")
+        self.world, self.rank = world, rank
+
+    def fedavg_allreduce(self, flat, scratch, num: float, total: float):
+        _dev(flat, scratch)
+        _chk(load().feddat_fedavg_allreduce(self._h, _p(flat), _p(scratch), flat.numel(), float(num), float(total),
+                                            _stream()), "feddat_fedavg_allreduce")
+
+    def close(self):
+        if self._h:
+            load().feddat_comm_destroy(self._h)
+            self._h = vp()
 
 
 def _p(t: Optional[torch.Tensor]):

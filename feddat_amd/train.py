@@ -23,7 +23,7 @@ import torch
 
 from . import lib as L
 from . import vilt_spec
-from .fedavg import allreduce_average, get_average_net  # noqa: F401  (re-exported: main.py:50)
+from .fedavg import all_reduce_sum, allreduce_average, get_average_net  # noqa: F401  (re-exported: main.py:50)
 from .modeling import ViltContinualLearner, create_vilt_continual_learner_model
 
 
@@ -99,6 +99,8 @@ class TaskTrainer:
                                num_epochs=self.num_epochs, warmup_ratio=self.warmup_ratio,
                                opt_adapters=optimizer.adapters)
         model.adapter_requires_grad[2] = False
+        if self.use_graph:
+            eng.ensure_captured()      # before the upload worker below starts: capture never overlaps a prefetch
         loss = None
         dev = model.device
         upload = lambda b: {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
@@ -182,7 +184,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--checkpoint", type=str, default=None)
     p.add_argument("--model_path", type=str, default=None)
     # synthetic stand-ins for the private datasets / checkpoints (no network in this environment)
-    p.add_argument("--synthetic_steps", type=int, default=8, help="batches per client per round")
+    p.add_argument("--synthetic_steps", type=str, default="8",
+                   help="batches per client per round: one integer, or a comma list dealt to the clients in order "
+                        "(heterogeneous len(loader), e.g. 40,50,60,70,80,45,55,65 for 8 clients)")
     p.add_argument("--image_size", type=int, default=384)
     p.add_argument("--num_layers", type=int, default=12)
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
@@ -208,13 +212,25 @@ def main(argv=None):
     import torch.distributed as dist
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # FEDDAT_FORCE_DEVICE / FEDDAT_DIST_BACKEND: several ranks on one GPU over gloo, so that the multi-rank control flow
+    # (HIP pre-scale + all-reduce + write-back) can be tested on a single-GPU box; production = one GPU per rank, RCCL
+    if os.environ.get("FEDDAT_FORCE_DEVICE") is not None:
+        local = int(os.environ["FEDDAT_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("FEDDAT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     tasks = TASK_SETS.get(args.ordered_cl_tasks, args.ordered_cl_tasks.split(","))
     my_tasks = tasks[rank::world]                       # client -> GPU mapping
     if not my_tasks:
-        raise L.FeddatHipError(f"rank {rank} of {world} has no client: use at most {len(tasks)} processes")
+        # more GPUs than clients (the reference's default 'domain' set has 5): this rank holds no client; it still joins
+        # every round's all-reduce with a zero contribution so that the average over the K real clients is unchanged
+        log.warning("rank %d of %d holds no client (%d clients): idle, joins the all-reduce only", rank, world, len(tasks))
+    steps_list = [int(x) for x in str(args.synthetic_steps).split(",")]
+    steps_of = {t: steps_list[i % len(steps_list)] for i, t in enumerate(tasks)}
     dev = torch.device("cuda", local)
     params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)    # stand-in for from_pretrained
     model = create_vilt_continual_learner_model(params, tasks, dev, args.batch_size, args.image_size,
@@ -225,7 +241,7 @@ def main(argv=None):
         return {n: v.clone() for n, v in sd.items() if ("task" in n or "adapter_0" in n or "adapter_2" in n)}
     personal_params = {t: personal(model.state_dict()) for t in my_tasks}
     data = {t: [vilt_spec.synthetic_batch(args.batch_size, args.image_size, args.seed + 1000 * ti + s, device=dev)
-                for s in range(args.synthetic_steps)] for ti, t in enumerate(tasks) if t in my_tasks}
+                for s in range(steps_of[t])] for ti, t in enumerate(tasks) if t in my_tasks}
     server_flat = eng.comm_flat().clone()
     acc = torch.zeros_like(server_flat)
     comm_names = model.comm_state_dict_names
@@ -254,8 +270,10 @@ def main(argv=None):
             personal_params[task_key] = personal(model.state_dict())     # main.py:493-497
             # local pre-sum in client order, then (if distributed) one all-reduce: main.py:50-65
             L.fedavg_accumulate(acc, eng.comm_flat(), 1.0, float(len(tasks)), k == 0)
+        if not my_tasks:
+            acc.zero_()
         if world > 1:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            all_reduce_sum(acc)             # RCCL over xGMI, in place on the 3.58 MB device buffer
         server_flat.copy_(acc)
         if args.save_every and ((comm_round + 1) % args.save_every == 0 or comm_round == args.comm_rounds - 1):
             from . import checkpoint

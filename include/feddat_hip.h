@@ -6,7 +6,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless stated; the library never allocates or frees;
- *   - all launches are asynchronous on `stream`; functions are re-entrant per stream, no global state;
+ *   - all launches are asynchronous on `stream`; functions are re-entrant per stream; the only library-side state is the
+ *     per-device cache described under "Devices and contexts" (thread-safe) and the optional feddat_ctx handles;
  *   - return value: FEDDAT_OK (0), FEDDAT_EINVAL (bad shape / alignment / null), FEDDAT_ELAUNCH (HIP launch error);
  *   - "bf16" buffers are passed as void* (raw bfloat16, 2 bytes per element); fp32 as float*;
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
@@ -28,8 +29,24 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_EINVAL 1
 #define FEDDAT_ELAUNCH 2
 
-#define FEDDAT_ABI_VERSION 2   /* 2: Hi/Wi in im2col, pos_batch_stride in image_embed_assemble, new entry points */
+#define FEDDAT_ABI_VERSION 3   /* 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce */
 int feddat_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Devices and contexts.  The per-op entry points below are stateless towards the caller: whatever they cache (compute-unit
+ * count, per-kernel "max dynamic LDS" attributes) is keyed by the calling thread's CURRENT HIP device and mutex-guarded,
+ * so one process may drive several GPUs from several threads.  feddat_ctx makes that explicit for callers that want
+ * it: create = switch to `device`, look up its CU count and set every kernel's attributes there (so that no later launch
+ * pays for it, e.g. inside a stream capture); destroy frees only the handle.  The composite entry points
+ * (feddat_vilt_layer_fwd/bwd) take a ctx.
+ * feddat_set_debug_flags: GEMM ablation switches used by tools/ (8 = skip epilogue, 32/64 = force 192-/256-row tiles,
+ * bits 8.. = cap on persistent blocks); process-wide, 0 by default, never read from the environment by the library.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct feddat_ctx feddat_ctx;
+int feddat_ctx_create(int device, feddat_ctx** ctx);
+int feddat_ctx_destroy(feddat_ctx* ctx);
+int feddat_ctx_device(const feddat_ctx* ctx, int* device, int* compute_units);
+int feddat_set_debug_flags(int flags);
 
 /* ---------------------------------------------------------------------------------------------
  * K1  bf16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T  (+ fused epilogue)
@@ -258,6 +275,17 @@ int feddat_scatter_cls_rows(const float* rows, float* out_f32, void* out_bf16, i
  * ------------------------------------------------------------------------------------------- */
 int feddat_fedavg_accumulate(float* acc, const float* x, long n, float num, float total, int first,
                              hipStream_t stream);
+/* The collective itself, for callers without torch.distributed: RCCL bound at run time (dlopen of the librccl already in
+ * the process, else the system one).  `comm` is an ncclComm_t (passed as void*): either the caller's own, or one made
+ * here -- rank 0 calls feddat_comm_unique_id (128 bytes, host memory), ships the id to the other ranks by any host
+ * channel, every rank calls feddat_comm_create on its device (collective, like ncclCommInitRank).
+ * feddat_fedavg_allreduce: scratch = flat * num / total (reference op order, main.py:62); all-reduce(SUM) of scratch over
+ * `comm` on `stream` (xGMI); flat <- scratch.  flat / scratch: fp32 [n] device buffers (ViLT: n = 894 528 = 3.58 MB).
+ * Replaces get_average_net's host loop over K clients x 48 tensors (main.py:50-65, call site main.py:510). */
+int feddat_comm_unique_id(void* id_128_bytes);
+int feddat_comm_create(const void* id_128_bytes, int world, int rank, void** comm_out);
+int feddat_comm_destroy(void* comm);
+int feddat_fedavg_allreduce(void* comm, float* flat, float* scratch, long n, float num, float total, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * hardware-semantics probes used by tests/ (MFMA operand pairing, ds_read_b64_tr_b16 layout)

@@ -242,10 +242,37 @@ def golden_g6(out):
     print("G6 losses", losses)
 
 
+def golden_g8(out, steps=40):
+    """G8: one REALISTIC local round of the full 12-layer ViLT-B/32 on the reference: B=4, 384x384, len(loader)=40,
+    num_epochs=15 -> N=600 scheduler ticks, warm-up 60 ticks = 30 batches, so the last 10 batches run at lr ~ 1e-4
+    (task_trainer.py:53-59).  Stored per adapter_0 / adapter_1 / head tensor: the UPDATE dW = W_after - W_init as L2 norm,
+    mean |dW| and 1024 strided samples (W_init is the name-seeded fill, regenerated by the tests), so that parity is
+    asserted on the distance the weights moved, not on the weights."""
+    d = O.ViltDims(layers=12)
+    model = build_reference_model(d, ["art"], bias_std=0.02)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batches = [O.synthetic_batch(4, 384, 8000 + s) for s in range(steps)]
+    losses, _ = ref_local_update(model, "art", batches, lr=1e-4)
+    rec = {"losses": np.array(losses, np.float32), "steps": np.array(steps)}
+    for k, v in model.state_dict().items():
+        if "adapter_0" in k or "adapter_1" in k or k.startswith("task_layer.art."):
+            dw = (v.detach() - init[k]).flatten()
+            idx = torch.linspace(0, dw.numel() - 1, min(1024, dw.numel())).long()
+            rec["dnorm::" + k] = np_(dw.norm())
+            rec["dmean::" + k] = np_(dw.abs().mean())
+            rec["dmax::" + k] = np_(dw.abs().max())
+            rec["dsamp::" + k] = np_(dw[idx])
+    np.savez_compressed(os.path.join(out, "g8_round40.npz"), **rec)
+    print("G8 losses", losses[:3], "...", losses[-3:])
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     torch.manual_seed(0)
+    if "--only-g8" in sys.argv:
+        golden_g8(out)
+        return
     if "--only-g6" in sys.argv:          # the other fixtures are unchanged; regenerate just this one
         golden_g6(out)
         return
@@ -413,6 +440,7 @@ def main():
             rec["samp256::" + k] = np_(flat[idx])
     np.savez_compressed(os.path.join(out, "g4_vilt12_384.npz"), **rec)
     golden_g6(out)
+    golden_g8(out)
     print("G4 losses", losses)
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)) // 1024, "KiB")

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import feddat_oracle as O
-from tests.golden_util import load
+from tests.golden_util import assert_update_parity, load
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -87,13 +87,14 @@ def test_continual_learner_train_and_fedavg_round(api, golden_dir):
         assert score == 0.0 and c_model is server
         assert server.gating and server.active == "adapter_0"        # final mode of train_step, task_trainer.py:311-312
         c_models.append({n: server.state_dict()[n].clone() for n in server.comm_state_dict_names})
-        for k in [k for k in r if k.startswith(f"personal.{t}.")]:
-            n = k[len(f"personal.{t}."):]
-            assert (server.state_dict()[n].cpu() - torch.from_numpy(r[k])).abs().max() < 1e-3, k
+        # parity on the UPDATE of the personal adapter_0 tensors (they move ~1.5e-4 in 3 steps: a bare 1e-3 bound on the
+        # weights could not fail), against the reference's own round
+        pk = {k[len(f"personal.{t}."):]: torch.from_numpy(r[k]) for k in r if k.startswith(f"personal.{t}.")}
+        assert_update_parity(list(pk), server.state_dict(), pk, P, 1e-3, 0.1, f"personal {t}")
     server.load_state_dict(server_sd)
     api.train.get_average_net(server, c_models, [1, 1], tasks, DEV)
-    for k in [k[7:] for k in r if k.startswith("server.")]:
-        assert (server.state_dict()[k].cpu() - torch.from_numpy(r["server." + k])).abs().max() < 1e-3, k
+    sk = {k[7:]: torch.from_numpy(r[k]) for k in r if k.startswith("server.")}
+    assert_update_parity(list(sk), server.state_dict(), sk, P, 1e-3, 0.1, "averaged adapter_1")
     # eval leaves the model in the adapter_1 state -> the next optimizer would not hold adapter_0 (reference quirk)
     ev = api.train.TaskTrainer(args, "art", [], [_dev(O.synthetic_batch(4, 224, 5))]).eval(server)
     assert len(ev) == 3 and server.optimizer_adapters() == (1,)
@@ -194,3 +195,22 @@ def test_device_prefetcher_matches_synchronous_upload(api):
     with pytest.raises(ValueError):
         for _ in DevicePrefetcher(host, boom, DEV):
             pass
+
+
+def test_train_with_pageable_host_batches_prefetch_and_graph(api):
+    """TaskTrainer.train as main() drives it, with PAGEABLE host batches, the upload worker and hipGraph replay together
+    (the graph is captured before the worker starts; capture mode is thread-local): same result as device-resident
+    batches without graph."""
+    d = O.ViltDims(layers=2)
+    host = [O.synthetic_batch(2, 224, 70 + s) for s in range(4)]
+    finals = []
+    for graph, prefetch, src in ((False, False, [_dev(b) for b in host]), (True, True, host)):
+        P = O.make_params(d, ["art"], bias_std=0.02)
+        m = api.modeling.create_vilt_continual_learner_model(P, ["art"], DEV, batch_size=2, image_size=224, num_layers=2)
+        args = types.SimpleNamespace(local_epochs=2, num_epochs=15, lr=1e-4, optimizer_mode="dat", debug=0,
+                                     hip_graph=graph, prefetch=prefetch)
+        api.train.TaskTrainer(args, "art", src).train(m)
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in m.state_dict().items() if "adapter_2" not in k})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k

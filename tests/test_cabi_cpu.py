@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/feddat_hip.h but not exported"
-    assert lib.feddat_abi_version() == 2
+    assert lib.feddat_abi_version() == 3
 
 
 def test_python_binding_covers_the_header():
@@ -50,3 +50,15 @@ def test_ops_fail_loudly_without_a_device():
     x = torch.zeros(16, 768)
     with pytest.raises(lib.FeddatHipError):
         lib.tanh_fwd(x)
+
+
+def test_library_does_not_read_the_environment_or_link_rccl():
+    """The launch path must not call getenv (ablation flags come in through feddat_set_debug_flags), and RCCL is bound at
+    run time only (dlopen), so the single-GPU path has no dependency on it."""
+    import subprocess
+    from feddat_amd import build
+    path = build.build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()

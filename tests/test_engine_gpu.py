@@ -4,21 +4,25 @@ fixtures captured from the reference (tests/golden/g3*, g4*).
 Stated tolerances (bf16 MFMA compute, fp32 accumulate / residual stream / master weights / Adam moments):
   * pooled features and logits of a forward pass: max-abs-diff <= 3e-2 vs the fp32 CPU path (logits are O(1));
   * the scalar losses the reference logs (loss_0 = BCE*100): relative 2e-3;
-  * trainable tensors after N local steps: max-abs-diff < 1e-3 (BASELINE.json north_star), and additionally the
-    MEAN abs diff < 3e-5 so that the bound is not met by a few lucky elements.  AdamW normalises every gradient
-    to O(1) whatever its magnitude, so elements whose true gradient is ~0 take +-lr random-walk steps under any
-    change of rounding (the reference's own torch.multinomial patch shuffle already moves them, see
-    tests/test_oracle_golden.py); the bound is therefore a few times lr_max * sqrt(steps), not fp32 epsilon.
+  * trainable tensors after N local steps, asserted on the UPDATE dW = W_after - W_init (tests/golden_util.py
+    assert_update_parity): |dW_hip - dW_ref|.max() < 1e-3 (BASELINE.json north_star) AND
+    |dW_hip - dW_ref|.mean() <= REL_MEAN * |dW_ref|.mean() per tensor.  The second bound is the one with teeth: in the 2-5
+    steps these tests run the reference's weights move only 1.5e-4 .. 3.3e-4, so a bare 1e-3 bound on the weights could
+    not fail; a missing or mis-scaled update gives a ratio of 1.  AdamW normalises every gradient to O(1) whatever its
+    magnitude, so elements whose true gradient is ~0 take +-lr random-walk steps under any change of rounding; that
+    noise is what the ratio measures.  tests/test_round40_gpu.py runs the same assertion over a realistic 40-step round.
 """
 import numpy as np
 import pytest
 import torch
 
 from oracle import feddat_oracle as O
-from tests.golden_util import load, max_abs_diff_vs_golden
+from tests.golden_util import (assert_update_parity, golden_tensor, load, max_abs_diff_vs_golden,
+                               sampled_update_parity)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+REL_MEAN = 0.1     # mean |dW_hip - dW_ref| per tensor, as a fraction of the reference's mean |dW|
 
 
 @pytest.fixture(scope="module")
@@ -33,16 +37,17 @@ def _to_dev(b):
     return {k: v.to(DEV) for k, v in b.items()}
 
 
-def _compare_state(eng, P, names, tol_max, tol_mean):
-    sd = eng.state_dict()
-    worst = (0.0, None)
-    for n in names:
-        d = (sd[n].cpu() - P[n]).abs()
-        assert float(d.max()) < tol_max, (n, float(d.max()))
-        assert float(d.mean()) < tol_mean, (n, float(d.mean()))
-        if float(d.max()) > worst[0]:
-            worst = (float(d.max()), n)
-    return worst
+def _clone(P):
+    return {k: v.detach().clone() for k, v in P.items()}
+
+
+def _golden_update_parity(g, prefix, sd, init):
+    """Every `prefix`-ed tensor of a fixture (whole or 2048-sample form) against the engine, on the update."""
+    whole = [k[len(prefix):] for k in g if k.startswith(prefix)]
+    ref = {k: golden_tensor(g, prefix + k).reshape(init[k].shape) for k in whole}
+    w = assert_update_parity(whole, sd, ref, init, 1e-3, REL_MEAN, prefix)
+    w2 = sampled_update_parity(g, prefix, sd, init, 2048, 1e-3, REL_MEAN)
+    return max(w[0], w2[0]), max(w[1], w2[1])
 
 
 @pytest.mark.parametrize("res", [224, 384])
@@ -86,6 +91,7 @@ def test_train_steps_two_layers_vs_reference_golden(eng_mod, golden_dir, use_gra
     g = load(golden_dir, "g3_vilt2_224.npz")
     d = O.ViltDims(layers=2)
     P = O.make_params(d, ["art", "gqa"], bias_std=0.02)
+    P0 = _clone(P)
     eng = eng_mod.ViltDatEngine(P, ["art", "gqa"], DEV, batch=4, res=224, layers=2)
     batches = [O.synthetic_batch(4, 224, 1234 + s) for s in range(5)]
     client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=5)
@@ -100,14 +106,10 @@ def test_train_steps_two_layers_vs_reference_golden(eng_mod, golden_dir, use_gra
         assert abs(loss - float(g["losses"][s])) < 2e-3 * abs(ref_loss) + 2e-3
         assert abs(float(out[2]) - client.last_L0) < 2e-3 * abs(client.last_L0) + 2e-3
         assert abs(float(eng.loss_buf["p1"][2]) - client.last_L1) < 2e-3 * abs(client.last_L1) + 2e-3
-        worst = _compare_state(eng, P, names, 1e-3, 3e-5)
+        worst = assert_update_parity(names, eng.state_dict(), P, P0, 1e-3, REL_MEAN, f"oracle step {s + 1}")
         if s + 1 in (1, 2, 5):   # the reference's own tensors at these steps
-            sd = eng.state_dict()
-            keys = [k[len(f"after{s+1}."):] for k in g if k.startswith(f"after{s+1}.")]
-            keys += [k.split("::", 1)[1][len(f"after{s+1}."):] for k in g if k.startswith(f"samp::after{s+1}.")]
-            for k in keys:
-                assert max_abs_diff_vs_golden(g, f"after{s+1}.{k}", sd[k]) < 1e-3, k
-    print("worst tensor diff after 5 steps:", worst)
+            worst_g = _golden_update_parity(g, f"after{s+1}.", eng.state_dict(), P0)
+    print("after 5 steps: worst (max |ddW|, mean ratio) vs oracle", worst, "vs reference golden", worst_g)
     # adapter_2 is the frozen teacher = adapter_1 at the start of the round; nothing may have touched it
     sd = eng.state_dict()
     for n in sd:
@@ -120,6 +122,7 @@ def test_optimizer_membership_flags(eng_mod, golden_dir):
     g = load(golden_dir, "g3q_flags.npz")
     d = O.ViltDims(layers=2)
     P = O.make_params(d, ["art", "gqa"], bias_std=0.02)
+    P0 = _clone(P)
     eng = eng_mod.ViltDatEngine(P, ["art", "gqa"], DEV, batch=4, res=224, layers=2)
     before = {n: v.clone() for n, v in eng.state_dict().items()}
     eng.begin_local_update("art", steps_per_epoch=3, opt_adapters=(1,))
@@ -127,8 +130,8 @@ def test_optimizer_membership_flags(eng_mod, golden_dir):
         out = eng.train_step(_to_dev(O.synthetic_batch(4, 224, 1234 + s)))
         assert abs(float(out[0]) - float(g["losses"][s])) < 2e-3 * float(g["losses"][s])
     sd = eng.state_dict()
-    for k in [k[len("after3."):] for k in g if k.startswith("after3.")]:
-        assert max_abs_diff_vs_golden(g, "after3." + k, sd[k]) < 1e-3, k
+    _golden_update_parity(g, "after3.", sd, P0)
+    for k in sd:
         if "adapter_0" in k:
             assert torch.equal(sd[k], before[k])
 
@@ -138,6 +141,7 @@ def test_full_12_layer_vs_reference_golden(eng_mod, golden_dir):
     g = load(golden_dir, "g4_vilt12_384.npz")
     d = O.ViltDims(layers=12)
     P = O.make_params(d, ["art"], bias_std=0.02)
+    P0 = _clone(P)
     eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=4, res=384, layers=12)
     batches = [O.synthetic_batch(4, 384, 4321 + s) for s in range(4)]
     for mode in ("gating", "adapter_1"):
@@ -151,19 +155,15 @@ def test_full_12_layer_vs_reference_golden(eng_mod, golden_dir):
         out = eng.train_step(_to_dev(b))
         ref = float(g["losses"][s])
         assert abs(float(out[0]) - ref) < 3e-3 * ref, (s, float(out[0]), ref)
-    sd = eng.state_dict()
-    worst = 0.0
-    for k in [k.split("::", 1)[1] for k in g if k.startswith("samp256::")]:
-        dd = max_abs_diff_vs_golden(g, k, sd[k])
-        worst = max(worst, dd)
-        assert dd < 1e-3, (k, dd)
-    print("12-layer worst adapter diff after 4 steps:", worst)
+    worst = sampled_update_parity(g, "", eng.state_dict(), P0, 256, 1e-3, REL_MEAN)
+    print("12-layer after 4 steps: worst (max |ddW|, mean ratio) vs reference golden:", worst)
 
 
 def test_non_square_image_384x640(eng_mod):
     """ViLT's processor yields up to 384 x 640 inputs: 12 x 20 patches, S = 40 + 1 + 240 = 281 tokens (> 256)."""
     d = O.ViltDims(layers=2)
     P = O.make_params(d, ["art"], bias_std=0.02)
+    P0 = _clone(P)
     eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=2, res=(384, 640), layers=2)
     g = torch.Generator().manual_seed(3)
     b = O.synthetic_batch(2, 384, 21)
@@ -175,12 +175,12 @@ def test_non_square_image_384x640(eng_mod):
     assert (pooled.cpu() - rp).abs().max() < 3e-2 and (logits.cpu() - rl).abs().max() < 3e-2
     client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=2)
     eng.begin_local_update("art", steps_per_epoch=2)
-    ref = float(client.train_step(b)[0])
-    out = eng.train_step(_to_dev(b))
-    assert abs(float(out[0]) - ref) < 2e-3 * abs(ref) + 2e-3
-    sd = eng.state_dict()
-    for n in O.trainable_names(P, "art", 0):
-        assert (sd[n].cpu() - P[n]).abs().max() < 1e-3, n
+    for _ in range(2):       # two steps: the very first adapter_1 update has lr * lambda(0) = 0
+        ref = float(client.train_step(b)[0])
+        out = eng.train_step(_to_dev(b))
+        assert abs(float(out[0]) - ref) < 2e-3 * abs(ref) + 2e-3
+    names = O.trainable_names(P, "art", 0) + [n for n in O.trainable_names(P, "art", 1) if "adapter_1" in n]
+    assert_update_parity(names, eng.state_dict(), P, P0, 1e-3, REL_MEAN)
 
 
 G6_VALID = [(384, 384), (256, 384), (384, 224), (160, 320)]
@@ -195,6 +195,7 @@ def test_padded_images_vs_reference_golden(eng_mod, golden_dir):
     batches = [O.pad_batch(O.synthetic_batch(4, 384, 6000 + s), G6_VALID, G6_TEXT) for s in range(2)]
     for use_graph in (False, True):
         P = O.make_params(d, ["art"], bias_std=0.02)
+        P0 = _clone(P)
         eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=4, res=384, layers=2)
         for mode in ("gating", "adapter_1"):
             pooled, logits = eng.forward(_to_dev(batches[0]), mode, "art")
@@ -208,9 +209,7 @@ def test_padded_images_vs_reference_golden(eng_mod, golden_dir):
             out = eng.train_step(_to_dev(b), use_graph=use_graph)
             ref = float(g["losses"][s])
             assert abs(float(out[0]) - ref) < 2e-3 * ref + 2e-3, (use_graph, s, float(out[0]), ref)
-        sd = eng.state_dict()
-        for k in [k[len("after2."):] for k in g if k.startswith("after2.")]:
-            assert max_abs_diff_vs_golden(g, "after2." + k, sd[k]) < 1e-3, k
+        _golden_update_parity(g, "after2.", eng.state_dict(), P0)
 
 
 @pytest.mark.parametrize("B,res,layers,text_len,graph", [(1, 224, 2, 40, False), (3, 224, 3, 40, True),
@@ -221,6 +220,7 @@ def test_unusual_shapes_train_steps(eng_mod, B, res, layers, text_len, graph):
     against the oracle."""
     d = O.ViltDims(layers=layers)
     P = O.make_params(d, ["art"], bias_std=0.02)
+    P0 = _clone(P)
     eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=B, res=res, layers=layers, text_len=text_len)
     bs = [O.synthetic_batch(B, res, 100 + s, text_len=text_len) for s in range(2)]
     client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=2)
@@ -229,6 +229,6 @@ def test_unusual_shapes_train_steps(eng_mod, B, res, layers, text_len, graph):
         ref = float(client.train_step(b)[0])
         out = eng.train_step(_to_dev(b), use_graph=graph)
         assert abs(float(out[0]) - ref) < 3e-3 * abs(ref)
-    sd = eng.state_dict()
-    for n in O.trainable_names(P, "art", 0):
-        assert (sd[n].cpu() - P[n]).abs().max() < 1e-3, n
+    names = O.trainable_names(P, "art", 0) + [n for n in O.trainable_names(P, "art", 1) if "adapter_1" in n]
+    # B = 1: per-element gradients are single-sample, more of them sit at the noise floor of the bf16 forward
+    assert_update_parity(names, eng.state_dict(), P, P0, 1e-3, REL_MEAN if B > 1 else 2 * REL_MEAN)

@@ -54,7 +54,9 @@ def test_probe_tr16_layout(L):
 
 
 # ------------------------------------------------------------------ K1 GEMM
-@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (5920, 768, 3072), (11840, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (5920, 768, 3072), (11840, 2304, 768),
+                                   (11840, 3072, 768),    # the only production shape on the 256 x 192 (WM = 4) tiles
+                                   (11849, 3072, 768)])   # the same plan with a ragged last M tile
 def test_gemm_epilogues(L, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -597,3 +599,50 @@ def test_gemm_race_screen_bit_identical_repeats(L, M, N, K, epi):
         out.zero_()
         L.gemm_bf16_nt(A, Bw, epi, **kw)
         assert torch.equal(out, first)
+
+
+# ------------------------------------------------------------------ contexts / RCCL-direct collective
+def test_two_contexts_in_one_process_and_threads(L):
+    """Two feddat_ctx handles (a one-GPU box: both on device 0) and launches from two host threads: the per-device caches
+    are keyed by device and mutex-guarded, nothing is first-caller-wins."""
+    import threading
+    c0, c1 = L.Context(0), L.Context(0)
+    assert c0.info() == c1.info() and c0.info()[1] >= 64
+    A = bf(torch.randn(1200, 768, device=DEV))
+    Bw = bf(torch.randn(768, 768, device=DEV) * 0.05)
+    ref = A.float() @ Bw.float().t()
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                o = torch.empty(1200, 768, dtype=torch.bfloat16, device=DEV)
+                for _ in range(20):
+                    L.gemm_bf16_nt(A, Bw, L.EPI_BF16, out_bf16=o)
+                s.synchronize()
+                outs[i] = o
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert torch.equal(outs[0], outs[1]) and rel_err(outs[0], ref) < 1.5e-2
+    c0.close()
+    c1.close()
+
+
+def test_fedavg_allreduce_through_the_c_abi_single_rank(L):
+    """feddat_comm_* + feddat_fedavg_allreduce with a 1-rank RCCL communicator (all a one-GPU box can hold): run-time RCCL
+    binding, pre-scale in the reference's op order, all-reduce, write-back."""
+    comm = L.RcclComm(1, 0, lambda ident: ident)
+    g = torch.Generator().manual_seed(5)
+    flat = torch.randn(894528, generator=g).to(DEV)
+    want = (flat * 3.0 / 7.0).clone()
+    scratch = torch.empty_like(flat)
+    comm.fedavg_allreduce(flat, scratch, 3.0, 7.0)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want)
+    comm.close()

@@ -159,3 +159,19 @@ def test_g6_padded_images_and_questions(golden_dir):
     assert np.allclose(losses, g["losses"], rtol=2e-5, atol=1e-4), (losses, g["losses"])
     for k in [k[len("after2."):] for k in g if k.startswith("after2.")]:
         assert max_abs_diff_vs_golden(g, "after2." + k, P[k]) < TOL_W, k
+
+
+def test_g8_oracle_reproduces_reference_round_of_40_steps(golden_dir):
+    """G8: a realistic local round (12 layers, B=4, 384x384, 40 steps, schedule past warm-up) -- the oracle against the
+    reference's own run, on the weight UPDATES (they reach 2-3e-3): this pins the oracle at round length."""
+    from tests.golden_util import delta_vs_golden
+    g = load(golden_dir, "g8_round40.npz")
+    d = O.ViltDims(layers=12)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    init = {k: v.clone() for k, v in P.items()}
+    c = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=int(g["steps"]))
+    losses = [float(c.train_step(O.synthetic_batch(4, 384, 8000 + s))[0]) for s in range(int(g["steps"]))]
+    assert np.abs(np.array(losses) - g["losses"]).max() < 1e-3
+    for k in [k.split("::", 1)[1] for k in g if k.startswith("dsamp::")]:
+        mx, mean, ref_mean, dnorm = delta_vs_golden(g, k, P[k] - init[k])
+        assert mx < 3e-5 and mean < 0.01 * ref_mean, (k, mx, mean, ref_mean)
