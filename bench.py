@@ -124,6 +124,11 @@ def measure_gemms_in_step(L, eng, batches, steps=3):
         eng.train_step(batches[0], use_graph=False)        # untimed: eager path warm
         rec.clear()
         for i in range(steps):
+            # the host needs ~15 us per eager launch, the GPU less: without a plug the queue runs dry and every event pair
+            # would also time the host's launch latency.  A 25 ms spin kernel (no memory traffic, caches untouched) lets the
+            # whole step queue up behind it, so the events are processed back-to-back with the kernels they bracket.
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(0.025 * 2.4e9))
             eng.train_step(batches[i % len(batches)], use_graph=False)
         torch.cuda.synchronize()
     finally:
@@ -174,7 +179,7 @@ def cpu_baseline(params_cpu, batches_cpu, B, res, task, timed_steps=3):
     ncpu = os.cpu_count()
     small = {k: v[:8].clone() for k, v in batches_cpu[0].items()}
     sweep = {}
-    for nt in sorted({min(ncpu, n) for n in (16, 32, 64, 128)}):
+    for nt in sorted({min(ncpu, n) for n in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         c = O.DatClient({k: v.clone() for k, v in params_cpu.items()}, d, task, lr=1e-4, steps_per_epoch=50)
         c.train_step(small)

@@ -34,18 +34,27 @@ __device__ __forceinline__ bf16x8 load_x8(const float* p) {
 // output tiles 2q and 2q+1 (accumulator layout: 4 consecutive columns 16 ct + 4g), so the fp32 row values are kept in
 // registers (`keep`) and x is read from HBM once.  The weight operand uses the same permutation: `w` is the
 // slot-permuted bf16 copy written by adapter_pack ([48][768], position 32q + 8g + 4*half + j), one 16-byte load.
-template <int NA>
-__device__ __forceinline__ void down_proj(const float* __restrict__ xrow, const bf16* const* w, int lane, int ks0,
-                                          f32x4 (&z)[2][NT], f32x4 (&keep)[KS / 4][2]) {
-    const int g = lane >> 4, i16 = lane & 15;
+// All of a wave's HBM reads are issued up front (12 x 16-byte loads per lane = 12 KiB per wave in flight), ahead of any
+// weight load or MFMA: the row data is what comes from HBM, everything else from L2, and a shallow load window would
+// turn the kernel into a chain of HBM round trips.  The compiler fence keeps the loads from being sunk to their uses.
+__device__ __forceinline__ void load_rows(const float* __restrict__ xrow, int lane, int ks0, f32x4 (&keep)[KS / 4][2]) {
+    const int g = lane >> 4;
 #pragma unroll
     for (int k = 0; k < KS / 4; ++k) {
         const int q = ks0 + k;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 4 * g);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 16 + 4 * g);
-        keep[k][0] = x0;
-        keep[k][1] = x1;
-        const bf16x8 xf = cvt8(x0, x1);
+        keep[k][0] = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 4 * g);
+        keep[k][1] = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 16 + 4 * g);
+    }
+}
+#define FD_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+template <int NA>
+__device__ __forceinline__ void down_proj(const bf16* const* w, int lane, int ks0, f32x4 (&z)[2][NT],
+                                          const f32x4 (&keep)[KS / 4][2]) {
+#pragma unroll
+    for (int k = 0; k < KS / 4; ++k) {
+        const int q = ks0 + k;
+        const bf16x8 xf = cvt8(keep[k][0], keep[k][1]);
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -104,7 +113,7 @@ struct LnFuse {            // optional LayerNorm of the adapter output (the next
 template <int NA>
 __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __restrict__ out,
                                          const feddat_adapter_seg& sg, int row0, f32x4* part, const LnFuse& ln,
-                                         float* lnred) {
+                                         float* lnred, const float* lngb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int row = row0 + i16;
@@ -118,7 +127,9 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 xk[KS / 4][2];
-    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z, xk);
+    load_rows(xrow, lane, wave * (KS / 4), xk);
+    FD_COMPILER_FENCE();
+    down_proj<NA>(wd, lane, wave * (KS / 4), z, xk);
     ksplit_reduce<NA>(part, wave, lane, z);
 
     bf16x8 zb01[NA], zb2[NA];
@@ -133,7 +144,11 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
         zb01[a] = cvt8(z[a][0], z[a][1]);
         zb2[a] = pad8(z[a][2]);
     }
-    f32x4 oo[CT / 4];                          // this lane's 48 outputs of its token (kept only when LN is fused)
+    // Up-projection of this wave's 12 column tiles.  NO store is issued before the last load of the kernel: with a store
+    // in flight every s_waitcnt in front of an MFMA has to be vmcnt(0) (loads and stores share the counter and retire
+    // out of order with respect to each other), i.e. one full HBM write round trip per column tile -- that serial chain,
+    // not bandwidth, was 2/3 of this kernel's time.  All outputs stay in registers (48 floats per lane) until the end.
+    f32x4 oo[CT / 4];
 #pragma unroll
     for (int k = 0; k < CT / 4; ++k) {
         const int ct = wave * (CT / 4) + k;
@@ -150,10 +165,16 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += sc * (y[e] + bu4[e]);
         }
-        if (valid) *reinterpret_cast<f32x4*>(out + (size_t)row * H + c) = o;
         oo[k] = o;
     }
-    if (!ln.gamma) return;                     // uniform over the launch
+    float* orow = out + (size_t)row * H + wave * (CT / 4) * 16 + 4 * g;
+    if (!ln.gamma) {                            // uniform over the launch
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<f32x4*>(orow + k * 16) = oo[k];
+        }
+        return;
+    }
     // LayerNorm over the 768 outputs of each token: 48 per lane -> 4 lane groups (shuffles) -> 4 waves (LDS, fixed
     // order); two passes (mean, then centred second moment) like the stand-alone LN kernel
     float s1 = 0.f;
@@ -178,34 +199,47 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
     __syncthreads();
     const float var = ((lnred[64 + i16] + lnred[80 + i16]) + (lnred[96 + i16] + lnred[112 + i16])) * (1.0f / H);
     const float rstd = rsqrtf(var + ln.eps);
+    bf16x4 y16v[CT / 4];                        // gamma / beta come from LDS (staged at kernel start): no VMEM round trips
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) {
+        const int c = (wave * (CT / 4) + k) * 16 + 4 * g;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(lngb + c);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lngb + H + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (oo[k][e] - mean) * rstd * g4[e] + b4[e];
+        y16v[k] = cvt4(y);
+    }
     if (!valid) return;
+    bf16* yrow = ln.y16 + (size_t)row * H + wave * (CT / 4) * 16 + 4 * g;
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<f32x4*>(orow + k * 16) = oo[k];
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<bf16x4*>(yrow + k * 16) = y16v[k];
     if (wave == 0 && g == 0 && ln.stats) {
         ln.stats[2 * (size_t)row] = mean;
         ln.stats[2 * (size_t)row + 1] = rstd;
     }
-#pragma unroll
-    for (int k = 0; k < CT / 4; ++k) {
-        const int c = (wave * (CT / 4) + k) * 16 + 4 * g;
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln.gamma + c);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(ln.beta + c);
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (oo[k][e] - mean) * rstd * g4[e] + b4[e];
-        *reinterpret_cast<bf16x4*>(ln.y16 + (size_t)row * H + c) = cvt4(y);
-    }
 }
 
-__global__ __launch_bounds__(256) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           AdapterLaunch L, LnFuse ln) {
     __shared__ __attribute__((aligned(16))) f32x4 part[4 * 2 * NT * 64];
     __shared__ float lnred[128];
+    __shared__ __attribute__((aligned(16))) float lngb[2 * H];    // LN gamma | beta (visible after the k-split barrier)
+    if (ln.gamma) {
+        for (int i = threadIdx.x; i < H; i += 256) {
+            lngb[i] = ln.gamma[i];
+            lngb[H + i] = ln.beta[i];
+        }
+    }
     const int tile = blockIdx.x;
     const int s = tile < L.tiles0 ? 0 : 1;
     const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
     const int row0 = sg.row_begin + t * 16;
-    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, part, ln, lnred);
-    else fwd_body<1>(x, out, sg, row0, part, ln, lnred);
+    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, part, ln, lnred, lngb);
+    else fwd_body<1>(x, out, sg, row0, part, ln, lnred, lngb);
 }
 
 template <int NA>
@@ -233,13 +267,18 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
             gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     f32x4 xk[KS / 4][2], dyk[KS / 4][2];
-    down_proj<NA>(xrow, wd, lane, wave * (KS / 4), z, xk);
-    down_proj<NA>(dyrow, wuT, lane, wave * (KS / 4), gr, dyk);
+    load_rows(xrow, lane, wave * (KS / 4), xk);
+    load_rows(dyrow, lane, wave * (KS / 4), dyk);
+    FD_COMPILER_FENCE();
+    down_proj<NA>(wd, lane, wave * (KS / 4), z, xk);
+    down_proj<NA>(wuT, lane, wave * (KS / 4), gr, dyk);
     ksplit_reduce<NA>(part, wave, lane, z);
     ksplit_reduce<NA>(part + 4 * 2 * NT * 64, wave, lane, gr);
 
-    // 3. dz = scale * g * (z > 0); export z and dz of the trainable slot for the weight gradients
+    // 3. dz = scale * g * (z > 0); z and dz of the trainable slot are exported for the weight gradients -- at the END of
+    // the kernel: no store may precede a load (see fwd_body)
     bf16x8 dzb01[NA], dzb2[NA];
+    f32x4 z_keep = f32x4{0.f, 0.f, 0.f, 0.f}, dz_keep = z_keep;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         const float sc = sg.scale[a];
@@ -253,34 +292,45 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
                 dz[e] = zz[e] > 0.f ? sc * gr[a][nt][e] : 0.f;
             }
             gr[a][nt] = dz;
-            if (a == sg.train_slot && nt == wave && valid && z_out) {
-                *reinterpret_cast<f32x4*>(z_out + (size_t)row * R + nt * 16 + 4 * g) = zz;
-                *reinterpret_cast<f32x4*>(dz_out + (size_t)row * R + nt * 16 + 4 * g) = dz;
+            if (a == sg.train_slot && nt == wave) {
+                z_keep = zz;
+                dz_keep = dz;
             }
         }
         dzb01[a] = cvt8(gr[a][0], gr[a][1]);
         dzb2[a] = pad8(gr[a][2]);
     }
+    const bool export_z = sg.train_slot >= 0 && wave < NT && valid && z_out;
 
-    // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48]); this wave's quarter of the columns
-    if (!dx) return;
+    // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48]); this wave's quarter of the columns; results
+    // accumulate in place of the kept dy values, all stores after the last weight load
+    if (dx) {
 #pragma unroll
-    for (int k = 0; k < CT / 4; ++k) {
-        const int ct = wave * (CT / 4) + k;
-        const int c = ct * 16 + 4 * g;
-        f32x4 o = dyk[k >> 1][k & 1];          // dy[row][c .. c+3], kept from the Wu^T dy product
+        for (int k = 0; k < CT / 4; ++k) {
+            const int ct = wave * (CT / 4) + k;
+            f32x4 o = dyk[k >> 1][k & 1];          // dy[row][c .. c+3], kept from the Wu^T dy product
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            bf16x8 w01, w2;
-            load_w48((const bf16*)sg.wdT[a], ct, lane, w01, w2);
-            f32x4 y = mfma16x32(w01, dzb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
-            y = mfma16x32(w2, dzb2[a], y);
-            o = o + y;
+            for (int a = 0; a < NA; ++a) {
+                bf16x8 w01, w2;
+                load_w48((const bf16*)sg.wdT[a], ct, lane, w01, w2);
+                f32x4 y = mfma16x32(w01, dzb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
+                y = mfma16x32(w2, dzb2[a], y);
+                o = o + y;
+            }
+            dyk[k >> 1][k & 1] = o;
         }
-        if (valid) {
-            *reinterpret_cast<f32x4*>(dx + (size_t)row * H + c) = o;
-            if (dx16) *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * H + c) = cvt4(o);
-        }
+    }
+    if (export_z) {
+        *reinterpret_cast<f32x4*>(z_out + (size_t)row * R + wave * 16 + 4 * g) = z_keep;
+        *reinterpret_cast<f32x4*>(dz_out + (size_t)row * R + wave * 16 + 4 * g) = dz_keep;
+    }
+    if (!dx || !valid) return;
+    const size_t off = (size_t)row * H + wave * (CT / 4) * 16 + 4 * g;
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<f32x4*>(dx + off + k * 16) = dyk[k >> 1][k & 1];
+    if (dx16) {
+#pragma unroll
+        for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<bf16x4*>(dx16 + off + k * 16) = cvt4(dyk[k >> 1][k & 1]);
     }
 }
 

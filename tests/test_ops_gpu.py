@@ -640,7 +640,9 @@ def test_fedavg_allreduce_through_the_c_abi_single_rank(L):
     comm = L.RcclComm(1, 0, lambda ident: ident)
     g = torch.Generator().manual_seed(5)
     flat = torch.randn(894528, generator=g).to(DEV)
-    want = (flat * 3.0 / 7.0).clone()
+    # the reference's CPU arithmetic (main.py:62): (x * num) / total with a true fp32 division (torch's GPU scalar division
+    # multiplies by the reciprocal instead, so it is not the yardstick)
+    want = torch.from_numpy((flat.cpu().numpy() * np.float32(3.0)) / np.float32(7.0)).to(DEV)
     scratch = torch.empty_like(flat)
     comm.fedavg_allreduce(flat, scratch, 3.0, 7.0)
     torch.cuda.synchronize()
