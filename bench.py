@@ -102,49 +102,25 @@ def gemm_algorithmic_bytes(M, N, K, epi):
 
 
 def measure_gemms_in_step(L, eng, batches, steps=3):
-    """K1 durations INSIDE the train_step: the engine's own launches (eager replay of the same kernel sequence the graph
-    holds), each bracketed by HIP events on the launch stream, so every GEMM sees the caches as the preceding kernels of
-    the step left them -- not the MALL-warm state of back-to-back repeats.  Returns per-shape mean durations over
-    `steps` steps, FLOP/s over all K1 launches of a step, and the count-weighted mean algorithmic bytes per launch."""
-    orig = L.gemm_bf16_nt
-    rec = []
-
-    def timed(A, B, epi, **kw):
-        M = kw.get("M") or A.shape[0]
-        N, K = B.shape[0], A.shape[1]
-        if kw.get("skinny_workspace") is not None and M <= 64:
-            return orig(A, B, epi, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig(A, B, epi, **kw)
-        e1.record()
-        rec.append((M, N, K, epi, e0, e1))
-    L.gemm_bf16_nt = timed
-    try:
-        eng.train_step(batches[0], use_graph=False)        # untimed: eager path warm
-        rec.clear()
-        for i in range(steps):
-            # the host needs ~15 us per eager launch, the GPU less: without a plug the queue runs dry and every event pair
-            # would also time the host's launch latency.  A 25 ms spin kernel (no memory traffic, caches untouched) lets the
-            # whole step queue up behind it, so the events are processed back-to-back with the kernels they bracket.
-            torch.cuda.synchronize()
-            torch.cuda._sleep(int(0.025 * 2.4e9))
-            eng.train_step(batches[i % len(batches)], use_graph=False)
-        torch.cuda.synchronize()
-    finally:
-        L.gemm_bf16_nt = orig
-    agg = {}
-    for M, N, K, epi, e0, e1 in rec:
-        a = agg.setdefault((M, N, K, epi), [0, 0.0])
-        a[0] += 1
-        a[1] += e0.elapsed_time(e1) * 1e-3
-    tot_t = sum(t for _, t in agg.values()) / steps
-    tot_f = sum(2.0 * M * N * K * n for (M, N, K, _), (n, _) in agg.items()) / steps
-    launches = sum(n for n, _ in agg.values()) / steps
-    alg = sum(gemm_algorithmic_bytes(M, N, K, epi) * n for (M, N, K, epi), (n, _) in agg.items()) / steps / launches
-    rows = [dict(M=M, N=N, K=K, epi=epi, count=n // steps, us=round(t / n * 1e6, 2),
-                 tflops=round(2.0 * M * N * K * n / t / 1e12, 1)) for (M, N, K, epi), (n, t) in sorted(agg.items())]
-    return tot_f / tot_t, tot_t, rows, alg, launches
+    """K1 durations INSIDE the train_step (tools/step_breakdown.measure): the engine's own launches, an eager replay of the
+    kernel sequence the graph holds, EVERY op bracketed by HIP events on the launch stream and the whole step queued
+    behind a spin kernel, so each GEMM sees the caches as the preceding kernels of the step left them -- not the
+    MALL-warm state of back-to-back repeats; the cost of an empty event bracket is measured in the same queue and
+    subtracted.  Returns FLOP/s over all K1 launches of a step, their summed time, per-shape rows, the count-weighted mean
+    algorithmic bytes per launch and the launch count."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from step_breakdown import measure
+    agg, step_ms, empty_us = measure(eng, L, batches, steps, detail=True)
+    g = {k[1:5]: v for k, v in agg.items() if isinstance(k, tuple) and k[0] == "gemm" and not k[5]}
+    tot_t = sum(ms for _, ms in g.values()) * 1e-3
+    tot_f = sum(2.0 * M * N * K * n for (M, N, K, _), (n, _) in g.items())
+    launches = sum(n for n, _ in g.values())
+    alg = sum(gemm_algorithmic_bytes(M, N, K, epi) * n for (M, N, K, epi), (n, _) in g.items()) / launches
+    rows = [dict(M=M, N=N, K=K, epi=epi, count=n, us=round(ms / n * 1e3, 2),
+                 tflops=round(2.0 * M * N * K * n / (ms * 1e-3) / 1e12, 1)) for (M, N, K, epi), (n, ms) in sorted(g.items())]
+    other = {str(k): round(v[1], 4) for k, v in agg.items() if not (isinstance(k, tuple) and not k[5])}
+    return tot_f / tot_t, tot_t, rows, alg, launches, dict(eager_step_ms=round(step_ms, 3),
+                                                           empty_bracket_us=round(empty_us, 2), other_ops_ms_per_step=other)
 
 
 def profiled_traffic(kernel_substr="gemm_nt_v2_kernel"):
@@ -333,7 +309,7 @@ def main():
             # achieved = FLOPs of all K1 launches of a step / their summed in-step durations (HIP events around the
             # engine's own launches); the isolated figure (10 back-to-back launches per shape, operands MALL/L2-warm) is
             # reported beside it and is NOT what `frac` is.
-            ach, tsum, rows, alg_bytes, launches = measure_gemms_in_step(L, eng, batches)
+            ach, tsum, rows, alg_bytes, launches, in_step_info = measure_gemms_in_step(L, eng, batches)
             ach_iso, tsum_iso, rows_iso = measure_gemms(L, gemms)
             tr = profiled_traffic()
             out["roofline"] = {"kernel": "gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one "
@@ -347,7 +323,7 @@ def main():
                                "traffic_source": (tr["source"] + ": " + tr["note"]) if tr else None,
                                "launches_per_step": launches,
                                "gemm_ms_per_step": round(tsum * 1e3, 3), "gemm_ms_per_step_isolated": round(tsum_iso * 1e3, 3),
-                               "shapes": rows, "shapes_isolated": rows_iso}
+                               "shapes": rows, "shapes_isolated": rows_iso, "in_step": in_step_info}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline({k: v.float().cpu() for k, v in params.items()},
                                                [{k: v.cpu() for k, v in b.items()} for b in batches], B, res, task)

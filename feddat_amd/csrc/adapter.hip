@@ -2,19 +2,32 @@
 // Reference: src/modeling/models/adapter.py:124-163 (single: 125-131; gating: 133-146, get_agg_out 118-122),
 // called as adapter(h, h) from Adaptered_ViltOutput.forward (src/modeling/adaptered_output.py:77).
 //
-// One block (4 waves) owns 16 tokens.  The token rows stream straight from HBM into MFMA operand registers
-// (fp32 -> bf16 in flight), the [16 x 48] bottleneck never reaches HBM: the down-projection is
-// computed as Z^T[r, tok] so that its accumulator layout (lane: token = lane & 15, four consecutive r)
-// is already the operand layout of the up-projection (contraction slots are paired (g, j) <-> (g, j),
-// so the slot -> r permutation only has to be applied to the weight operand).  The up-projection is
-// computed as Y^T[c, tok]: every lane ends with 4 consecutive output columns of one token ->
-// 16-byte residual loads and stores.  Adapter weights (72 KiB per matrix, bf16) are read through L1/L2.
-// HBM-bound: 2 x T x 768 x 4 B algorithmic bytes per call.
+// One block (4 waves) owns 16 tokens; wave w owns features / output columns [192 w, 192 w + 192) of them.
+//   * HBM <-> registers is ROW-CONTIGUOUS: a wave moves its [16 x 192] fp32 slice with 12 x 16-byte accesses per lane in
+//     which consecutive lanes touch consecutive addresses (runs of 768 B).  The MFMA operand / accumulator layout wants
+//     lane & 15 = token, i.e. 16 different rows per 16-lane group -- loading or storing in THAT layout makes every
+//     wave instruction 64 separate 16-byte L1 accesses (measured: TCP_TOTAL_CACHE_ACCESSES 26-32 per VMEM instruction,
+//     the L1 tag pipeline busy for the whole kernel), so the slice is transposed through a per-wave LDS tile instead
+//     (800-byte rows: fragment reads conflict-free).
+//   * The [16 x 48] bottleneck never reaches HBM: the down-projection is computed as Z^T[r, tok] so that its
+//     accumulator layout (lane: token = lane & 15, four consecutive r) is already the operand layout of the
+//     up-projection; each wave contracts its quarter of the features, partials are summed through LDS in a fixed order.
+//   * The up-projection is computed as Y^T[c, tok]: every lane ends with 4 consecutive output columns of one token, the
+//     residual comes from the fragment registers kept from the down-projection (x is read from HBM once).
+//   * No store is issued before the last load: loads and stores share vmcnt and retire out of order with respect to
+//     each other, so a store in flight turns every later wait into vmcnt(0) = an HBM write round trip.
+// Adapter weights (72 KiB per matrix, bf16, fragment-major copies) are read through L1/L2.
+// HBM-bound: 2 x T x 768 x 4 B algorithmic bytes per forward call (+ T x 768 x 2 B with the fused LayerNorm).
 #include "common.hip.h"
 
 namespace {
 
 constexpr int H = 768, R = 48, NT = 3, KS = H / 32, CT = H / 16;
+constexpr int WCOLS = H / 4;                  // columns per wave
+constexpr int WCH = WCOLS / 4;                // 16-byte chunks per row of a wave's slice (48)
+constexpr int NLD = 16 * WCH / 64;            // row-contiguous accesses per lane and slice (12)
+constexpr int ROWF = 200;                     // padded LDS row (floats): fragment reads hit 64 distinct banks
+constexpr int STG_WAVE = 16 * ROWF;           // floats of LDS per wave (12.5 KiB)
 
 struct AdapterLaunch {
     feddat_adapter_seg seg[2];
@@ -22,32 +35,49 @@ struct AdapterLaunch {
     int tiles0;  // number of 16-token tiles of segment 0
 };
 
-__device__ __forceinline__ bf16x8 load_x8(const float* p) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
-    return cvt8(a, b);
-}
-
-// Z^T[a][nt] += W[a] (rows r) x X^T (cols tok), contraction over the wave's quarter of the 768 features
-// (k-steps ks0 .. ks0+5 of 32 features).  Contraction slots are permuted: in k-step q lane group g supplies features
-// 32q + 4g + (0..3) and 32q + 16 + 4g + (0..3) -- exactly the two float4 this lane needs again for the residual add of
-// output tiles 2q and 2q+1 (accumulator layout: 4 consecutive columns 16 ct + 4g), so the fp32 row values are kept in
-// registers (`keep`) and x is read from HBM once.  The weight operand uses the same permutation: `w` is the
-// slot-permuted bf16 copy written by adapter_pack ([48][768], position 32q + 8g + 4*half + j), one 16-byte load.
-// All of a wave's HBM reads are issued up front (12 x 16-byte loads per lane = 12 KiB per wave in flight), ahead of any
-// weight load or MFMA: the row data is what comes from HBM, everything else from L2, and a shallow load window would
-// turn the kernel into a chain of HBM round trips.  The compiler fence keeps the loads from being sunk to their uses.
-__device__ __forceinline__ void load_rows(const float* __restrict__ xrow, int lane, int ks0, f32x4 (&keep)[KS / 4][2]) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int k = 0; k < KS / 4; ++k) {
-        const int q = ks0 + k;
-        keep[k][0] = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 4 * g);
-        keep[k][1] = *reinterpret_cast<const f32x4*>(xrow + q * 32 + 16 + 4 * g);
-    }
-}
 #define FD_COMPILER_FENCE() asm volatile("" ::: "memory")
 
+// ---- row-contiguous slice <-> registers -------------------------------------------------------------------------
+// access j of lane l covers chunk f = 64 j + l of the slice in row-major chunk order: row f / 48, chunk f % 48
+__device__ __forceinline__ void slice_load(const float* __restrict__ src, int nvalid, int lane, f32x4 (&v)[NLD]) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+        const int rr = r < nvalid ? r : nvalid - 1;          // rows past the segment end re-read its last row
+        v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)rr * H + c * 4);
+    }
+}
+__device__ __forceinline__ void slice_to_lds(float* stg, int lane, const f32x4 (&v)[NLD]) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+        *reinterpret_cast<f32x4*>(stg + r * ROWF + c * 4) = v[j];
+    }
+}
+// MFMA operand fragments of the slice: in k-step k lane group g supplies features 32k + 4g + (0..3) and
+// 32k + 16 + 4g + (0..3) of token lane & 15 -- exactly the two float4 this lane needs again for the residual add of
+// output tiles 2k and 2k+1 (accumulator layout: 4 consecutive columns 16 ct + 4g).  The weight operand uses the same slot
+// permutation (adapter_pack).
+__device__ __forceinline__ void frags_from_lds(const float* stg, int lane, f32x4 (&keep)[KS / 4][2]) {
+    const float* p = stg + (lane & 15) * ROWF + 4 * (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < KS / 4; ++k) {
+        keep[k][0] = *reinterpret_cast<const f32x4*>(p + k * 32);
+        keep[k][1] = *reinterpret_cast<const f32x4*>(p + k * 32 + 16);
+    }
+}
+__device__ __forceinline__ void frags_to_lds(float* stg, int lane, const f32x4 (&keep)[KS / 4][2]) {
+    float* p = stg + (lane & 15) * ROWF + 4 * (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < KS / 4; ++k) {
+        *reinterpret_cast<f32x4*>(p + k * 32) = keep[k][0];
+        *reinterpret_cast<f32x4*>(p + k * 32 + 16) = keep[k][1];
+    }
+}
+
+// Z^T[a][nt] += W[a] (rows r) x X^T (cols tok), contraction over the wave's quarter of the 768 features (k-steps
+// ks0 .. ks0+5 of 32 features).  `w` is the slot-permuted fragment-major bf16 copy written by adapter_pack
+// ([48][768], position 32q + 8g + 4*half + j): one contiguous 1 KiB load per wave and MFMA.
 template <int NA>
 __device__ __forceinline__ void down_proj(const bf16* const* w, int lane, int ks0, f32x4 (&z)[2][NT],
                                           const f32x4 (&keep)[KS / 4][2]) {
@@ -80,28 +110,21 @@ __device__ __forceinline__ bf16x8 pad8(const f32x4 a) {
     return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], 0, 0, 0, 0};
 }
 
-// cross-wave sum of the K-split partial bottleneck tiles: part[w][slot][lane] (f32x4), slot = a * NT + nt
-template <int NA>
-__device__ __forceinline__ void ksplit_reduce(f32x4* part, int wave, int lane, f32x4 (&z)[2][NT]) {
+// K-split partial bottleneck tiles: wave w parks its partials at the start of its OWN staging region (its slice has
+// been consumed by then), slot s of NS at [s][lane] (f32x4); after the block barrier every wave sums the four regions
+// in a fixed order.
+template <int NS>
+__device__ __forceinline__ void ksplit_store(float* stg_all, int wave, int lane, int s, const f32x4 v) {
+    reinterpret_cast<f32x4*>(stg_all + wave * STG_WAVE)[s * 64 + lane] = v;
+}
+template <int NS>
+__device__ __forceinline__ f32x4 ksplit_sum(const float* stg_all, int lane, int s) {
+    f32x4 t = reinterpret_cast<const f32x4*>(stg_all)[s * 64 + lane];
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) part[(wave * (2 * NT) + a * NT + nt) * 64 + lane] = z[a][nt];
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x4 s = part[(0 * (2 * NT) + a * NT + nt) * 64 + lane];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) s = s + part[(w * (2 * NT) + a * NT + nt) * 64 + lane];
-            z[a][nt] = s;
-        }
+    for (int w = 1; w < 4; ++w) t = t + reinterpret_cast<const f32x4*>(stg_all + w * STG_WAVE)[s * 64 + lane];
+    return t;
 }
 
-// One block (4 waves) = 16 tokens.  Each wave contracts a quarter of the 768 features in the down-projection
-// (partials summed through LDS, fixed order) and then owns a quarter of the 768 output columns of the
-// up-projection: 4x shorter dependent chain per wave and 4x more waves in flight than one-wave-per-tile.
 struct LnFuse {            // optional LayerNorm of the adapter output (the next layer's layernorm_before), fused
     const float* gamma;    // null = off
     const float* beta;
@@ -112,48 +135,56 @@ struct LnFuse {            // optional LayerNorm of the adapter output (the next
 
 template <int NA>
 __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __restrict__ out,
-                                         const feddat_adapter_seg& sg, int row0, f32x4* part, const LnFuse& ln,
-                                         float* lnred, const float* lngb) {
+                                         const feddat_adapter_seg& sg, int row0, float* stg_all, const LnFuse& ln,
+                                         float* lnred) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
-    const int row = row0 + i16;
-    const bool valid = row < sg.row_end;
-    const float* xrow = x + (size_t)((valid ? row : sg.row_end - 1) + sg.x_row_delta) * H;
+    const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
+    float* stg = stg_all + wave * STG_WAVE;
 
+    // 1. this wave's [16 x 192] slice of x: HBM -> registers (row-contiguous) -> LDS -> MFMA fragments
+    f32x4 xk[KS / 4][2];
+    {
+        f32x4 v[NLD];
+        slice_load(x + (size_t)(row0 + sg.x_row_delta) * H + wave * WCOLS, nvalid, lane, v);
+        FD_COMPILER_FENCE();
+        slice_to_lds(stg, lane, v);
+    }
+    frags_from_lds(stg, lane, xk);
+
+    // 2. down-projection of this wave's feature quarter, K-split reduce
     const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
     f32x4 z[2][NT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 xk[KS / 4][2];
-    load_rows(xrow, lane, wave * (KS / 4), xk);
-    FD_COMPILER_FENCE();
     down_proj<NA>(wd, lane, wave * (KS / 4), z, xk);
-    ksplit_reduce<NA>(part, wave, lane, z);
-
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ksplit_store<NA * NT>(stg_all, wave, lane, a * NT + nt, z[a][nt]);
+    __syncthreads();
     bf16x8 zb01[NA], zb2[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 t = ksplit_sum<NA * NT>(stg_all, lane, a * NT + nt);
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(z[a][nt][e] + b4[e], 0.f);
+            for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(t[e] + b4[e], 0.f);
         }
         zb01[a] = cvt8(z[a][0], z[a][1]);
         zb2[a] = pad8(z[a][2]);
     }
-    // Up-projection of this wave's 12 column tiles.  NO store is issued before the last load of the kernel: with a store
-    // in flight every s_waitcnt in front of an MFMA has to be vmcnt(0) (loads and stores share the counter and retire
-    // out of order with respect to each other), i.e. one full HBM write round trip per column tile -- that serial chain,
-    // not bandwidth, was 2/3 of this kernel's time.  All outputs stay in registers (48 floats per lane) until the end.
-    f32x4 oo[CT / 4];
+
+    // 3. up-projection of this wave's 12 column tiles; the results replace the kept x fragments
 #pragma unroll
     for (int k = 0; k < CT / 4; ++k) {
         const int ct = wave * (CT / 4) + k;
         const int c = ct * 16 + 4 * g;
-        f32x4 o = xk[k >> 1][k & 1];           // x[row][c .. c+3], kept from the down-projection
+        f32x4 o = xk[k >> 1][k & 1];           // x[row][c .. c+3]
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             bf16x8 w01, w2;
@@ -165,97 +196,126 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += sc * (y[e] + bu4[e]);
         }
-        oo[k] = o;
+        xk[k >> 1][k & 1] = o;
     }
-    float* orow = out + (size_t)row * H + wave * (CT / 4) * 16 + 4 * g;
-    if (!ln.gamma) {                            // uniform over the launch
-        if (valid) {
+
+    // 4. LayerNorm statistics over the 768 outputs of each token: 48 per lane -> 4 lane groups (shuffles) -> 4 waves
+    // (LDS, fixed order); two passes (mean, then centred second moment) like the stand-alone LN kernel
+    float mean = 0.f, rstd = 0.f;
+    f32x4 gam[3], bet[3];                      // read-back path: lane l handles chunks (l + 16 j) % 48, j = 0..2
+    if (ln.gamma) {                            // uniform over the launch
 #pragma unroll
-            for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<f32x4*>(orow + k * 16) = oo[k];
+        for (int j = 0; j < 3; ++j) {
+            const int c = (lane + 16 * j) % WCH;
+            gam[j] = *reinterpret_cast<const f32x4*>(ln.gamma + wave * WCOLS + c * 4);
+            bet[j] = *reinterpret_cast<const f32x4*>(ln.beta + wave * WCOLS + c * 4);
+        }
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CT / 4; ++k) {
+            const f32x4 o = xk[k >> 1][k & 1];
+            s1 += (o[0] + o[1]) + (o[2] + o[3]);
+        }
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (g == 0) lnred[wave * 16 + i16] = s1;
+        __syncthreads();
+        mean = ((lnred[i16] + lnred[16 + i16]) + (lnred[32 + i16] + lnred[48 + i16])) * (1.0f / H);
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CT / 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = xk[k >> 1][k & 1][e] - mean;
+                s2 += d * d;
+            }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (g == 0) lnred[64 + wave * 16 + i16] = s2;
+        __syncthreads();
+        const float var = ((lnred[64 + i16] + lnred[80 + i16]) + (lnred[96 + i16] + lnred[112 + i16])) * (1.0f / H);
+        rstd = rsqrtf(var + ln.eps);
+        // per-wave copy of the row statistics for the read-back path (rows are indexed by f / 48 there, not by lane & 15)
+        if (g == 0) {
+            lnred[128 + wave * 32 + 2 * i16] = mean;
+            lnred[128 + wave * 32 + 2 * i16 + 1] = rstd;
+        }
+    } else {
+        __syncthreads();                       // every wave is done with the partials parked in the staging regions
+    }
+
+    // 5. outputs: fragment layout -> LDS -> row-contiguous stores (fp32 out; bf16 LN(out) computed on the way)
+    frags_to_lds(stg, lane, xk);
+    float* orow = out + (size_t)row0 * H + wave * WCOLS;
+    if (!ln.gamma) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * ROWF + c * 4);
+            if (r < nvalid) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v;
         }
         return;
     }
-    // LayerNorm over the 768 outputs of each token: 48 per lane -> 4 lane groups (shuffles) -> 4 waves (LDS, fixed
-    // order); two passes (mean, then centred second moment) like the stand-alone LN kernel
-    float s1 = 0.f;
+    bf16* yrow = ln.y16 + (size_t)row0 * H + wave * WCOLS;
+    f32x4 v[NLD];
 #pragma unroll
-    for (int k = 0; k < CT / 4; ++k) s1 += (oo[k][0] + oo[k][1]) + (oo[k][2] + oo[k][3]);
-    s1 += __shfl_xor(s1, 16, 64);
-    s1 += __shfl_xor(s1, 32, 64);
-    if (g == 0) lnred[wave * 16 + i16] = s1;
-    __syncthreads();
-    const float mean = ((lnred[i16] + lnred[16 + i16]) + (lnred[32 + i16] + lnred[48 + i16])) * (1.0f / H);
-    float s2 = 0.f;
+    for (int j = 0; j < NLD; ++j) {
+        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+        v[j] = *reinterpret_cast<const f32x4*>(stg + r * ROWF + c * 4);
+    }
 #pragma unroll
-    for (int k = 0; k < CT / 4; ++k)
+    for (int j = 0; j < NLD; ++j) {
+        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+        if (r < nvalid) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = oo[k][e] - mean;
-            s2 += d * d;
-        }
-    s2 += __shfl_xor(s2, 16, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (g == 0) lnred[64 + wave * 16 + i16] = s2;
-    __syncthreads();
-    const float var = ((lnred[64 + i16] + lnred[80 + i16]) + (lnred[96 + i16] + lnred[112 + i16])) * (1.0f / H);
-    const float rstd = rsqrtf(var + ln.eps);
-    bf16x4 y16v[CT / 4];                        // gamma / beta come from LDS (staged at kernel start): no VMEM round trips
-#pragma unroll
-    for (int k = 0; k < CT / 4; ++k) {
-        const int c = (wave * (CT / 4) + k) * 16 + 4 * g;
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(lngb + c);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lngb + H + c);
+    for (int j = 0; j < NLD; ++j) {
+        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+        const float m = lnred[128 + wave * 32 + 2 * r], rs = lnred[128 + wave * 32 + 2 * r + 1];
         f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (oo[k][e] - mean) * rstd * g4[e] + b4[e];
-        y16v[k] = cvt4(y);
+        for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - m) * rs * gam[j % 3][e] + bet[j % 3][e];
+        if (r < nvalid) *reinterpret_cast<bf16x4*>(yrow + (size_t)r * H + c * 4) = cvt4(y);
     }
-    if (!valid) return;
-    bf16* yrow = ln.y16 + (size_t)row * H + wave * (CT / 4) * 16 + 4 * g;
-#pragma unroll
-    for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<f32x4*>(orow + k * 16) = oo[k];
-#pragma unroll
-    for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<bf16x4*>(yrow + k * 16) = y16v[k];
-    if (wave == 0 && g == 0 && ln.stats) {
-        ln.stats[2 * (size_t)row] = mean;
-        ln.stats[2 * (size_t)row + 1] = rstd;
+    if (wave == 0 && g == 0 && i16 < nvalid && ln.stats) {
+        ln.stats[2 * (size_t)(row0 + i16)] = mean;
+        ln.stats[2 * (size_t)(row0 + i16) + 1] = rstd;
     }
 }
 
 __global__ __launch_bounds__(256, 3) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                          AdapterLaunch L, LnFuse ln) {
-    __shared__ __attribute__((aligned(16))) f32x4 part[4 * 2 * NT * 64];
-    __shared__ float lnred[128];
-    __shared__ __attribute__((aligned(16))) float lngb[2 * H];    // LN gamma | beta (visible after the k-split barrier)
-    if (ln.gamma) {
-        for (int i = threadIdx.x; i < H; i += 256) {
-            lngb[i] = ln.gamma[i];
-            lngb[H + i] = ln.beta[i];
-        }
-    }
+                                                             AdapterLaunch L, LnFuse ln) {
+    __shared__ __attribute__((aligned(16))) float stg[4 * STG_WAVE];
+    __shared__ float lnred[128 + 4 * 32];
     const int tile = blockIdx.x;
     const int s = tile < L.tiles0 ? 0 : 1;
     const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
     const int row0 = sg.row_begin + t * 16;
-    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, part, ln, lnred, lngb);
-    else fwd_body<1>(x, out, sg, row0, part, ln, lnred, lngb);
+    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, stg, ln, lnred);
+    else fwd_body<1>(x, out, sg, row0, stg, ln, lnred);
 }
 
 template <int NA>
 __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const float* __restrict__ dy,
                                          float* __restrict__ dx, bf16* __restrict__ dx16, float* __restrict__ z_out,
                                          float* __restrict__ dz_out, const feddat_adapter_seg& sg, int row0,
-                                         f32x4* part) {
+                                         float* stg_all) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
+    const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
+    const bool valid = i16 < nvalid;
     const int row = row0 + i16;
-    const bool valid = row < sg.row_end;
-    const size_t rclamp = (size_t)(valid ? row : sg.row_end - 1);
-    const float* xrow = x + (rclamp + sg.x_row_delta) * H;
-    const float* dyrow = dy + rclamp * H;
+    float* stg = stg_all + wave * STG_WAVE;
 
-    // 1. recompute z = relu(Wd x + bd);  2. g = Wu^T dy (weight operand = WuT [48, 768]); both K-split over the waves
+    // 1. the x slice leaves HBM first (row-contiguous, 12 x 16 B per lane in flight); the dy slice is requested as soon
+    // as x has been handed to LDS, so its latency hides behind the first down-projection
+    f32x4 vx[NLD], vd[NLD];
+    slice_load(x + (size_t)(row0 + sg.x_row_delta) * H + wave * WCOLS, nvalid, lane, vx);
+    FD_COMPILER_FENCE();
+
+    // 2. recompute z = relu(Wd x + bd);  3. g = Wu^T dy (weight operand = WuT [48, 768]); both K-split over the waves.
+    // The two slices take turns in the wave's staging region; the dy fragments are kept for the residual of dx.
     const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
     const bf16* wuT[2] = {(const bf16*)sg.wuT[0], (const bf16*)sg.wuT[NA - 1]};
     f32x4 z[2][NT], gr[2][NT];
@@ -266,17 +326,29 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
             z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    f32x4 xk[KS / 4][2], dyk[KS / 4][2];
-    load_rows(xrow, lane, wave * (KS / 4), xk);
-    load_rows(dyrow, lane, wave * (KS / 4), dyk);
-    FD_COMPILER_FENCE();
-    down_proj<NA>(wd, lane, wave * (KS / 4), z, xk);
+    f32x4 dyk[KS / 4][2];
+    {
+        f32x4 xk[KS / 4][2];
+        slice_to_lds(stg, lane, vx);
+        slice_load(dy + (size_t)row0 * H + wave * WCOLS, nvalid, lane, vd);
+        FD_COMPILER_FENCE();
+        frags_from_lds(stg, lane, xk);
+        down_proj<NA>(wd, lane, wave * (KS / 4), z, xk);
+    }
+    slice_to_lds(stg, lane, vd);
+    frags_from_lds(stg, lane, dyk);
     down_proj<NA>(wuT, lane, wave * (KS / 4), gr, dyk);
-    ksplit_reduce<NA>(part, wave, lane, z);
-    ksplit_reduce<NA>(part + 4 * 2 * NT * 64, wave, lane, gr);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            ksplit_store<2 * NA * NT>(stg_all, wave, lane, a * NT + nt, z[a][nt]);
+            ksplit_store<2 * NA * NT>(stg_all, wave, lane, NA * NT + a * NT + nt, gr[a][nt]);
+        }
+    __syncthreads();
 
-    // 3. dz = scale * g * (z > 0); z and dz of the trainable slot are exported for the weight gradients -- at the END of
-    // the kernel: no store may precede a load (see fwd_body)
+    // 4. dz = scale * g * (z > 0); z and dz of the trainable slot are exported for the weight gradients -- at the END of
+    // the kernel: no store may precede a load
     bf16x8 dzb01[NA], dzb2[NA];
     f32x4 z_keep = f32x4{0.f, 0.f, 0.f, 0.f}, dz_keep = z_keep;
 #pragma unroll
@@ -284,12 +356,14 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
         const float sc = sg.scale[a];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 zs = ksplit_sum<2 * NA * NT>(stg_all, lane, a * NT + nt);
+            const f32x4 gs = ksplit_sum<2 * NA * NT>(stg_all, lane, NA * NT + a * NT + nt);
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
             f32x4 zz, dz;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                zz[e] = fmaxf(z[a][nt][e] + b4[e], 0.f);
-                dz[e] = zz[e] > 0.f ? sc * gr[a][nt][e] : 0.f;
+                zz[e] = fmaxf(zs[e] + b4[e], 0.f);
+                dz[e] = zz[e] > 0.f ? sc * gs[e] : 0.f;
             }
             gr[a][nt] = dz;
             if (a == sg.train_slot && nt == wave) {
@@ -302,13 +376,13 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
     }
     const bool export_z = sg.train_slot >= 0 && wave < NT && valid && z_out;
 
-    // 4. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48]); this wave's quarter of the columns; results
-    // accumulate in place of the kept dy values, all stores after the last weight load
+    // 5. dx = dy + sum_a Wd[a]^T dz[a]   (weight operand = WdT [768, 48]); this wave's quarter of the columns; results
+    // accumulate in place of the kept dy fragments
     if (dx) {
 #pragma unroll
         for (int k = 0; k < CT / 4; ++k) {
             const int ct = wave * (CT / 4) + k;
-            f32x4 o = dyk[k >> 1][k & 1];          // dy[row][c .. c+3], kept from the Wu^T dy product
+            f32x4 o = dyk[k >> 1][k & 1];          // dy[row][c .. c+3]
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 bf16x8 w01, w2;
@@ -319,33 +393,49 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
             }
             dyk[k >> 1][k & 1] = o;
         }
+        __syncthreads();                           // every wave is done with the partials parked in the staging regions
+        frags_to_lds(stg, lane, dyk);
     }
     if (export_z) {
         *reinterpret_cast<f32x4*>(z_out + (size_t)row * R + wave * 16 + 4 * g) = z_keep;
         *reinterpret_cast<f32x4*>(dz_out + (size_t)row * R + wave * 16 + 4 * g) = dz_keep;
     }
-    if (!dx || !valid) return;
-    const size_t off = (size_t)row * H + wave * (CT / 4) * 16 + 4 * g;
+    if (!dx) return;
+    // 6. fragment layout -> LDS -> row-contiguous stores (fp32 dx and its bf16 copy for the next GEMM)
+    float* orow = dx + (size_t)row0 * H + wave * WCOLS;
+    f32x4 v[NLD];
 #pragma unroll
-    for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<f32x4*>(dx + off + k * 16) = dyk[k >> 1][k & 1];
+    for (int j = 0; j < NLD; ++j) {
+        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+        v[j] = *reinterpret_cast<const f32x4*>(stg + r * ROWF + c * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+        if (r < nvalid) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
+    }
     if (dx16) {
+        bf16* brow = dx16 + (size_t)row0 * H + wave * WCOLS;
 #pragma unroll
-        for (int k = 0; k < CT / 4; ++k) *reinterpret_cast<bf16x4*>(dx16 + off + k * 16) = cvt4(dyk[k >> 1][k & 1]);
+        for (int j = 0; j < NLD; ++j) {
+            const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
+            if (r < nvalid) *reinterpret_cast<bf16x4*>(brow + (size_t)r * H + c * 4) = cvt4(v[j]);
+        }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dx, bf16* __restrict__ dx16,
                                                           float* __restrict__ z_out, float* __restrict__ dz_out,
                                                           AdapterLaunch L) {
-    __shared__ __attribute__((aligned(16))) f32x4 part[2 * 4 * 2 * NT * 64];
+    __shared__ __attribute__((aligned(16))) float stg[4 * STG_WAVE];
     const int tile = blockIdx.x;
     const int s = tile < L.tiles0 ? 0 : 1;
     const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
     const int row0 = sg.row_begin + t * 16;
-    if (sg.n_adapters == 2) bwd_body<2>(x, dy, dx, dx16, z_out, dz_out, sg, row0, part);
-    else bwd_body<1>(x, dy, dx, dx16, z_out, dz_out, sg, row0, part);
+    if (sg.n_adapters == 2) bwd_body<2>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg);
+    else bwd_body<1>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg);
 }
 
 __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
@@ -413,6 +503,9 @@ int prep_launch(const feddat_adapter_seg* segs, int nseg, int T, AdapterLaunch& 
     return FEDDAT_OK;
 }
 
+// tools/ ablation: bits 16..23 of the debug flags = extra dynamic LDS in KiB (caps the resident blocks per CU)
+int dbg_extra_lds() { return ((fd_debug_flags() >> 16) & 0xff) * 1024; }
+
 }  // namespace
 
 extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int r, const feddat_adapter_seg* segs,
@@ -423,7 +516,7 @@ extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int
     const int rc = prep_launch(segs, nseg, T, L, tiles, false);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), 0, stream, x, out, L,
+    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, out, L,
                        LnFuse{nullptr, nullptr, nullptr, nullptr, 0.f});
     FD_LAUNCH_RET();
 }
@@ -437,7 +530,7 @@ extern "C" int feddat_adapter_fwd_ln(const float* x, float* out, int T, int Hd, 
     const int rc = prep_launch(segs, nseg, T, L, tiles, false);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), 0, stream, x, out, L,
+    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, out, L,
                        LnFuse{ln_gamma, ln_beta, (bf16*)y_bf16, stats, eps});
     FD_LAUNCH_RET();
 }
@@ -452,8 +545,8 @@ extern "C" int feddat_adapter_bwd(const float* x, const float* dy, float* dx, vo
     const int rc = prep_launch(segs, nseg, T, L, tiles, true);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    hipLaunchKernelGGL(adapter_bwd_kernel, dim3(tiles), dim3(256), 0, stream, x, dy, dx, (bf16*)dx_bf16, z_out, dz_out,
-                       L);
+    hipLaunchKernelGGL(adapter_bwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx, (bf16*)dx_bf16,
+                       z_out, dz_out, L);
     FD_LAUNCH_RET();
 }
 

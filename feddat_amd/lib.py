@@ -112,6 +112,12 @@ def load() -> C.CDLL:
     return lib
 
 
+def set_debug_flags(flags: int):
+    """tools/ ablations only (GEMM: 8 skip epilogue, 32/64 force tile height, bits 8..15 block cap; adapter kernels: bits
+    16..23 extra dynamic LDS in KiB)."""
+    _chk(load().feddat_set_debug_flags(int(flags)), "feddat_set_debug_flags")
+
+
 class Context:
     """feddat_ctx: explicit per-device handle (sets every kernel's launch attributes on that device at creation)."""
 
