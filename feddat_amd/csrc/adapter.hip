@@ -136,7 +136,7 @@ struct LnFuse {            // optional LayerNorm of the adapter output (the next
 template <int NA>
 __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __restrict__ out,
                                          const feddat_adapter_seg& sg, int row0, float* stg_all, const LnFuse& ln,
-                                         float* lnred) {
+                                         float* lnred, float* __restrict__ z_save) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
@@ -166,14 +166,17 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
         for (int nt = 0; nt < NT; ++nt) ksplit_store<NA * NT>(stg_all, wave, lane, a * NT + nt, z[a][nt]);
     __syncthreads();
     bf16x8 zb01[NA], zb2[NA];
+    f32x4 z_mine[NA];                           // waves 0..2 save r-tile `wave` of every adapter's bottleneck (backward)
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
+        z_mine[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f32x4 t = ksplit_sum<NA * NT>(stg_all, lane, a * NT + nt);
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(t[e] + b4[e], 0.f);
+            if (nt == wave) z_mine[a] = z[a][nt];
         }
         zb01[a] = cvt8(z[a][0], z[a][1]);
         zb2[a] = pad8(z[a][2]);
@@ -246,6 +249,11 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
 
     // 5. outputs: fragment layout -> LDS -> row-contiguous stores (fp32 out; bf16 LN(out) computed on the way)
     frags_to_lds(stg, lane, xk);
+    if (z_save && wave < NT && i16 < nvalid) {  // relu(Wd x + bd), fp32 [T][2][48]: the backward neither re-reads x nor
+#pragma unroll                                  // repeats the down-projection
+        for (int a = 0; a < NA; ++a)
+            *reinterpret_cast<f32x4*>(z_save + (size_t)(row0 + i16) * (2 * R) + a * R + wave * 16 + 4 * g) = z_mine[a];
+    }
     float* orow = out + (size_t)row0 * H + wave * WCOLS;
     if (!ln.gamma) {
 #pragma unroll
@@ -284,7 +292,7 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
 }
 
 __global__ __launch_bounds__(256, 3) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                             AdapterLaunch L, LnFuse ln) {
+                                                             AdapterLaunch L, LnFuse ln, float* __restrict__ z_save) {
     __shared__ __attribute__((aligned(16))) float stg[4 * STG_WAVE];
     __shared__ float lnred[128 + 4 * 32];
     const int tile = blockIdx.x;
@@ -292,15 +300,17 @@ __global__ __launch_bounds__(256, 3) void adapter_fwd_kernel(const float* __rest
     const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
     const int row0 = sg.row_begin + t * 16;
-    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, stg, ln, lnred);
-    else fwd_body<1>(x, out, sg, row0, stg, ln, lnred);
+    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, stg, ln, lnred, z_save);
+    else fwd_body<1>(x, out, sg, row0, stg, ln, lnred, z_save);
 }
 
-template <int NA>
+// ZS: the forward saved z = relu(Wd x + bd) for every adapter of the segment (feddat_adapter_fwd*'s z_save): the backward
+// then reads dy and 192-384 B of z per token instead of dy and x, and runs one K=768 product per adapter instead of two.
+template <int NA, bool ZS>
 __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const float* __restrict__ dy,
                                          float* __restrict__ dx, bf16* __restrict__ dx16, float* __restrict__ z_out,
                                          float* __restrict__ dz_out, const feddat_adapter_seg& sg, int row0,
-                                         float* stg_all) {
+                                         float* stg_all, const float* __restrict__ z_saved) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
@@ -308,14 +318,6 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
     const int row = row0 + i16;
     float* stg = stg_all + wave * STG_WAVE;
 
-    // 1. the x slice leaves HBM first (row-contiguous, 12 x 16 B per lane in flight); the dy slice is requested as soon
-    // as x has been handed to LDS, so its latency hides behind the first down-projection
-    f32x4 vx[NLD], vd[NLD];
-    slice_load(x + (size_t)(row0 + sg.x_row_delta) * H + wave * WCOLS, nvalid, lane, vx);
-    FD_COMPILER_FENCE();
-
-    // 2. recompute z = relu(Wd x + bd);  3. g = Wu^T dy (weight operand = WuT [48, 768]); both K-split over the waves.
-    // The two slices take turns in the wave's staging region; the dy fragments are kept for the residual of dx.
     const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
     const bf16* wuT[2] = {(const bf16*)sg.wuT[0], (const bf16*)sg.wuT[NA - 1]};
     f32x4 z[2][NT], gr[2][NT];
@@ -327,7 +329,23 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
             gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     f32x4 dyk[KS / 4][2];
-    {
+    f32x4 vd[NLD];
+    if (ZS) {
+        // 1. the dy slice leaves HBM row-contiguous (12 x 16 B per lane in flight), next to it the saved z of the 16 tokens
+        slice_load(dy + (size_t)row0 * H + wave * WCOLS, nvalid, lane, vd);
+        const float* zrow = z_saved + (size_t)(valid ? row : row0 + nvalid - 1) * (2 * R) + 4 * g;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) z[a][nt] = *reinterpret_cast<const f32x4*>(zrow + a * R + nt * 16);
+        FD_COMPILER_FENCE();
+    } else {
+        // 1. the x slice leaves HBM first (row-contiguous, 12 x 16 B per lane in flight); the dy slice is requested as
+        // soon as x has been handed to LDS, so its latency hides behind the first down-projection
+        f32x4 vx[NLD];
+        slice_load(x + (size_t)(row0 + sg.x_row_delta) * H + wave * WCOLS, nvalid, lane, vx);
+        FD_COMPILER_FENCE();
+        // 2. recompute z = relu(Wd x + bd) (K-split over the waves)
         f32x4 xk[KS / 4][2];
         slice_to_lds(stg, lane, vx);
         slice_load(dy + (size_t)row0 * H + wave * WCOLS, nvalid, lane, vd);
@@ -335,6 +353,7 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
         frags_from_lds(stg, lane, xk);
         down_proj<NA>(wd, lane, wave * (KS / 4), z, xk);
     }
+    // 3. g = Wu^T dy (weight operand = WuT [48, 768]), K-split over the waves; the dy fragments are kept for the residual
     slice_to_lds(stg, lane, vd);
     frags_from_lds(stg, lane, dyk);
     down_proj<NA>(wuT, lane, wave * (KS / 4), gr, dyk);
@@ -342,7 +361,7 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            ksplit_store<2 * NA * NT>(stg_all, wave, lane, a * NT + nt, z[a][nt]);
+            if (!ZS) ksplit_store<2 * NA * NT>(stg_all, wave, lane, a * NT + nt, z[a][nt]);
             ksplit_store<2 * NA * NT>(stg_all, wave, lane, NA * NT + a * NT + nt, gr[a][nt]);
         }
     __syncthreads();
@@ -356,15 +375,18 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
         const float sc = sg.scale[a];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 zs = ksplit_sum<2 * NA * NT>(stg_all, lane, a * NT + nt);
             const f32x4 gs = ksplit_sum<2 * NA * NT>(stg_all, lane, NA * NT + a * NT + nt);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
             f32x4 zz, dz;
+            if (ZS) {
+                zz = z[a][nt];
+            } else {
+                const f32x4 zs = ksplit_sum<2 * NA * NT>(stg_all, lane, a * NT + nt);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                zz[e] = fmaxf(zs[e] + b4[e], 0.f);
-                dz[e] = zz[e] > 0.f ? sc * gs[e] : 0.f;
+                for (int e = 0; e < 4; ++e) zz[e] = fmaxf(zs[e] + b4[e], 0.f);
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = zz[e] > 0.f ? sc * gs[e] : 0.f;
             gr[a][nt] = dz;
             if (a == sg.train_slot && nt == wave) {
                 z_keep = zz;
@@ -427,15 +449,20 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
 __global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dx, bf16* __restrict__ dx16,
                                                           float* __restrict__ z_out, float* __restrict__ dz_out,
-                                                          AdapterLaunch L) {
+                                                          AdapterLaunch L, const float* __restrict__ z_saved) {
     __shared__ __attribute__((aligned(16))) float stg[4 * STG_WAVE];
     const int tile = blockIdx.x;
     const int s = tile < L.tiles0 ? 0 : 1;
     const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
     const int row0 = sg.row_begin + t * 16;
-    if (sg.n_adapters == 2) bwd_body<2>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg);
-    else bwd_body<1>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg);
+    if (z_saved) {
+        if (sg.n_adapters == 2) bwd_body<2, true>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
+        else bwd_body<1, true>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
+    } else {
+        if (sg.n_adapters == 2) bwd_body<2, false>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
+        else bwd_body<1, false>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
+    }
 }
 
 __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
@@ -509,7 +536,7 @@ int dbg_extra_lds() { return ((fd_debug_flags() >> 16) & 0xff) * 1024; }
 }  // namespace
 
 extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int r, const feddat_adapter_seg* segs,
-                                  int nseg, hipStream_t stream) {
+                                  int nseg, float* z_save, hipStream_t stream) {
     FD_CHECK_ARG(x && out && T > 0 && Hd == H && r == R);
     AdapterLaunch L;
     int tiles;
@@ -517,13 +544,13 @@ extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
     hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, out, L,
-                       LnFuse{nullptr, nullptr, nullptr, nullptr, 0.f});
+                       LnFuse{nullptr, nullptr, nullptr, nullptr, 0.f}, z_save);
     FD_LAUNCH_RET();
 }
 
 extern "C" int feddat_adapter_fwd_ln(const float* x, float* out, int T, int Hd, int r, const feddat_adapter_seg* segs,
                                      int nseg, const float* ln_gamma, const float* ln_beta, float eps, void* y_bf16,
-                                     float* stats, hipStream_t stream) {
+                                     float* stats, float* z_save, hipStream_t stream) {
     FD_CHECK_ARG(x && out && T > 0 && Hd == H && r == R && ln_gamma && ln_beta && y_bf16);
     AdapterLaunch L;
     int tiles;
@@ -531,14 +558,14 @@ extern "C" int feddat_adapter_fwd_ln(const float* x, float* out, int T, int Hd, 
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
     hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, out, L,
-                       LnFuse{ln_gamma, ln_beta, (bf16*)y_bf16, stats, eps});
+                       LnFuse{ln_gamma, ln_beta, (bf16*)y_bf16, stats, eps}, z_save);
     FD_LAUNCH_RET();
 }
 
-extern "C" int feddat_adapter_bwd(const float* x, const float* dy, float* dx, void* dx_bf16, float* z_out,
-                                  float* dz_out, int T, int Hd, int r, const feddat_adapter_seg* segs, int nseg,
-                                  hipStream_t stream) {
-    FD_CHECK_ARG(x && dy && (dx || z_out) && T > 0 && Hd == H && r == R);
+extern "C" int feddat_adapter_bwd(const float* x, const float* z_saved, const float* dy, float* dx, void* dx_bf16,
+                                  float* z_out, float* dz_out, int T, int Hd, int r, const feddat_adapter_seg* segs,
+                                  int nseg, hipStream_t stream) {
+    FD_CHECK_ARG((x || z_saved) && dy && (dx || z_out) && T > 0 && Hd == H && r == R);
     FD_CHECK_ARG((z_out == nullptr) == (dz_out == nullptr));
     AdapterLaunch L;
     int tiles;
@@ -546,7 +573,7 @@ extern "C" int feddat_adapter_bwd(const float* x, const float* dy, float* dx, vo
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
     hipLaunchKernelGGL(adapter_bwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx, (bf16*)dx_bf16,
-                       z_out, dz_out, L);
+                       z_out, dz_out, L, z_saved);
     FD_LAUNCH_RET();
 }
 

@@ -211,6 +211,9 @@ class ViltDatEngine:
         self.dqkv = b16(R2, 3 * H)
         self.z = f32(R2, self.r)
         self.dz = f32(R2, self.r)
+        # relu(W_down h3 + b_down) of every adapter slot, saved by the adapter forward of each layer for its backward
+        # (fp32 [rows, 2, 48]: 384 B per token instead of re-reading the 3 KB row and repeating the down-projection)
+        self.zsave = [f32(R2, 2, self.r) for _ in range(layers - 1)] + [f32(nb2 if layers > 1 else R2, 2, self.r)]
         self.wpart = f32(L.adapter_wgrad_workspace_elems(2))
         self._segs_cache: Dict = {}
         self.graph = None
@@ -340,11 +343,11 @@ class ViltDatEngine:
             where that layer's LN kernel would have put them)."""
             nx, Wn = self.act[i + 1], self.layers[i + 1]
             L.adapter_fwd_ln(x, nx["h_in"], self._segs(i, first, False), R2, Wn["ln1g"], Wn["ln1b"], self.ln_eps,
-                             self.x16[:R2], nx["st1"])
+                             self.x16[:R2], nx["st1"], z_save=self.zsave[i])
         if self.nl > 1:
             adapter_then_ln1(l0["h3"], 0, True)
         else:
-            L.adapter_fwd(l0["h3"], self.h_out, self._segs(0, True, False), R2)
+            L.adapter_fwd(l0["h3"], self.h_out, self._segs(0, True, False), R2, z_save=self.zsave[0])
         for i in range(1, self.nl - 1):
             a = self.act[i]
             self._layer_body(i, a["h_in"], R2, 2 * B, a["qkv"], a["ctx"], a["lse"], a["h2"], a["h3"], st1=a["st1"],
@@ -394,7 +397,7 @@ class ViltDatEngine:
                        skinny_workspace=self._skinny_ws())
         L.gemm_bf16_nt(t["f16"], W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=t["h2"], out_f32=t["h3"],
                        skinny_workspace=self._skinny_ws())
-        L.adapter_fwd(t["h3"], t["h_out"], self._top_segs(False), nb)
+        L.adapter_fwd(t["h3"], t["h_out"], self._top_segs(False), nb, z_save=self.zsave[i])
 
     def _skinny_ws(self):
         """fp32 split-K partials of the top layer's 2B-row GEMMs (largest: 2B x 3072 x 768)."""
@@ -488,8 +491,8 @@ class ViltDatEngine:
         for i in range(top - 1, 0, -1):
             a, W = self.act[i], self.layers[i]
             # adapter: dh3 (fp32 in `oth`, bf16 copy in dh16), z/dz for the weight gradients
-            L.adapter_bwd(a["h3"], cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
-                          dz_out=self.dz)
+            L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
+                          dz_out=self.dz, z_saved=self.zsave[i])
             self._adapter_wgrads(i, a["h3"], 0, cur)
             # FFN2^T (+ gelu'), FFN1^T, LN2 backward (+ residual)
             L.gemm_bf16_nt(self.dh16, W["w2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
@@ -503,7 +506,8 @@ class ViltDatEngine:
             L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
             cur, oth = oth, cur
         # layer 0: weight gradients only (nothing trainable below)
-        L.adapter_bwd(self.l0["h3"], cur, None, self._segs(0, True, True), R2, z_out=self.z, dz_out=self.dz)
+        L.adapter_bwd(None, cur, None, self._segs(0, True, True), R2, z_out=self.z, dz_out=self.dz,
+                      z_saved=self.zsave[0])
         self._adapter_wgrads(0, self.l0["h3"], -R, cur)
 
     def _top_layer_bwd(self, cur, oth, mask):
@@ -512,8 +516,8 @@ class ViltDatEngine:
         i = self.nl - 1
         a, W, H, t = self.act[i], self.layers[i], self.H, self.top
         R2, nb, B = 2 * self.R, 2 * self.B, self.B
-        L.adapter_bwd(t["h3"], self.dcls, t["dh3"], self._top_segs(True), nb, dx_bf16=t["dh316"], z_out=self.z,
-                      dz_out=self.dz)
+        L.adapter_bwd(None, self.dcls, t["dh3"], self._top_segs(True), nb, dx_bf16=t["dh316"], z_out=self.z,
+                      dz_out=self.dz, z_saved=self.zsave[i])
         key = ("wg-top", self.opt_adapters)
         if key not in self._segs_cache:
             n = self.ad_layer_numel

@@ -49,9 +49,9 @@ _SIGS = {
     "feddat_layernorm_fwd": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp],
     "feddat_layernorm_bwd_dx": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp],
     "feddat_layernorm_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
-    "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
-    "feddat_adapter_fwd_ln": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp, f32, vp, vp, vp],
-    "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
+    "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp],
+    "feddat_adapter_fwd_ln": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp, f32, vp, vp, vp, vp],
+    "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_pack": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "feddat_adapter_pack_strided": [vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "feddat_adapter_wgrad_workspace_elems": [i32],
@@ -271,22 +271,27 @@ def make_segs(segs: Sequence[dict]):
     return arr
 
 
-def adapter_fwd(x, out, segs_arr, T, H=768, r=48):
-    _dev(x, out)
-    _chk(load().feddat_adapter_fwd(_p(x), _p(out), T, H, r, segs_arr, len(segs_arr), _stream()), "feddat_adapter_fwd")
+def adapter_fwd(x, out, segs_arr, T, H=768, r=48, z_save=None):
+    """z_save: optional fp32 [T, 2, r] receiving relu(W_down x + b_down) per adapter slot (for adapter_bwd's z_saved)."""
+    _dev(x, out, z_save)
+    _chk(load().feddat_adapter_fwd(_p(x), _p(out), T, H, r, segs_arr, len(segs_arr), _p(z_save), _stream()),
+         "feddat_adapter_fwd")
 
 
-def adapter_fwd_ln(x, out, segs_arr, T, gamma, beta, eps, y_bf16, stats=None, H=768, r=48):
+def adapter_fwd_ln(x, out, segs_arr, T, gamma, beta, eps, y_bf16, stats=None, H=768, r=48, z_save=None):
     """adapter_fwd + the next layer's LayerNorm of the output rows (bf16 y, [T,2] stats)."""
-    _dev(x, out, y_bf16)
+    _dev(x, out, y_bf16, z_save)
     _chk(load().feddat_adapter_fwd_ln(_p(x), _p(out), T, H, r, segs_arr, len(segs_arr), _p(gamma), _p(beta), eps,
-                                      _p(y_bf16), _p(stats), _stream()), "feddat_adapter_fwd_ln")
+                                      _p(y_bf16), _p(stats), _p(z_save), _stream()), "feddat_adapter_fwd_ln")
 
 
-def adapter_bwd(x, dy, dx, segs_arr, T, *, dx_bf16=None, z_out=None, dz_out=None, H=768, r=48):
-    _dev(x, dy, dx)
-    _chk(load().feddat_adapter_bwd(_p(x), _p(dy), _p(dx), _p(dx_bf16), _p(z_out), _p(dz_out), T, H, r, segs_arr,
-                                   len(segs_arr), _stream()), "feddat_adapter_bwd")
+def adapter_bwd(x, dy, dx, segs_arr, T, *, dx_bf16=None, z_out=None, dz_out=None, z_saved=None, H=768, r=48):
+    """x may be None when z_saved (the forward's z_save) is given: the backward then does not read x at all."""
+    _dev(x, dy, dx, z_saved)
+    if x is None and z_saved is None:
+        raise FeddatHipError("adapter_bwd needs x or z_saved")
+    _chk(load().feddat_adapter_bwd(_p(x), _p(z_saved), _p(dy), _p(dx), _p(dx_bf16), _p(z_out), _p(dz_out), T, H, r,
+                                   segs_arr, len(segs_arr), _stream()), "feddat_adapter_bwd")
 
 
 def make_wgrad_segs(segs: Sequence[dict]):

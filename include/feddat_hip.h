@@ -29,7 +29,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_EINVAL 1
 #define FEDDAT_ELAUNCH 2
 
-#define FEDDAT_ABI_VERSION 3   /* 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce */
+#define FEDDAT_ABI_VERSION 3   /* 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -125,21 +125,26 @@ typedef struct {
     const float* bu[2];  /* fp32 [H]    */
 } feddat_adapter_seg;
 
+/* z_save (optional, may be NULL): fp32 [T, 2, r]; row t receives relu(W_down[a] x + b_down[a]) of adapter slot a at
+ * z_save[t][a][:] (slot 1 untouched for single-adapter segments).  feddat_adapter_bwd takes it back as z_saved. */
 int feddat_adapter_fwd(const float* x, float* out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg,
-                       hipStream_t stream);
+                       float* z_save, hipStream_t stream);
 /* feddat_adapter_fwd that also applies the NEXT layer's layernorm_before to its output rows (HF ViltLayer,
  * layernorm_before -> attention): y_bf16[t] = LN(out[t]) * gamma + beta (bf16 [T,H]), stats[2t] = mean, stats[2t+1] = rstd.
  * Saves re-reading the fp32 output (feddat_layernorm_fwd on `out` gives the same result up to fp32 summation order). */
 int feddat_adapter_fwd_ln(const float* x, float* out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg,
                           const float* ln_gamma, const float* ln_beta, float eps, void* y_bf16, float* stats,
-                          hipStream_t stream);
+                          float* z_save, hipStream_t stream);
 /* backward: dx = dy + sum_a W_down[a]^T (relu' .* (scale[a] * W_up[a]^T dy)); optional bf16 copy of dx;
  * dx may be NULL (only z/dz are produced: nothing trainable lies below the first adapter).
+ * The bottleneck activations come either from z_saved (what the forward wrote into z_save; x may then be NULL and is
+ * not read: 3 KB less HBM traffic per token and one K = 768 product less per adapter) or, with z_saved == NULL, are
+ * recomputed from x.
  * For the segment's train_slot the kernel also writes z = relu(W_down x + b_down) and dz = scale * relu' .* (W_up^T dy)
  * (fp32 [T,r] each, rows of that segment) that feddat_sgemm_f32 turns into dW_up = scale * dy^T z,
  * db_up = scale * sum_t dy, dW_down = dz^T x, db_down = sum_t dz. */
-int feddat_adapter_bwd(const float* x, const float* dy, float* dx, void* dx_bf16, float* z_out, float* dz_out, int T,
-                       int H, int r, const feddat_adapter_seg* segs, int nseg, hipStream_t stream);
+int feddat_adapter_bwd(const float* x, const float* z_saved, const float* dy, float* dx, void* dx_bf16, float* z_out,
+                       float* dz_out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg, hipStream_t stream);
 /* Weight gradients of the trainable adapter of up to two row segments, from the z/dz written by
  * feddat_adapter_bwd: grad = flat fp32 [wd (r x H) | bd (r) | wu (H x r) | bu (H)] (the state-dict order of one
  * layer's adapter), fully overwritten.  x, dy: fp32 [rows, H] (row stride H); z, dz: fp32 [rows, r].

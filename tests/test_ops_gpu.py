@@ -302,6 +302,20 @@ def test_adapter_full_size_and_ragged_rows(L):
         dict(row_begin=h, row_end=T, train_slot=0, adapters=[dict(ads[1], scale=1.0)]),
     ])
     L.adapter_bwd(x, dy, dx, segs_b, T, z_out=z, dz_out=dz)
+    # the engine's path: the forward saves z = relu(Wd x + bd) of every slot, the backward takes it back and does not read
+    # x -- same arithmetic in the same order, so every output is bit-identical with the recompute path
+    zs = torch.full((T, 2, 48), float("nan"), device=DEV)
+    out2 = torch.empty_like(x)
+    L.adapter_fwd(x, out2, segs_b, T, z_save=zs)
+    assert torch.equal(out2, out)
+    dx2, z2, dz2 = torch.empty_like(x), torch.empty(T, 48, device=DEV), torch.empty(T, 48, device=DEV)
+    dx16a = torch.empty(T, 768, dtype=torch.bfloat16, device=DEV)
+    L.adapter_bwd(None, dy, dx2, segs_b, T, dx_bf16=dx16a, z_out=z2, dz_out=dz2, z_saved=zs)
+    assert torch.equal(dx2, dx) and torch.equal(z2, z) and torch.equal(dz2, dz)
+    assert torch.equal(zs[:h, 0], z[:h]) and torch.equal(zs[h:, 0], z[h:]) and not torch.isnan(zs[:h, 1]).any()
+    assert torch.equal(dx16a, dx2.to(torch.bfloat16))
+    with pytest.raises(L.FeddatHipError):
+        L.adapter_bwd(None, dy, dx2, segs_b, T)
     n = 48 * 768 + 48 + 768 * 48 + 768
     grads = torch.full((2, n), float("nan"), device=DEV)
     part = torch.empty(L.adapter_wgrad_workspace_elems(2), device=DEV)

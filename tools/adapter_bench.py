@@ -20,7 +20,7 @@ x = torch.randn(T, 768, device=dev); dy = torch.randn(T, 768, device=dev)
 out = torch.empty_like(x); dx = torch.empty_like(x); dx16 = torch.empty(T, 768, dtype=torch.bfloat16, device=dev)
 y16 = torch.empty(T, 768, dtype=torch.bfloat16, device=dev); st = torch.empty(T, 2, device=dev)
 gam = torch.ones(768, device=dev); bet = torch.zeros(768, device=dev)
-z = torch.empty(T, 48, device=dev); dz = torch.empty(T, 48, device=dev)
+z = torch.empty(T, 48, device=dev); dz = torch.empty(T, 48, device=dev); zs = torch.zeros(T, 2, 48, device=dev)
 segs = [dict(row_begin=0, row_end=R, adapters=[dict(a0, scale=0.5), dict(a2, scale=0.5)], train_slot=0),
         dict(row_begin=R, row_end=T, adapters=[dict(a1, scale=1.0)], train_slot=0)]
 sa = L.make_segs(segs)
@@ -46,9 +46,10 @@ def ctx(fn, pre, n=8):
 def gemm_pre():
     for _ in range(3): L.gemm_bf16_nt(A, Bw, 1, bias=bias, resid=res, out_f32=o32)
 ops = {
-    "fwd_ln": (lambda xx: L.adapter_fwd_ln(xx, out, sa, T, gam, bet, 1e-12, y16, st), (2 * 4 + 2) * T * 768),
+    "fwd_ln": (lambda xx: L.adapter_fwd_ln(xx, out, sa, T, gam, bet, 1e-12, y16, st, z_save=zs), (2 * 4 + 2) * T * 768),
     "fwd": (lambda xx: L.adapter_fwd(xx, out, sa, T), 2 * 4 * T * 768),
     "bwd": (lambda xx: L.adapter_bwd(xx, dy, dx, sa, T, dx_bf16=dx16, z_out=z, dz_out=dz), (3 * 4 + 2) * T * 768),
+    "bwd_zs": (lambda xx: L.adapter_bwd(None, xx, dx, sa, T, dx_bf16=dx16, z_out=z, dz_out=dz, z_saved=zs), (2 * 4 + 2) * T * 768),
 }
 if os.environ.get("QUICK"):       # a handful of dispatches per op, for counter collection
     for name, (fn, nbytes) in ops.items():
