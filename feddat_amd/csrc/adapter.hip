@@ -166,17 +166,19 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
         for (int nt = 0; nt < NT; ++nt) ksplit_store<NA * NT>(stg_all, wave, lane, a * NT + nt, z[a][nt]);
     __syncthreads();
     bf16x8 zb01[NA], zb2[NA];
-    f32x4 z_mine[NA];                           // waves 0..2 save r-tile `wave` of every adapter's bottleneck (backward)
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        z_mine[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f32x4 t = ksplit_sum<NA * NT>(stg_all, lane, a * NT + nt);
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(t[e] + b4[e], 0.f);
-            if (nt == wave) z_mine[a] = z[a][nt];
+            // relu(Wd x + bd), fp32 [T][2][48], saved for the backward (which then neither re-reads x nor repeats the
+            // down-projection).  Wave nt stores r-tile nt right here: the one early store of the kernel costs the later
+            // weight waits one L2 write acknowledgement, keeping 6 tiles alive to the end cost spills
+            if (z_save && nt == wave && i16 < nvalid)
+                *reinterpret_cast<f32x4*>(z_save + (size_t)(row0 + i16) * (2 * R) + a * R + nt * 16 + 4 * g) = z[a][nt];
         }
         zb01[a] = cvt8(z[a][0], z[a][1]);
         zb2[a] = pad8(z[a][2]);
@@ -249,11 +251,6 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __r
 
     // 5. outputs: fragment layout -> LDS -> row-contiguous stores (fp32 out; bf16 LN(out) computed on the way)
     frags_to_lds(stg, lane, xk);
-    if (z_save && wave < NT && i16 < nvalid) {  // relu(Wd x + bd), fp32 [T][2][48]: the backward neither re-reads x nor
-#pragma unroll                                  // repeats the down-projection
-        for (int a = 0; a < NA; ++a)
-            *reinterpret_cast<f32x4*>(z_save + (size_t)(row0 + i16) * (2 * R) + a * R + wave * 16 + 4 * g) = z_mine[a];
-    }
     float* orow = out + (size_t)row0 * H + wave * WCOLS;
     if (!ln.gamma) {
 #pragma unroll
@@ -446,6 +443,7 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
     }
 }
 
+template <bool ZS>
 __global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dx, bf16* __restrict__ dx16,
                                                           float* __restrict__ z_out, float* __restrict__ dz_out,
@@ -456,13 +454,8 @@ __global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __rest
     const int t = s ? tile - L.tiles0 : tile;
     const feddat_adapter_seg& sg = L.seg[s];
     const int row0 = sg.row_begin + t * 16;
-    if (z_saved) {
-        if (sg.n_adapters == 2) bwd_body<2, true>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
-        else bwd_body<1, true>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
-    } else {
-        if (sg.n_adapters == 2) bwd_body<2, false>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
-        else bwd_body<1, false>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
-    }
+    if (sg.n_adapters == 2) bwd_body<2, ZS>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
+    else bwd_body<1, ZS>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
 }
 
 __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
@@ -572,8 +565,12 @@ extern "C" int feddat_adapter_bwd(const float* x, const float* z_saved, const fl
     const int rc = prep_launch(segs, nseg, T, L, tiles, true);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    hipLaunchKernelGGL(adapter_bwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx, (bf16*)dx_bf16,
-                       z_out, dz_out, L, z_saved);
+    if (z_saved)
+        hipLaunchKernelGGL(adapter_bwd_kernel<true>, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx,
+                           (bf16*)dx_bf16, z_out, dz_out, L, z_saved);
+    else
+        hipLaunchKernelGGL(adapter_bwd_kernel<false>, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx,
+                           (bf16*)dx_bf16, z_out, dz_out, L, z_saved);
     FD_LAUNCH_RET();
 }
 

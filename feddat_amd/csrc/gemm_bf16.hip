@@ -269,6 +269,77 @@ __device__ __forceinline__ void v2_piece_ptrs(const GemmArgs& g, int m0, int m_l
     }
 }
 
+// bf16-output epilogues (plain, GELU + u, . gelu'(aux)) of one wave tile ([16 WM] x 96): every global access is 16 bytes
+// per lane.  All arithmetic happens in the accumulator layout (bias, GELU); a [16 rows][96 cols] slab goes to the wave's
+// LDS buffer as bf16 and comes back as 192-byte row runs (12 lanes x 8 bf16), i.e. 3 x global_store_dwordx4 per slab
+// instead of 6 x dwordx2 (the 8-byte form was store-issue-bound at ~9 B/clk/CU: 9.5 us of every 27 us FFN1 tile).
+// The aux operand of MUL_DGELU takes the opposite way: 16-byte row-contiguous loads -> LDS -> accumulator layout.
+constexpr int V2_EPI_LD16 = 208;              // bytes per staged bf16 row (96 x 2 + 16 pad)
+template <int EPI, int WM>
+__device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)[WM][6], char* stg, int mbase, int nbase,
+                                                 int m_end, int lane) {
+    asm volatile("" : "+v"(lane));
+    const int frow = lane & 15, fg = lane >> 4;
+    f32x4 bias4[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        bias4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nbase + j * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    int srow[3], sc8[3];                       // row-contiguous slots of this lane: (row, 8-column group) = divmod(64 p + lane, 12)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int idx = p * 64 + lane;
+        srow[p] = idx / 12;
+        sc8[p] = idx - srow[p] * 12;
+    }
+    bf16x8 ux[WM][3];
+    auto aux_load = [&](int i) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned mc = (unsigned)min(mbase + i * 16 + srow[p], m_end - 1);
+            const unsigned off = (mc * (unsigned)g.ldaux + (unsigned)(nbase + sc8[p] * 8)) * 2u;
+            ux[i][p] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(g.aux) + off);
+        }
+    };
+    if (EPI == FEDDAT_EPI_MUL_DGELU) {         // the whole wave tile's aux up front: 3 WM loads per lane in flight
+#pragma unroll
+        for (int i = 0; i < WM; ++i) aux_load(i);
+    }
+    char* wr = stg + frow * V2_EPI_LD16 + fg * 8;          // accumulator-layout position: row frow, cols 16 j + 4 fg
+    auto put = [&](bf16* dst, int ld, int i, const f32x4 (&val)[6]) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<bf16x4*>(wr + j * 32) = cvt4(val[j]);
+        bf16x8 v[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) v[p] = *reinterpret_cast<const bf16x8*>(stg + srow[p] * V2_EPI_LD16 + sc8[p] * 16);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int m = mbase + i * 16 + srow[p];
+            if (m < m_end) *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        f32x4 val[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) val[j] = acc[i][j] + bias4[j];
+        if (EPI == FEDDAT_EPI_MUL_DGELU) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(stg + srow[p] * V2_EPI_LD16 + sc8[p] * 16) = ux[i][p];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const bf16x4 u = *reinterpret_cast<const bf16x4*>(wr + j * 32);
+                val[j] = val[j] * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
+            }
+        }
+        if (EPI == FEDDAT_EPI_GELU) {
+            if (g.out2_bf16) put(g.out2_bf16, g.ldo2, i, val);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) val[j] = gelu4_pk(val[j]);
+        }
+        put(g.out_bf16, g.ldo16, i, val);
+    }
+}
+
 // Epilogue of one wave tile (48 x 96) through its private LDS staging buffer.  The accumulators (+ bias, added in
 // the accumulator layout from registers) go down as [16 rows][48 cols] fp32 chunks and come back row-contiguous
 // (192-byte runs per row); the residual / aux operands of chunk c+1 are requested before chunk c is stored, so the
@@ -442,7 +513,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     int pm0 = 0, pn0 = 0, pml = 0;
     auto run_epilogue = [&](int em0, int en0, int eml) {
         const int mb = em0 + wm * (16 * WM), nb = en0 + wn * 96, me = eml + 1;
-        if (!(a.dbg & 8)) v2_epilogue<EPI, WM>(g, acc, stg, mb, nb, me, lane);
+        if (!(a.dbg & 8)) {
+            if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU)
+                v2_epilogue_bf16<EPI, WM>(g, acc, stg, mb, nb, me, lane);
+            else
+                v2_epilogue<EPI, WM>(g, acc, stg, mb, nb, me, lane);
+        }
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -726,6 +802,18 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             break;
         case FEDDAT_EPI_F32: FD_CHECK_ARG(out_f32 && ldo32 % 4 == 0); break;
         default: return FEDDAT_EINVAL;
+    }
+    if (use_v2) {      // 16-byte bf16 stores / aux loads of the persistent kernel's epilogue
+        if (epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU)
+            FD_CHECK_ARG(ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
+        if (epi == FEDDAT_EPI_GELU && out2_bf16) FD_CHECK_ARG(ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0);
+        if (epi == FEDDAT_EPI_MUL_DGELU) FD_CHECK_ARG(ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0);
+    }
+    if (use_v2) {      // 16-byte bf16 stores / aux loads of the persistent kernel's epilogue
+        if (epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU)
+            FD_CHECK_ARG(ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
+        if (epi == FEDDAT_EPI_GELU && out2_bf16) FD_CHECK_ARG(ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0);
+        if (epi == FEDDAT_EPI_MUL_DGELU) FD_CHECK_ARG(ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0);
     }
     GemmArgs g;
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.bias = bias; g.resid = resid; g.aux = (const bf16*)aux;

@@ -1,0 +1,26 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from feddat_amd import lib as L
+dev = "cuda"
+def run(M, N, K, epi, iters=20):
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+    kw = {}
+    if epi in (0, 2, 3): kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    if epi == 2: kw["out2_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    if epi == 3: kw["aux"] = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    if epi == 1: kw["resid"] = torch.randn(M, N, device=dev); kw["out_f32"] = torch.empty(M, N, device=dev)
+    if epi != 3: kw["bias"] = torch.randn(N, device=dev)
+    for _ in range(3): L.gemm_bf16_nt(A, B, epi, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): L.gemm_bf16_nt(A, B, epi, **kw)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+for (M, N, K, epi) in [(11840, 3072, 768, 2), (11840, 3072, 768, 3), (11840, 768, 3072, 1), (11840, 2304, 768, 0), (11840, 768, 768, 1), (11840, 768, 768, 0)]:
+    res = []
+    for d in (0, 1, 2, 3, 4):
+        L.set_debug_flags(d << 24)
+        res.append(round(run(M, N, K, epi), 1))
+    L.set_debug_flags(0)
+    print((M, N, K, epi), "delay units 0..4 (x3.4us):", res, flush=True)
