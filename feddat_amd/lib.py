@@ -69,6 +69,9 @@ _SIGS = {
     "feddat_vilt_image_workspace_bytes": [vp, vp, vp, vp, i32],
     "feddat_vilt_image_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i64, vp],
     "feddat_pos_embed_resize": [vp, vp, i32, i32, i32, i32, vp],
+    "feddat_wordpiece_table_entries": [i32],
+    "feddat_wordpiece_table_build": [vp, vp, i32, vp, i64],
+    "feddat_wordpiece_encode": [vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "feddat_cvt_f32_bf16": [vp, vp, i64, vp],
     "feddat_transpose_f32_bf16": [vp, vp, i32, i32, vp],
     "feddat_tanh_fwd": [vp, i64, vp],
@@ -103,7 +106,7 @@ def load() -> C.CDLL:
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes")) else i32
+        fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes", "_table_entries")) else i32
     if lib.feddat_abi_version() != 3:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
     if os.environ.get("FEDDAT_GEMM_DEBUG"):       # tools/ ablations: the env var is read HERE, never by the library

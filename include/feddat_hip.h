@@ -255,6 +255,26 @@ int feddat_vilt_image_preprocess(const uint8_t* images, const long* offsets, con
                                  long* pixel_mask, void* workspace, long workspace_bytes, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input pipeline, text half: BERT WordPiece tokenisation as the reference obtains it from
+ * ViltProcessor(text=..., padding=True, truncation=True, max_length=40) (src/modeling/vilt.py:98) and
+ * BertTokenizer(..., truncation=True, max_length=25) (src/modeling/albef.py:56-57), once per batch on the device.
+ * Vocabulary: feddat_wordpiece_table_build (HOST function, HOST pointers) turns the vocab.txt tokens -- blob of bytes,
+ * token i at [offsets[i], offsets[i+1]) -- into an open-addressing table of feddat_wordpiece_table_entries(n) entries of 16
+ * bytes, which the caller uploads.  feddat_wordpiece_encode: texts = device blob of UTF-8 bytes, text t at
+ * [offsets[t], offsets[t+1]) (device int64 offsets); writes int64 [n_texts, max_len] input_ids ([CLS] pieces[:max_len-2]
+ * [SEP], padded with pad_id) and attention_mask, and out_len[t] = number of real tokens, or -1 for a text the kernel
+ * refuses (raw control characters, more than 2048 bytes): the caller normalises such texts on the host first.
+ * The kernel lower-cases ASCII, folds ASCII whitespace, splits ASCII punctuation, and treats UTF-8 multi-byte sequences as
+ * word characters (cut only at character boundaries); accent stripping / CJK and non-ASCII punctuation spacing /
+ * non-ASCII lower-casing (BertNormalizer) are the caller's job for non-ASCII texts (feddat_amd/tokenization.py).
+ * ------------------------------------------------------------------------------------------- */
+long feddat_wordpiece_table_entries(int n_vocab);
+int feddat_wordpiece_table_build(const char* blob, const long* offsets, int n_vocab, void* table_host, long entries);
+int feddat_wordpiece_encode(const void* text, const long* offsets, int n_texts, const void* table, long entries,
+                            int unk_id, int cls_id, int sep_id, int pad_id, int max_len, long* out_ids, long* out_mask,
+                            int* out_len, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * misc element-wise helpers
  * ------------------------------------------------------------------------------------------- */
 int feddat_cvt_f32_bf16(const float* in, void* out_bf16, long n, hipStream_t stream);
