@@ -1,0 +1,363 @@
+// K2b: general fused attention (any S_q, S_kv; separate Q / K / V operands; key-padding mask; causal), forward and
+// backward -- the ALBEF path: ViT-B/16 self-attention over 577 tokens (src/modeling/models/vit.py:60-76), BERT self- and
+// cross-attention of the text encoder / decoder (src/modeling/models/xbert.py BertSelfAttention: S_q <= 40,
+// S_kv = 577 image tokens or <= 40 text tokens; decoder causal).  The ViLT kernels (attention.hip) keep a whole head in
+// LDS and stop at S = 320; here K / V (forward, dQ) or Q / dO (dK, dV) stream through LDS in 64-row chunks with an
+// online softmax, so S is unbounded.  head_dim = 64, scores scaled by 1/8.
+//
+// One workgroup (4 waves) = one (sample, head, 64-row block); wave w owns rows 16 w .. 16 w + 15 of the block.  All
+// HBM accesses are row-contiguous 16-byte pieces (operands are staged through LDS cooperatively, results leave through
+// LDS): the MFMA lane layout (lane & 15 = row) would make every VMEM instruction 64 separate L1 accesses.
+// Operand plumbing as in attention.hip: score tiles are produced in the orientation whose accumulator layout is the
+// operand layout of the next product.
+#include "common.hip.h"
+
+namespace {
+
+constexpr int D = 64;
+constexpr int ROWB = D * 2;            // bytes per LDS row
+constexpr int BLK = 64;                // rows per block and per streamed chunk
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SC = 0.125f * LOG2E;   // scores in the log2 domain
+
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ bf16x8 row_frag(const char* m, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(m + sw_off(row, chunk));
+}
+__device__ __forceinline__ bf16x4 tr_frag(const char* m, int r0, int c0, int lane) {
+    const int i = lane & 15;
+    const int row = r0 + (i >> 2);
+    const int col = c0 + ((i & 3) << 2);
+    const char* p = m + sw_off(row, col >> 3) + ((col & 7) << 1);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ bf16x8 tr_frag8(const char* m, int r0a, int r0b, int c0, int lane) {
+    const bf16x4 a = tr_frag(m, r0a, c0, lane);
+    const bf16x4 b = tr_frag(m, r0b, c0, lane);
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// cooperative, row-contiguous load of rows [r0, r0 + 64) of one head's [S][64] bf16 slice into swizzled LDS (zero beyond S)
+__device__ __forceinline__ void load_rows(const bf16* __restrict__ src, long ld, int r0, int S, char* dst, int tid) {
+    for (int idx = tid; idx < BLK * 8; idx += 256) {
+        const int row = idx >> 3, chunk = idx & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r0 + row < S) v = *reinterpret_cast<const bf16x8*>(src + (size_t)(r0 + row) * ld + chunk * 8);
+        *reinterpret_cast<bf16x8*>(dst + sw_off(row, chunk)) = v;
+    }
+}
+// the block's [64][64] result, written by the waves in accumulator layout (row 16 w + i16, cols 16 dt + 4 g ..), leaves
+// LDS row-contiguously
+__device__ __forceinline__ void put_acc(char* stg, int wave, int lane, const f32x4 (&o)[4], float mul) {
+    const int g = lane >> 4, i16 = lane & 15;
+    const int row = wave * 16 + i16;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int col = dt * 16 + 4 * g;
+        *reinterpret_cast<bf16x4*>(stg + sw_off(row, col >> 3) + ((col & 7) << 1)) =
+            cvt4(o[dt] * f32x4{mul, mul, mul, mul});
+    }
+}
+__device__ __forceinline__ void store_rows(bf16* __restrict__ dst, long ld, int r0, int S, const char* stg, int tid) {
+    for (int idx = tid; idx < BLK * 8; idx += 256) {
+        const int row = idx >> 3, chunk = idx & 7;
+        if (r0 + row < S)
+            *reinterpret_cast<bf16x8*>(dst + (size_t)(r0 + row) * ld + chunk * 8) =
+                *reinterpret_cast<const bf16x8*>(stg + sw_off(row, chunk));
+    }
+}
+
+struct Attn2Args {
+    const bf16 *q, *k, *v;
+    long ldq, ldk, ldv;          // row strides (elements); head h at column 64 h
+    long sq_b, skv_b;            // rows per sample of the q-side / kv-side operands (batch strides = rows * ld)
+    const uint8_t* kmask;        // [B, Skv] 1 = attend, or null
+    int Sq, Skv, heads, causal;
+    bf16* o;  long ldo;          // ctx [B*Sq, ldo]
+    float* lse;                  // [B, heads, Sq]
+    // backward
+    const bf16* dout;  long lddo;
+    float* dsum;                 // [B, heads, Sq]: rowsum(dO * O), written by the dQ kernel, read by the dK/dV kernel
+    bf16 *dq, *dk, *dv;  long lddq, lddk, lddv;
+};
+
+__global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
+    __shared__ __attribute__((aligned(16))) char Qs[BLK * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
+    __shared__ float mask_add[BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qb * BLK;
+    const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
+    const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
+    const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
+    load_rows(Q, a.ldq, q0, a.Sq, Qs, tid);
+    __syncthreads();
+    const bf16x8 qf0 = row_frag(Qs, wave * 16 + i16, g), qf1 = row_frag(Qs, wave * 16 + i16, 4 + g);
+    const int qi = q0 + wave * 16 + i16;          // this lane's query
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kend = a.causal ? min(a.Skv, q0 + BLK) : a.Skv;
+    for (int k0 = 0; k0 < kend; k0 += BLK) {
+        __syncthreads();
+        load_rows(K, a.ldk, k0, a.Skv, Ks, tid);
+        load_rows(V, a.ldv, k0, a.Skv, Vs, tid);
+        if (tid < BLK) {
+            const int kk = k0 + tid;
+            mask_add[tid] = (kk < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + kk])) ? 0.f : -INFINITY;
+        }
+        __syncthreads();
+        f32x4 s[4];
+        float cmx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            t = mfma16x32(row_frag(Ks, kt * 16 + i16, g), qf0, t);        // S^T: rows = keys kt*16 + 4g + e, col = query i16
+            t = mfma16x32(row_frag(Ks, kt * 16 + i16, 4 + g), qf1, t);
+            const f32x4 ma = *reinterpret_cast<const f32x4*>(mask_add + kt * 16 + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = t[e] * SC + ma[e];
+                if (a.causal && k0 + kt * 16 + 4 * g + e > qi) x = -INFINITY;
+                t[e] = x;
+                cmx = fmaxf(cmx, x);
+            }
+            s[kt] = t;
+        }
+        cmx = fmaxf(cmx, __shfl_xor(cmx, 16, 64));
+        cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
+        const float m_new = fmaxf(m, cmx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;         // a fully masked prefix contributes nothing
+        const float alpha = __builtin_amdgcn_exp2f(m - m_use);         // m = -inf -> 0
+        float csum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - m_use);
+                csum += s[kt][e];
+            }
+        csum += __shfl_xor(csum, 16, 64);
+        csum += __shfl_xor(csum, 32, 64);
+        l = l * alpha + csum;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * f32x4{alpha, alpha, alpha, alpha};
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8 pb = cvt8(s[2 * st], s[2 * st + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)                               // O^T[d][q] += V^T[d][key] P^T[key][q]
+                o[dt] = mfma16x32(tr_frag8(Vs, st * 32 + 4 * g, st * 32 + 16 + 4 * g, dt * 16, lane), pb, o[dt]);
+        }
+    }
+    __syncthreads();                                                     // Qs is reused as the output staging tile
+    put_acc(Qs, wave, lane, o, l > 0.f ? 1.0f / l : 0.f);
+    if (g == 0 && qi < a.Sq && a.lse)
+        a.lse[((size_t)b * a.heads + h) * a.Sq + qi] = l > 0.f ? m * (1.0f / LOG2E) + __logf(l) : -INFINITY;
+    __syncthreads();
+    store_rows(a.o + (size_t)b * a.sq_b * a.ldo + h * D, a.ldo, q0, a.Sq, Qs, tid);
+}
+
+// dQ (and D = rowsum(dO * O)) of one 64-query block: K / V stream through LDS.
+__global__ __launch_bounds__(256) void attn2_bwd_dq_kernel(Attn2Args a) {
+    __shared__ __attribute__((aligned(16))) char Qs[BLK * ROWB], Gs[BLK * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
+    __shared__ float Dv[BLK], kvalid[BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qb * BLK;
+    const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
+    const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
+    const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
+    const bf16* O = a.o + (size_t)b * a.sq_b * a.ldo + h * D;
+    const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
+    load_rows(Q, a.ldq, q0, a.Sq, Qs, tid);
+    for (int idx = tid; idx < BLK * 8; idx += 256) {          // dO -> LDS, D[q] = sum_d dO[q][d] O[q][d]
+        const int row = idx >> 3, chunk = idx & 7;
+        bf16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
+        float part = 0.f;
+        if (q0 + row < a.Sq) {
+            gv = *reinterpret_cast<const bf16x8*>(G + (size_t)(q0 + row) * a.lddo + chunk * 8);
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(O + (size_t)(q0 + row) * a.ldo + chunk * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)gv[e] * (float)ov[e];
+        }
+        *reinterpret_cast<bf16x8*>(Gs + sw_off(row, chunk)) = gv;
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (chunk == 0) {
+            Dv[row] = part;
+            if (q0 + row < a.Sq) a.dsum[((size_t)b * a.heads + h) * a.Sq + q0 + row] = part;
+        }
+    }
+    __syncthreads();
+    const int qrow = wave * 16 + i16, qi = q0 + qrow;
+    const bf16x8 qf0 = row_frag(Qs, qrow, g), qf1 = row_frag(Qs, qrow, 4 + g);
+    const bf16x8 gf0 = row_frag(Gs, qrow, g), gf1 = row_frag(Gs, qrow, 4 + g);
+    const float dq_ = Dv[qrow];
+    const float lq = qi < a.Sq ? a.lse[((size_t)b * a.heads + h) * a.Sq + qi] * LOG2E : 0.f;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kend = a.causal ? min(a.Skv, q0 + BLK) : a.Skv;
+    for (int k0 = 0; k0 < kend; k0 += BLK) {
+        __syncthreads();
+        load_rows(K, a.ldk, k0, a.Skv, Ks, tid);
+        load_rows(V, a.ldv, k0, a.Skv, Vs, tid);
+        if (tid < BLK) {
+            const int kk = k0 + tid;
+            kvalid[tid] = (kk < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + kk])) ? 1.f : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int krow = (2 * ks + t) * 16;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sc = mfma16x32(row_frag(Ks, krow + i16, g), qf0, sc);
+                sc = mfma16x32(row_frag(Ks, krow + i16, 4 + g), qf1, sc);
+                dp = mfma16x32(row_frag(Vs, krow + i16, g), gf0, dp);
+                dp = mfma16x32(row_frag(Vs, krow + i16, 4 + g), gf1, dp);
+                const f32x4 kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = kv4[e] * __builtin_amdgcn_exp2f(sc[e] * SC - lq);
+                    if (a.causal && k0 + krow + 4 * g + e > qi) pe = 0.f;
+                    ds[t][e] = pe * (dp[e] - dq_);                     // the 1/8 of dS is applied at the end
+                }
+            }
+            const bf16x8 dsb = cvt8(ds[0], ds[1]);
+            const int r0a = (2 * ks) * 16 + 4 * g, r0b = (2 * ks + 1) * 16 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
+        }
+    }
+    __syncthreads();
+    put_acc(Qs, wave, lane, dq, 0.125f);
+    __syncthreads();
+    store_rows(a.dq + (size_t)b * a.sq_b * a.lddq + h * D, a.lddq, q0, a.Sq, Qs, tid);
+}
+
+// dK, dV of one 64-key block: Q / dO (and their LSE / D) stream through LDS.
+__global__ __launch_bounds__(256) void attn2_bwd_dkv_kernel(Attn2Args a) {
+    __shared__ __attribute__((aligned(16))) char Ks[BLK * ROWB], Vs[BLK * ROWB], Qs[BLK * ROWB], Gs[BLK * ROWB];
+    __shared__ float Ls[BLK], Dv[BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int k0 = kb * BLK;
+    const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
+    const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
+    const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
+    const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
+    load_rows(K, a.ldk, k0, a.Skv, Ks, tid);
+    load_rows(V, a.ldv, k0, a.Skv, Vs, tid);
+    __syncthreads();
+    const int krow = wave * 16 + i16, key = k0 + krow;
+    const bf16x8 kf0 = row_frag(Ks, krow, g), kf1 = row_frag(Ks, krow, 4 + g);
+    const bf16x8 vf0 = row_frag(Vs, krow, g), vf1 = row_frag(Vs, krow, 4 + g);
+    const float kv = (key < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + key])) ? 1.f : 0.f;
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int qstart = a.causal ? (k0 / BLK) * BLK : 0;              // queries before the block's first key see none of it
+    for (int q0 = qstart; q0 < a.Sq; q0 += BLK) {
+        __syncthreads();
+        load_rows(Q, a.ldq, q0, a.Sq, Qs, tid);
+        load_rows(G, a.lddo, q0, a.Sq, Gs, tid);
+        if (tid < BLK) {
+            const int qq = q0 + tid;
+            const size_t si = ((size_t)b * a.heads + h) * a.Sq + qq;
+            Ls[tid] = qq < a.Sq ? a.lse[si] * LOG2E : INFINITY;          // rows past Sq: p = exp2(-inf) = 0
+            Dv[tid] = qq < a.Sq ? a.dsum[si] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qrow = (2 * qs + t) * 16;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sc = mfma16x32(row_frag(Qs, qrow + i16, g), kf0, sc);     // S: rows = queries qrow + 4g + e, col = key i16
+                sc = mfma16x32(row_frag(Qs, qrow + i16, 4 + g), kf1, sc);
+                dp = mfma16x32(row_frag(Gs, qrow + i16, g), vf0, dp);
+                dp = mfma16x32(row_frag(Gs, qrow + i16, 4 + g), vf1, dp);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qrow + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + qrow + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = kv * __builtin_amdgcn_exp2f(sc[e] * SC - l4[e]);
+                    if (a.causal && key > q0 + qrow + 4 * g + e) pe = 0.f;
+                    p[t][e] = pe;
+                    ds[t][e] = pe * (dp[e] - d4[e]);
+                }
+            }
+            const bf16x8 pb = cvt8(p[0], p[1]);
+            const bf16x8 dsb = cvt8(ds[0], ds[1]);
+            const int r0a = (2 * qs) * 16 + 4 * g, r0b = (2 * qs + 1) * 16 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = mfma16x32(tr_frag8(Gs, r0a, r0b, dt * 16, lane), pb, dv[dt]);
+                dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
+            }
+        }
+    }
+    __syncthreads();
+    put_acc(Qs, wave, lane, dk, 0.125f);
+    put_acc(Gs, wave, lane, dv, 1.0f);
+    __syncthreads();
+    store_rows(a.dk + (size_t)b * a.skv_b * a.lddk + h * D, a.lddk, k0, a.Skv, Qs, tid);
+    store_rows(a.dv + (size_t)b * a.skv_b * a.lddv + h * D, a.lddv, k0, a.Skv, Gs, tid);
+}
+
+int check(const Attn2Args& a, int B) {
+    if (!a.q || !a.k || !a.v || !a.o || B <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.heads <= 0) return FEDDAT_EINVAL;
+    if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 8) return FEDDAT_EINVAL;
+    if (a.sq_b < a.Sq || a.skv_b < a.Skv) return FEDDAT_EINVAL;
+    return FEDDAT_OK;
+}
+
+}  // namespace
+
+extern "C" int feddat_attn2_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                const uint8_t* key_mask, int causal, void* ctx, long ldo, float* lse, int B, int Sq,
+                                int Skv, long q_rows_per_sample, long kv_rows_per_sample, int heads, hipStream_t stream) {
+    Attn2Args a{};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq_b = q_rows_per_sample; a.skv_b = kv_rows_per_sample;
+    a.kmask = key_mask; a.Sq = Sq; a.Skv = Skv; a.heads = heads; a.causal = causal;
+    a.o = (bf16*)ctx; a.ldo = ldo; a.lse = lse;
+    const int rc = check(a, B);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn2_fwd_kernel, dim3((Sq + BLK - 1) / BLK, heads, B), dim3(256), 0, stream, a);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                const uint8_t* key_mask, int causal, const void* ctx, long ldo, const float* lse,
+                                const void* dctx, long lddo, float* dsum_ws, void* dq, long lddq, void* dk, long lddk,
+                                void* dv, long lddv, int B, int Sq, int Skv, long q_rows_per_sample,
+                                long kv_rows_per_sample, int heads, hipStream_t stream) {
+    Attn2Args a{};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq_b = q_rows_per_sample; a.skv_b = kv_rows_per_sample;
+    a.kmask = key_mask; a.Sq = Sq; a.Skv = Skv; a.heads = heads; a.causal = causal;
+    a.o = (bf16*)ctx; a.ldo = ldo; a.lse = const_cast<float*>(lse);
+    a.dout = (const bf16*)dctx; a.lddo = lddo; a.dsum = dsum_ws;
+    a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    const int rc = check(a, B);
+    if (rc) return rc;
+    FD_CHECK_ARG(lse && dctx && dsum_ws && dq && dk && dv && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0);
+    hipLaunchKernelGGL(attn2_bwd_dq_kernel, dim3((Sq + BLK - 1) / BLK, heads, B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(attn2_bwd_dkv_kernel, dim3((Skv + BLK - 1) / BLK, heads, B), dim3(256), 0, stream, a);
+    FD_LAUNCH_RET();
+}

@@ -46,6 +46,9 @@ _SIGS = {
                                    vp, i64, vp],
     "feddat_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "feddat_attn2_fwd": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, i32, i32, i32, i64, i64, i32, vp],
+    "feddat_attn2_bwd": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32,
+                         i32, i64, i64, i32, vp],
     "feddat_layernorm_fwd": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp],
     "feddat_layernorm_bwd_dx": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp],
     "feddat_layernorm_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
@@ -231,6 +234,24 @@ def attn_bwd(qkv, ctx, lse, dctx, dqkv, B, S, heads, key_mask=None):
     _dev(qkv, ctx, dctx, dqkv)
     _chk(load().feddat_attn_bwd(_p(qkv), _p(key_mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), B, S, heads, _stream()),
          "feddat_attn_bwd")
+
+
+def attn2_fwd(q, k, v, ctx, lse, B, Sq, Skv, heads, *, key_mask=None, causal=False, q_rows=None, kv_rows=None):
+    """General attention: q [B*q_rows, >=heads*64] / k, v [B*kv_rows, ...] bf16 2-D views (row strides from the tensors)."""
+    _dev(q, k, v, ctx)
+    _chk(load().feddat_attn2_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(key_mask), int(causal),
+                                 _p(ctx), ctx.stride(0), _p(lse), B, Sq, Skv, Sq if q_rows is None else q_rows,
+                                 Skv if kv_rows is None else kv_rows, heads, _stream()), "feddat_attn2_fwd")
+
+
+def attn2_bwd(q, k, v, ctx, lse, dctx, dsum_ws, dq, dk, dv, B, Sq, Skv, heads, *, key_mask=None, causal=False,
+              q_rows=None, kv_rows=None):
+    _dev(q, k, v, ctx, dctx, dq, dk, dv)
+    _chk(load().feddat_attn2_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(key_mask), int(causal),
+                                 _p(ctx), ctx.stride(0), _p(lse), _p(dctx), dctx.stride(0), _p(dsum_ws), _p(dq),
+                                 dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), B, Sq, Skv,
+                                 Sq if q_rows is None else q_rows, Skv if kv_rows is None else kv_rows, heads, _stream()),
+         "feddat_attn2_bwd")
 
 
 def layernorm_fwd(x, gamma, beta, eps, rows, H, *, x_stride=None, y_bf16=None, y_f32=None, stats=None):

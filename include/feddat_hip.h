@@ -88,6 +88,21 @@ int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* 
 int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* dctx,
                     void* dqkv, int B, int S, int heads, hipStream_t stream);
 
+/* General form (the ALBEF path): separate Q / K / V operands (bf16, head h at columns 64 h .. 64 h + 63 of each, row
+ * strides ld* in elements, sample b's rows at b * rows_per_sample), any S_q and S_kv (K / V stream through LDS with an
+ * online softmax), optional key-padding mask (uint8 [B, S_kv], 1 = attend) and causal masking (key j <= query i).
+ * Replaces: ViT-B/16 Attention.forward over 577 tokens (src/modeling/models/vit.py:60-76), BertSelfAttention self- and
+ * cross-attention of the ALBEF text encoder / decoder (src/modeling/models/xbert.py; additive -10000 masks == excluded
+ * keys in fp32).  ctx: bf16 [B * q_rows_per_sample, ldo]; lse: fp32 [B, heads, S_q].
+ * Backward: dq / dk / dv (bf16, same layouts as q / k / v) from dctx; dsum_ws: fp32 [B, heads, S_q] scratch. */
+int feddat_attn2_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const uint8_t* key_mask,
+                     int causal, void* ctx, long ldo, float* lse, int B, int Sq, int Skv, long q_rows_per_sample,
+                     long kv_rows_per_sample, int heads, hipStream_t stream);
+int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const uint8_t* key_mask,
+                     int causal, const void* ctx, long ldo, const float* lse, const void* dctx, long lddo, float* dsum_ws,
+                     void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, int B, int Sq, int Skv,
+                     long q_rows_per_sample, long kv_rows_per_sample, int heads, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K3  LayerNorm over the last dim (H <= 2048, H % 4 == 0), fp32 in.
  * fwd: y = (x - mean) * rstd * gamma + beta; x row r at x + r * x_stride (elements); writes y as bf16

@@ -662,3 +662,52 @@ def test_fedavg_allreduce_through_the_c_abi_single_rank(L):
     torch.cuda.synchronize()
     assert torch.equal(flat, want)
     comm.close()
+
+
+# ------------------------------------------------------------------ K2b general attention (ALBEF path)
+@pytest.mark.parametrize("B,Sq,Skv,heads,causal,masked", [
+    (2, 577, 577, 12, False, False),     # ViT-B/16 at 384 x 384
+    (3, 25, 577, 12, False, False),      # text -> image cross-attention
+    (3, 25, 25, 12, False, True),        # text self-attention with padded questions
+    (5, 7, 7, 12, True, True),           # decoder: causal + padded answers
+    (5, 7, 25, 12, False, True),         # decoder -> question cross-attention
+    (1, 130, 200, 2, True, False),       # causal across chunk boundaries
+])
+def test_attn2_fwd_bwd_vs_fp32_reference(L, B, Sq, Skv, heads, causal, masked):
+    g = torch.Generator().manual_seed(Sq * 1000 + Skv)
+    H = heads * 64
+    q = bf(torch.randn(B * Sq, H, generator=g)).to(DEV)
+    kv = bf(torch.randn(B * Skv, 2 * H, generator=g)).to(DEV)       # [K | V] fused, as a cross-attention K/V GEMM leaves it
+    k, v = kv[:, :H], kv[:, H:]
+    do = bf(torch.randn(B * Sq, H, generator=g)).to(DEV)
+    km = None
+    if masked:
+        km = torch.ones(B, Skv, dtype=torch.uint8)
+        for b in range(B):
+            km[b, max(1, Skv - 1 - 2 * b):] = 0
+        km = km.to(DEV)
+    ctx = torch.zeros(B * Sq, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, heads, Sq, device=DEV)
+    L.attn2_fwd(q, k, v, ctx, lse, B, Sq, Skv, heads, key_mask=km, causal=causal)
+    # fp32 restatement on the same bf16-rounded operands
+    qr = q.float().view(B, Sq, heads, 64).transpose(1, 2).requires_grad_(True)
+    kr = k.float().reshape(B, Skv, heads, 64).transpose(1, 2).requires_grad_(True)
+    vr = v.float().reshape(B, Skv, heads, 64).transpose(1, 2).requires_grad_(True)
+    sc = qr @ kr.transpose(-1, -2) / 8.0
+    if km is not None:
+        sc = sc + (1.0 - km.float())[:, None, None, :] * -10000.0      # the reference's additive mask
+    if causal:
+        sc = sc + torch.triu(torch.full((Sq, Skv), -10000.0, device=DEV), diagonal=1)
+    pr = sc.softmax(-1)
+    ref = (pr @ vr).transpose(1, 2).reshape(B * Sq, H)
+    assert (ctx.float() - ref).abs().max() < 2e-2
+    assert (lse - torch.logsumexp(sc, -1)).abs().max() < 2e-3
+    ref.backward(do.float())
+    dq = torch.zeros_like(q)
+    dkv = torch.zeros_like(kv)
+    ws = torch.empty(B, heads, Sq, device=DEV)
+    L.attn2_bwd(q, k, v, ctx, lse, do, ws, dq, dkv[:, :H], dkv[:, H:], B, Sq, Skv, heads, key_mask=km, causal=causal)
+    for got, want in ((dq, qr.grad.transpose(1, 2).reshape(B * Sq, H)),
+                      (dkv[:, :H], kr.grad.transpose(1, 2).reshape(B * Skv, H)),
+                      (dkv[:, H:], vr.grad.transpose(1, 2).reshape(B * Skv, H))):
+        assert rel_err(got, want) < 2e-2, rel_err(got, want)
