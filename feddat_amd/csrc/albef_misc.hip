@@ -1,0 +1,173 @@
+// Small kernels of the ALBEF path (configs[3]): the LM-head token loss with vocabulary-axis MKD, row gather / segment sum
+// (answers <-> questions), and a 3-operand element-wise combine used around the BERT double-LayerNorm adapter variant.
+#include "common.hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void axpby3_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b,
+                                                     float beta, const float* __restrict__ c, float gamma,
+                                                     float* __restrict__ out, bf16* __restrict__ out16, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(a)[i] * f32x4{alpha, alpha, alpha, alpha};
+    if (b) v = v + reinterpret_cast<const f32x4*>(b)[i] * f32x4{beta, beta, beta, beta};
+    if (c) v = v + reinterpret_cast<const f32x4*>(c)[i] * f32x4{gamma, gamma, gamma, gamma};
+    if (out) reinterpret_cast<f32x4*>(out)[i] = v;
+    if (out16) reinterpret_cast<bf16x4*>(out16)[i] = cvt4(v);
+}
+
+// dst[r] = src[idx[r]] (fp32 rows of `width` floats, width % 4 == 0), optional bf16 copy
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          float* __restrict__ dst, bf16* __restrict__ dst16, int width) {
+    const int r = blockIdx.x;
+    const float* s = src + (size_t)idx[r] * width;
+    for (int c = threadIdx.x * 4; c < width; c += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + c);
+        if (dst) *reinterpret_cast<f32x4*>(dst + (size_t)r * width + c) = v;
+        if (dst16) *reinterpret_cast<bf16x4*>(dst16 + (size_t)r * width + c) = cvt4(v);
+    }
+}
+
+// dst[s] = (accumulate ? dst[s] : 0) + sum_{j in [off[s], off[s+1])} src[j]   (rows in index order: deterministic)
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __restrict__ src, const int* __restrict__ off,
+                                                               float* __restrict__ dst, int width, int accumulate) {
+    const int s = blockIdx.x;
+    const int j0 = off[s], j1 = off[s + 1];
+    for (int c = threadIdx.x * 4; c < width; c += 1024) {
+        f32x4 acc = accumulate ? *reinterpret_cast<const f32x4*>(dst + (size_t)s * width + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = j0; j < j1; ++j) acc = acc + *reinterpret_cast<const f32x4*>(src + (size_t)j * width + c);
+        *reinterpret_cast<f32x4*>(dst + (size_t)s * width + c) = acc;
+    }
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+// One block per logits row (one answer token position).  ce = logsumexp(l) - l[label] (0 for label < 0);
+// kl = sum_v q_v (log q_v - log p_v), p = softmax(l / T), q = softmax(teacher / T);
+// dlogits = 0.5 * ( row_w * (softmax(l) - onehot) [label >= 0]  +  kl_scale / T * (p - q) ), stored as bf16 (the operand
+// of the LM-head backward GEMM), zeros in the padding columns [V, ldd).
+__global__ __launch_bounds__(256) void lm_loss_kernel(const float* __restrict__ logits, const float* __restrict__ teacher,
+                                                      long ldl, const long* __restrict__ labels,
+                                                      const float* __restrict__ row_w, int V, float T, float kl_scale,
+                                                      bf16* __restrict__ dlogits, long ldd, float* __restrict__ row_terms) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* l = logits + (size_t)r * ldl;
+    const float* t = teacher ? teacher + (size_t)r * ldl : nullptr;
+    const float invT = 1.0f / T;
+    float m1 = -INFINITY, mt = -INFINITY;
+    for (int v = tid; v < V; v += 256) {
+        m1 = fmaxf(m1, l[v]);
+        if (t) mt = fmaxf(mt, t[v]);
+    }
+    m1 = block_max(m1, red);
+    if (t) mt = block_max(mt, red);
+    float z1 = 0.f, zp = 0.f, zq = 0.f, a = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        const float d = l[v] - m1;
+        z1 += __expf(d);
+        if (t) {
+            zp += __expf(d * invT);
+            const float eq = __expf((t[v] - mt) * invT);
+            zq += eq;
+            a += eq * (t[v] - l[v]) * invT;
+        }
+    }
+    z1 = block_sum(z1, red);
+    float kl = 0.f;
+    if (t) {
+        zp = block_sum(zp, red);
+        zq = block_sum(zq, red);
+        a = block_sum(a, red);
+        kl = a / zq - (mt - m1) * invT - __logf(zq) + __logf(zp);
+    }
+    const long lab = labels[r];
+    const float w = lab >= 0 ? row_w[r] : 0.f;
+    const float ce = lab >= 0 ? (m1 + __logf(z1) - l[lab]) : 0.f;
+    if (tid == 0) {
+        row_terms[2 * r] = w * ce;
+        row_terms[2 * r + 1] = kl;
+    }
+    if (!dlogits) return;
+    bf16* dl = dlogits + (size_t)r * ldd;
+    const float i1 = 1.0f / z1, ip = t ? 1.0f / zp : 0.f, iq = t ? 1.0f / zq : 0.f;
+    const float ks = kl_scale * invT;
+    for (int v = tid; v < (int)ldd; v += 256) {
+        float gv = 0.f;
+        if (v < V) {
+            const float d = l[v] - m1;
+            gv = w * (__expf(d) * i1 - (v == lab ? 1.f : 0.f));
+            if (t) gv += ks * (__expf(d * invT) * ip - __expf((t[v] - mt) * invT) * iq);
+            gv *= 0.5f;
+        }
+        dl[v] = (bf16)gv;
+    }
+}
+
+// scalars[0] = sum_r w_r ce_r (the loss ALBEF.forward returns), [1] = kl_scale * sum_r kl_r, [2] = ([0] + [1]) / 2
+__global__ void lm_loss_finish(const float* __restrict__ row_terms, int R, float kl_scale, float* __restrict__ scalars) {
+    float ce = 0.f, kl = 0.f;
+    for (int r = threadIdx.x; r < R; r += 64) {
+        ce += row_terms[2 * r];
+        kl += row_terms[2 * r + 1];
+    }
+    ce = wave_sum(ce);
+    kl = wave_sum(kl);
+    if (threadIdx.x == 0) {
+        scalars[0] = ce;
+        scalars[1] = kl * kl_scale;
+        scalars[2] = 0.5f * (ce + kl * kl_scale);
+    }
+}
+
+}  // namespace
+
+extern "C" int feddat_axpby3(const float* a, float alpha, const float* b, float beta, const float* c, float gamma,
+                             float* out_f32, void* out_bf16, long n, hipStream_t stream) {
+    FD_CHECK_ARG(a && (out_f32 || out_bf16) && n > 0 && n % 4 == 0);
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(axpby3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a, alpha, b, beta, c,
+                       gamma, out_f32, (bf16*)out_bf16, n4);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_gather_rows(const float* src, const int* idx, float* dst_f32, void* dst_bf16, int rows, int width,
+                                  hipStream_t stream) {
+    FD_CHECK_ARG(src && idx && (dst_f32 || dst_bf16) && rows > 0 && width > 0 && width % 4 == 0);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, stream, src, idx, dst_f32, (bf16*)dst_bf16, width);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_segment_sum_rows(const float* src, const int* seg_offsets, float* dst, int nseg, int width,
+                                       int accumulate, hipStream_t stream) {
+    FD_CHECK_ARG(src && seg_offsets && dst && nseg > 0 && width > 0 && width % 4 == 0);
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(nseg), dim3(256), 0, stream, src, seg_offsets, dst, width, accumulate);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
+                                      const float* row_weight, int R, int V, float temp, float kl_scale,
+                                      void* dlogits_bf16, long ldd, float* scalars, hipStream_t stream) {
+    FD_CHECK_ARG(logits && labels && row_weight && scalars && R > 0 && V > 0 && ldl >= V && temp > 0.f);
+    FD_CHECK_ARG(!dlogits_bf16 || ldd >= V);
+    float* row_terms = scalars + 4;       // scalars: 4 + 2 R floats
+    hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(256), 0, stream, logits, teacher, ldl, labels, row_weight, V, temp,
+                       kl_scale, (bf16*)dlogits_bf16, ldd, row_terms);
+    hipLaunchKernelGGL(lm_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, R, kl_scale, scalars);
+    FD_LAUNCH_RET();
+}

@@ -62,6 +62,10 @@ _SIGS = {
     "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
+    "feddat_lm_loss_fwd_bwd": [vp, vp, i64, vp, vp, i32, i32, f32, f32, vp, i64, vp, vp],
+    "feddat_axpby3": [vp, f32, vp, f32, vp, f32, vp, vp, i64, vp],
+    "feddat_gather_rows": [vp, vp, vp, vp, i32, i32, vp],
+    "feddat_segment_sum_rows": [vp, vp, vp, i32, i32, i32, vp],
     "feddat_adamw_flat": [vp, vp, vp, vp, i64, vp, vp, i32, vp, f32, i32, i32, f32, f32, f32, vp],
     "feddat_step_tick": [vp, i32, i32, vp],
     "feddat_text_embed": [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, vp],
@@ -368,6 +372,35 @@ def dat_loss_fwd_bwd(logits, teacher, target, dlogits, scalars, temp=3.0):
     assert scalars.numel() >= 4 + 2 * B
     _chk(load().feddat_dat_loss_fwd_bwd(_p(logits), _p(teacher), _p(target), B, Cn, temp, _p(dlogits), _p(scalars),
                                         _stream()), "feddat_dat_loss_fwd_bwd")
+
+
+def lm_loss_fwd_bwd(logits, teacher, labels, row_weight, V, temp, kl_scale, dlogits_bf16, scalars):
+    _dev(logits, teacher, labels, row_weight, dlogits_bf16, scalars)
+    R = logits.shape[0]
+    assert scalars.numel() >= 4 + 2 * R and labels.dtype == torch.int64
+    _chk(load().feddat_lm_loss_fwd_bwd(_p(logits), _p(teacher), logits.stride(0), _p(labels), _p(row_weight), R, V, temp,
+                                       kl_scale, _p(dlogits_bf16), 0 if dlogits_bf16 is None else dlogits_bf16.stride(0),
+                                       _p(scalars), _stream()), "feddat_lm_loss_fwd_bwd")
+
+
+def axpby3(a, alpha, b=None, beta=0.0, c=None, gamma=0.0, *, out_f32=None, out_bf16=None):
+    _dev(a, b, c, out_f32, out_bf16)
+    _chk(load().feddat_axpby3(_p(a), alpha, _p(b), beta, _p(c), gamma, _p(out_f32), _p(out_bf16), a.numel(), _stream()),
+         "feddat_axpby3")
+
+
+def gather_rows(src, idx, dst_f32=None, dst_bf16=None):
+    _dev(src, idx, dst_f32, dst_bf16)
+    assert idx.dtype == torch.int32
+    _chk(load().feddat_gather_rows(_p(src), _p(idx), _p(dst_f32), _p(dst_bf16), idx.numel(), src.shape[-1], _stream()),
+         "feddat_gather_rows")
+
+
+def segment_sum_rows(src, seg_offsets, dst, accumulate=False):
+    _dev(src, seg_offsets, dst)
+    assert seg_offsets.dtype == torch.int32
+    _chk(load().feddat_segment_sum_rows(_p(src), _p(seg_offsets), _p(dst), seg_offsets.numel() - 1, src.shape[-1],
+                                        int(accumulate), _stream()), "feddat_segment_sum_rows")
 
 
 def adamw_flat(p, g, m, v, seg_off, seg_wd, state, base_lr, warmup, total, beta1=0.9, beta2=0.98, eps=1e-8):

@@ -213,6 +213,19 @@ int feddat_reduce_partials(const float* in, long stride, int nsplit, long n, flo
 int feddat_dat_loss_fwd_bwd(const float* logits, const float* teacher, const float* target, int B, int C, float temp,
                             float* dlogits, float* scalars, hipStream_t stream);
 
+/* ALBEF (configs[3]) loss: BertLMHeadModel's shifted next-token cross-entropy, weighted per answer
+ * (src/modeling/models/xbert.py:1283-1297 with reduction='none'; ALBEF.forward: loss = sum_n weights[n] * lm_loss[n] / B,
+ * src/modeling/models/albef_model.py:142-143) plus the vocabulary-axis MKD term of the dat train_step,
+ * temp^2 * KLdiv_batchmean(log_softmax(logits / temp) || softmax(teacher / temp)) over the LAST axis
+ * (task_trainer.py:300,320,506-516), and dL/dlogits of L = (loss + kl) / 2.
+ * One row = one (answer, position) of logits[:, :-1]: logits / teacher fp32 [R, ldl] (V valid columns), labels int64 [R]
+ * (-100 = ignored by the CE, still part of the KL, as in the reference), row_weight[r] = weights[n] / B,
+ * kl_scale = temp^2 / N (N answers).  dlogits_bf16 [R, ldd] (may be NULL) gets zeros in columns [V, ldd) so that it can be
+ * the K-padded operand of the LM-head backward GEMM.  scalars: 4 + 2 R floats; [0] = loss, [1] = kl, [2] = L. */
+int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
+                           const float* row_weight, int R, int V, float temp, float kl_scale, void* dlogits_bf16, long ldd,
+                           float* scalars, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K6  fused multi-tensor AdamW over one flat fp32 parameter buffer (torch.optim.AdamW semantics,
  * task_trainer.py:477-504) with the HF polynomial-decay-with-warmup multiplier evaluated on device
@@ -304,6 +317,16 @@ int feddat_gelu_bwd(const float* x, const float* dy, float* dx, long n, hipStrea
 /* LayerNorm backward WITH affine gradients (task head clf_norm0, trainable): rows <= 1024 */
 int feddat_layernorm_bwd_full(const float* dy, const float* x, const float* stats, const float* gamma, int rows, int H,
                               float* dx, float* dgamma, float* dbeta, hipStream_t stream);
+/* out = alpha a + beta b + gamma c (b, c may be NULL), fp32 and / or bf16 copy; n % 4 == 0.  Glue around the BERT
+ * double-LayerNorm adapter variant (src/modeling/models/adapter.py:97-116): y + inp = (dense + inp) + (A(x) + x) - x. */
+int feddat_axpby3(const float* a, float alpha, const float* b, float beta, const float* c, float gamma, float* out_f32,
+                  void* out_bf16, long n, hipStream_t stream);
+/* dst[r] = src[idx[r]] (rows of `width` floats; one question's states repeated for each of its k answers,
+ * albef_model.py:93-98) and its adjoint over contiguous segments: dst[s] (+)= sum of src rows [off[s], off[s+1]). */
+int feddat_gather_rows(const float* src, const int* idx, float* dst_f32, void* dst_bf16, int rows, int width,
+                       hipStream_t stream);
+int feddat_segment_sum_rows(const float* src, const int* seg_offsets, float* dst, int nseg, int width, int accumulate,
+                            hipStream_t stream);
 /* scatter B rows into a zero-filled [B*S, H] fp32 buffer at token 0 of each sample (+ bf16 copy) */
 int feddat_scatter_cls_rows(const float* rows, float* out_f32, void* out_bf16, int B, int S, int H,
                             hipStream_t stream);
