@@ -1,0 +1,530 @@
+"""ALBEF (ViT-B/16 + BERT-base encoder + 6-layer decoder) dual-adapter (DAT + MKD) local-update engine on MI355X --
+BASELINE.json configs[3].
+
+Host-side sequencing of the HIP kernels in libfeddat_hip.so for the reference's two-stream path: ALBEF.forward(train=True)
+(src/modeling/models/albef_model.py:69-145) inside the dat branch of TaskTrainer.train_step
+(src/train/visionlanguage_tasks/task_trainer.py:280-330, ALBEF wiring :296-297,316-317, vocabulary-axis KL :506-516), with
+the adapters of vit.py:99-110 (after the MLP residual) and xbert.py:438-445 / adapter.py:97-116 (BertOutput, same LayerNorm
+before and after the adapter).  As in the ViLT engine, no arithmetic happens in Python / PyTorch: torch owns device
+buffers and the stream, every launch goes through the C ABI.
+
+Step algebra: only adapter tensors are trainable (main.py:138-159: the LM head `.cls.` is personal but frozen), so the
+no-grad gated pass P0 and the gated pass P2 of one train_step are the same computation (P1 updates adapter_1 only, the
+gated passes read adapter_0 / adapter_2) -> the gated forward runs ONCE; its logits serve as the teacher of P1 and as the
+student of P2.  Nothing trainable lies below the first ViT block's adapter, so the backward stops there.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+from .engine import FlatGroup
+
+PRE = "albef_model.albef."
+ADAPTER_TENSORS = ("down.weight", "down.bias", "up.weight", "up.bias")
+
+
+class AlbefDatEngine:
+    def __init__(self, params: Dict[str, torch.Tensor], device, batch: int, n_answers: int, q_len: int = 25, a_len: int = 4,
+                 vit_depth: int = 12, enc_layers: int = 12, fusion_layer: int = 6, dec_layers: int = 6, image: int = 384,
+                 vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0):
+        L.load()
+        self.dev = dev = torch.device(device)
+        self.B, self.N, self.Lq, self.La = batch, n_answers, q_len, a_len
+        self.vd, self.el, self.fl, self.dl = vit_depth, enc_layers, fusion_layer, dec_layers
+        self.H, self.I, self.heads, self.r, self.P = 768, 3072, 12, 48, 16
+        self.img = image
+        self.gp = image // self.P
+        self.Ni = self.gp * self.gp + 1
+        self.V, self.Vp = vocab, ((vocab + 127) // 128) * 128
+        self.pad_id = pad_id
+        self.lr, self.wd, self.eps = lr, weight_decay, adam_eps
+        H, I = self.H, self.I
+        self.Mi, self.Mq, self.Ma, self.R = batch * self.Ni, batch * q_len, n_answers * a_len, n_answers * (a_len - 1)
+
+        def Pm(name):
+            return params[PRE + name].to(dev, torch.float32).contiguous()
+
+        def bf16_of(w):
+            out = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
+            L.cvt_f32_bf16(w.contiguous(), out)
+            return out
+
+        def bf16_T(w):
+            out = torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev)
+            L.transpose_f32_bf16(w.contiguous(), out, w.shape[0], w.shape[1])
+            return out
+
+        def lin(prefix):          # forward operand, transposed operand (dX), bias
+            w = Pm(prefix + ".weight")
+            return dict(w=bf16_of(w), wT=bf16_T(w), b=Pm(prefix + ".bias"))
+
+        # ---------------- frozen ViT-B/16 ----------------
+        v = "visual_encoder."
+        self.vit = dict(cls=Pm(v + "cls_token").reshape(H), pos=Pm(v + "pos_embed")[0].contiguous(),
+                        wp=bf16_of(Pm(v + "patch_embed.proj.weight").reshape(H, 3 * self.P * self.P)),
+                        bp=Pm(v + "patch_embed.proj.bias"), ng=Pm(v + "norm.weight"), nb=Pm(v + "norm.bias"), blocks=[])
+        for i in range(vit_depth):
+            b = f"{v}blocks.{i}."
+            self.vit["blocks"].append(dict(qkv=lin(b + "attn.qkv"), proj=lin(b + "attn.proj"), fc1=lin(b + "mlp.fc1"),
+                                           fc2=lin(b + "mlp.fc2"), n1g=Pm(b + "norm1.weight"), n1b=Pm(b + "norm1.bias"),
+                                           n2g=Pm(b + "norm2.weight"), n2b=Pm(b + "norm2.bias")))
+        self.zero_h = torch.zeros(H, device=dev)
+
+        # ---------------- frozen BERT towers ----------------
+        def attn_block(prefix, cross):
+            wq, wk, wv = (Pm(f"{prefix}self.{n}.weight") for n in ("query", "key", "value"))
+            bq, bk, bv = (Pm(f"{prefix}self.{n}.bias") for n in ("query", "key", "value"))
+            d = dict(o=lin(prefix + "output.dense"), lng=Pm(prefix + "output.LayerNorm.weight"),
+                     lnb=Pm(prefix + "output.LayerNorm.bias"))
+            if cross:          # Q from the text stream, K | V fused from the other stream
+                d.update(q=dict(w=bf16_of(wq), wT=bf16_T(wq), b=bq),
+                         kv=dict(w=bf16_of(torch.cat([wk, wv], 0)), wT=bf16_T(torch.cat([wk, wv], 0)), b=torch.cat([bk, bv])))
+            else:
+                w = torch.cat([wq, wk, wv], 0)
+                d.update(qkv=dict(w=bf16_of(w), wT=bf16_T(w), b=torch.cat([bq, bk, bv])))
+            return d
+
+        def tower(prefix, layers, fusion):
+            e = prefix + "embeddings."
+            t = dict(word=Pm(e + "word_embeddings.weight"), pos=Pm(e + "position_embeddings.weight"),
+                     typ=Pm(e + "token_type_embeddings.weight"), lng=Pm(e + "LayerNorm.weight"), lnb=Pm(e + "LayerNorm.bias"),
+                     layers=[])
+            for i in range(layers):
+                Lp = f"{prefix}encoder.layer.{i}."
+                t["layers"].append(dict(att=attn_block(Lp + "attention.", False),
+                                        cross=attn_block(Lp + "crossattention.", True) if i >= fusion else None,
+                                        fc1=lin(Lp + "intermediate.dense"), fc2=lin(Lp + "output.dense"),
+                                        lng=Pm(Lp + "output.LayerNorm.weight"), lnb=Pm(Lp + "output.LayerNorm.bias")))
+            return t
+        self.enc = tower("text_encoder.", enc_layers, fusion_layer)
+        self.dec = tower("text_decoder.bert.", dec_layers, 0)
+        c = "text_decoder.cls.predictions."
+        wemb = torch.zeros(self.Vp, H, device=dev)
+        wemb[:vocab] = self.dec["word"]                      # tied LM-head weight, vocabulary padded to a multiple of 128
+        bpad = torch.zeros(self.Vp, device=dev)
+        bpad[:vocab] = Pm(c + "bias")
+        self.head = dict(t=lin(c + "transform.dense"), lng=Pm(c + "transform.LayerNorm.weight"),
+                         lnb=Pm(c + "transform.LayerNorm.bias"), w=bf16_of(wemb), wT=bf16_T(wemb), b=bpad)
+        del wemb
+
+        # ---------------- trainable state: three adapters over the 30 modules, flat per adapter ----------------
+        self.modules: List[str] = [f"visual_encoder.blocks.{i}.adapter." for i in range(vit_depth)] + \
+            [f"text_encoder.encoder.layer.{i}.output.adapter." for i in range(enc_layers)] + \
+            [f"text_decoder.bert.encoder.layer.{i}.output.adapter." for i in range(dec_layers)]
+        shp = {"down.weight": (self.r, H), "down.bias": (self.r,), "up.weight": (H, self.r), "up.bias": (H,)}
+        self.ad = [FlatGroup([(PRE + m + f"adapter_{a}_{t}", shp[t]) for m in self.modules for t in ADAPTER_TENSORS], dev,
+                             with_opt=(a != 2)) for a in range(3)]
+        for grp in self.ad:
+            for n in grp.names:
+                grp.view(n).copy_(params[n].to(dev, torch.float32))
+        self.ad_numel = self.r * H + self.r + H * self.r + H
+        nm = len(self.modules)
+        self._pack16 = [torch.empty(nm, 4, self.r * H, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+        for a in range(3):
+            self.repack_adapter(a)
+        self.sched = dict(warmup=1, total=2)
+        self.opt_adapters = (0, 1)
+        self._segs_cache: Dict = {}
+        self.wpart = torch.empty(L.adapter_wgrad_workspace_elems(1), device=dev)
+        self._alloc()
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _alloc(self):
+        dev, H, I = self.dev, self.H, self.I
+
+        def f32(*s):
+            return torch.empty(*s, device=dev)
+
+        def b16(*s):
+            return torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        B, N, Lq, La = self.B, self.N, self.Lq, self.La
+        self.inp = dict(image=f32(B, 3, self.img, self.img), question_ids=torch.zeros(B, Lq, dtype=torch.int64, device=dev),
+                        question_mask=torch.ones(B, Lq, dtype=torch.int64, device=dev),
+                        answer_ids=torch.zeros(N, La, dtype=torch.int64, device=dev),
+                        answer_mask=torch.ones(N, La, dtype=torch.int64, device=dev), weights=f32(N))
+        self.zero_tt_q = torch.zeros(B, Lq, dtype=torch.int64, device=dev)
+        self.zero_tt_a = torch.zeros(N, La, dtype=torch.int64, device=dev)
+        self.qmask8 = torch.ones(B, Lq, dtype=torch.uint8, device=dev)
+        self.amask8 = torch.ones(N, La, dtype=torch.uint8, device=dev)
+        self.qmask8_rep = torch.ones(N, Lq, dtype=torch.uint8, device=dev)
+        self.rep_idx = torch.zeros(N * Lq, dtype=torch.int32, device=dev)       # (answer, token) -> question-state row
+        self.seg_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)        # answers of question b: [off[b], off[b+1])
+        self.sel_idx = torch.zeros(self.R, dtype=torch.int32, device=dev)       # LM rows: (answer, t < La-1) -> decoder row
+        self.unsel_idx = torch.full((self.Ma,), -1, dtype=torch.int32, device=dev)
+        self.labels = torch.zeros(self.R, dtype=torch.int64, device=dev)
+        self.row_w = f32(self.R)
+        self.patches = b16(B * (self.Ni - 1), 3 * self.P * self.P)
+        self.proj = f32(B * (self.Ni - 1), H)
+
+        def vit_set():
+            Mi = self.Mi
+            return dict(h0=f32(Mi, H), st0=f32(Mi, 2), x16=b16(Mi, H), f16=b16(Mi, I),
+                        blocks=[dict(h_in=f32(Mi, H) if i else None, st1=f32(Mi, 2), qkv=b16(Mi, 3 * H), ctx=b16(Mi, H),
+                                     lse=f32(self.B, self.heads, self.Ni), h2=f32(Mi, H), st2=f32(Mi, 2), u=b16(Mi, I),
+                                     h3=f32(Mi, H), zs=f32(Mi, 2, self.r)) for i in range(self.vd)],
+                        out=f32(Mi, H), stf=f32(Mi, 2), emb16=b16(Mi, H))
+
+        def bert_set(M, nb, Sq, layers, cross_from, kv_rows):
+            def layer(i):
+                d = dict(qkv=b16(M, 3 * H), ctx=b16(M, H), lse=f32(nb, self.heads, Sq), t1=f32(M, H), st_a=f32(M, 2),
+                         a=f32(M, H), a16=b16(M, H), u=b16(M, I), s1=f32(M, H), st_x=f32(M, 2), x=f32(M, H),
+                         zs=f32(M, 2, self.r), s2=f32(M, H), st_o=f32(M, 2), out=f32(M, H), out16=b16(M, H))
+                if i >= cross_from:
+                    d.update(qc=b16(M, H), kvc=b16(kv_rows, 2 * H), ctx2=b16(M, H), lse2=f32(nb, self.heads, Sq),
+                             t2=f32(M, H), st_c=f32(M, 2), c=f32(M, H), c16=b16(M, H))
+                return d
+            return dict(h=f32(M, H), h16=b16(M, H), f16=b16(M, I), tA=f32(M, H), layers=[layer(i) for i in range(layers)])
+
+        def act_set():
+            return dict(vit=vit_set(), enc=bert_set(self.Mq, B, Lq, self.el, self.fl, self.Mi),
+                        dec=bert_set(self.Ma, N, La, self.dl, 0, N * Lq), enc_rep16=b16(N * Lq, H),
+                        hsel=f32(self.R, H), hsel16=b16(self.R, H), tu=f32(self.R, H), tg=f32(self.R, H), tst=f32(self.R, 2),
+                        ty16=b16(self.R, H), logits=f32(self.R, self.Vp), loss=f32(4 + 2 * self.R))
+        self.acts = {"gating": act_set(), "adapter_1": act_set()}
+        # backward scratch (one set, reused by both passes)
+        Mmax = max(self.Mi, self.Mq, self.Ma, N * Lq, self.R)
+        self.g = dict(dlogits=b16(self.R, self.Vp), d1=f32(Mmax, H), d2=f32(Mmax, H), d3=f32(Mmax, H), d4=f32(Mmax, H),
+                      b1=b16(Mmax, H), b2=b16(Mmax, H), bI=b16(Mmax, I), b3=b16(Mmax, 3 * H), bkv=b16(Mmax, 2 * H),
+                      z=f32(Mmax, self.r), dz=f32(Mmax, self.r), dsum=f32(max(B, N), self.heads, max(self.Ni, Lq, La)),
+                      d_img=f32(self.Mi, H), d_qs=f32(self.Mq, H), d_rep=f32(N * Lq, H), d_dec=f32(self.Ma, H))
+
+    # ------------------------------------------------------------------------------------------ adapters
+    def _pack(self, a: int, m: int):
+        c = self._pack16[a][m]
+        H, r = self.H, self.r
+        base = PRE + self.modules[m] + f"adapter_{a}_"
+        return dict(wd=c[0].view(r, H), wdT=c[1].view(H, r), wu=c[2].view(H, r), wuT=c[3].view(r, H),
+                    bd=self.ad[a].view(base + "down.bias"), bu=self.ad[a].view(base + "up.bias"),
+                    wd32=self.ad[a].view(base + "down.weight"), wu32=self.ad[a].view(base + "up.weight"))
+
+    def repack_adapter(self, a: int):
+        p0 = self._pack(a, 0)
+        L.adapter_pack_strided(p0["wd32"], p0["wu32"], self.ad_numel, p0["wd"], p0["wdT"], p0["wu"], p0["wuT"],
+                               4 * self.r * self.H, len(self.modules))
+
+    def _segs(self, m: int, mode: str, rows: int, bwd: bool):
+        key = (m, mode, rows, bwd)
+        if key not in self._segs_cache:
+            if mode == "gating":
+                ads = [dict(self._pack(0, m), scale=0.5), dict(self._pack(2, m), scale=0.5)]
+            else:
+                ads = [dict(self._pack(int(mode.split("_")[1]), m), scale=1.0)]
+            self._segs_cache[key] = L.make_segs([dict(row_begin=0, row_end=rows, train_slot=0 if bwd else -1, adapters=ads)])
+        return self._segs_cache[key]
+
+    def _wgrad(self, m: int, mode: str, x, dy, rows: int):
+        a = 0 if mode == "gating" else int(mode.split("_")[1])
+        if a not in self.opt_adapters:
+            return
+        key = ("wg", m, a, x.data_ptr(), dy.data_ptr(), rows)
+        if key not in self._segs_cache:
+            n = self.ad_numel
+            self._segs_cache[key] = L.make_wgrad_segs([dict(x=x, dy=dy, z=self.g["z"], dz=self.g["dz"],
+                                                            grad=self.ad[a].g[m * n:(m + 1) * n], rows=rows,
+                                                            scale=0.5 if mode == "gating" else 1.0)])
+        L.adapter_wgrad(self._segs_cache[key], self.wpart)
+
+    def copy_global_to_teacher(self):
+        self.ad[2].p.copy_(self.ad[1].p)
+        self.repack_adapter(2)
+
+    # ------------------------------------------------------------------------------------------ inputs
+    def set_batch(self, batch: Dict):
+        """Reference batch after tokenisation: image [B,3,R,R] f32; question_ids / question_mask [B,Lq]; answer_ids /
+        answer_mask [N,La]; weights [N]; k = answers per question (host list, sum = N)."""
+        for k in ("image", "question_ids", "question_mask", "answer_ids", "answer_mask", "weights"):
+            src = batch[k]
+            if tuple(src.shape) != tuple(self.inp[k].shape):
+                raise L.FeddatHipError(f"engine built for {k} {tuple(self.inp[k].shape)}, got {tuple(src.shape)}")
+            self.inp[k].copy_(src, non_blocking=True)
+        ks = list(batch["k"])
+        if len(ks) != self.B or sum(ks) != self.N:
+            raise L.FeddatHipError("k must list the answers per question and sum to the engine's n_answers")
+        if getattr(self, "_k", None) != ks:          # index maps depend on k only (host-built once per k pattern)
+            self._k = ks
+            Lq, La = self.Lq, self.La
+            qof = torch.repeat_interleave(torch.arange(self.B), torch.tensor(ks))
+            self.qof = qof.to(self.dev)
+            self.rep_idx.copy_((qof[:, None] * Lq + torch.arange(Lq)[None]).reshape(-1).int())
+            self.seg_off.copy_(torch.tensor([0] + list(torch.tensor(ks).cumsum(0)), dtype=torch.int32))
+            sel = (torch.arange(self.N)[:, None] * La + torch.arange(La - 1)[None]).reshape(-1)
+            self.sel_idx.copy_(sel.int())
+            un = torch.full((self.Ma,), -1, dtype=torch.int32)
+            un[sel] = torch.arange(self.R, dtype=torch.int32)
+            self.unsel_idx.copy_(un)
+        # masks, labels and per-row weights of this batch (tiny integer work on the device tensors)
+        self.qmask8.copy_(self.inp["question_mask"])
+        self.amask8.copy_(self.inp["answer_mask"])
+        self.qmask8_rep.copy_(self.qmask8[self.qof])
+        ids = self.inp["answer_ids"]
+        lab = ids[:, 1:].masked_fill(ids[:, 1:] == self.pad_id, -100)
+        self.labels.copy_(lab.reshape(-1))
+        self.row_w.copy_((self.inp["weights"] / self.B)[:, None].expand(self.N, self.La - 1).reshape(-1))
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _vit_fwd(self, S, mode: str):
+        B, H, Ni, vt = self.B, self.H, self.Ni, self.vit
+        V = S["vit"]
+        L.im2col_patches(self.inp["image"], self.patches, B, 3, self.img, self.img, self.P)
+        L.gemm_bf16_nt(self.patches, vt["wp"], L.EPI_F32, bias=vt["bp"], out_f32=self.proj)
+        # x = cat(cls, patches) + pos_embed  (vit.py:179-184): row 0 = cls + pos[0], rows 1.. = proj + pos[1..]
+        L.image_embed_assemble(self.proj, vt["cls"], vt["pos"][0], vt["pos"][1:], self.zero_h, V["h0"], B, 0, Ni - 1, Ni, H)
+        h = V["h0"]
+        b0 = vt["blocks"][0]
+        L.layernorm_fwd(h, b0["n1g"], b0["n1b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=V["blocks"][0]["st1"])
+        for i, W in enumerate(vt["blocks"]):
+            A = V["blocks"][i]
+            L.gemm_bf16_nt(V["x16"], W["qkv"]["w"], L.EPI_BF16, bias=W["qkv"]["b"], out_bf16=A["qkv"])
+            q, k, v = A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:]
+            L.attn2_fwd(q, k, v, A["ctx"], A["lse"], B, Ni, Ni, self.heads)
+            L.gemm_bf16_nt(A["ctx"], W["proj"]["w"], L.EPI_RESID_F32, bias=W["proj"]["b"], resid=h, out_f32=A["h2"])
+            L.layernorm_fwd(A["h2"], W["n2g"], W["n2b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=A["st2"])
+            L.gemm_bf16_nt(V["x16"], W["fc1"]["w"], L.EPI_GELU, bias=W["fc1"]["b"], out_bf16=V["f16"], out2_bf16=A["u"])
+            L.gemm_bf16_nt(V["f16"], W["fc2"]["w"], L.EPI_RESID_F32, bias=W["fc2"]["b"], resid=A["h2"], out_f32=A["h3"])
+            last = i == self.vd - 1
+            nxt = V["out"] if last else V["blocks"][i + 1]["h_in"]
+            g_, b_ = (vt["ng"], vt["nb"]) if last else (vt["blocks"][i + 1]["n1g"], vt["blocks"][i + 1]["n1b"])
+            # adapter (vit.py:107) fused with the NEXT LayerNorm: the next block's norm1, or the encoder's final norm whose
+            # bf16 output is image_embeds, the K / V source of the text encoder's cross-attention
+            L.adapter_fwd_ln(A["h3"], nxt, self._segs(i, mode, self.Mi, False), self.Mi, g_, b_, 1e-6,
+                             V["emb16"] if last else V["x16"], V["stf"] if last else V["blocks"][i + 1]["st1"],
+                             z_save=A["zs"])
+            h = nxt
+
+    def _embed(self, T, ids, tts, nb, Lt, out_f32, out_b16):
+        L.text_embed(ids, tts, T["word"], T["pos"], T["typ"], T["lng"], T["lnb"], 1e-12, self.zero_h, out_f32, nb, Lt, Lt,
+                     self.H)
+        L.cvt_f32_bf16(out_f32, out_b16)
+
+    def _attn_out(self, W, ctx, resid, M, t_out, st, y, y16):
+        """BertSelfOutput: LN(dense(ctx) + input) (xbert.py BertSelfOutput)."""
+        L.gemm_bf16_nt(ctx, W["o"]["w"], L.EPI_RESID_F32, bias=W["o"]["b"], resid=resid, out_f32=t_out)
+        L.layernorm_fwd(t_out, W["lng"], W["lnb"], 1e-12, M, self.H, y_bf16=y16, y_f32=y, stats=st)
+
+    def _bert_fwd(self, T, S, m0: int, mode: str, M, nb, Sq, self_mask, causal, enc16, enc_rows, Skv, enc_mask):
+        H = self.H
+        h, h16 = S["h"], S["h16"]
+        for i, W in enumerate(T["layers"]):
+            A = S["layers"][i]
+            L.gemm_bf16_nt(h16, W["att"]["qkv"]["w"], L.EPI_BF16, bias=W["att"]["qkv"]["b"], out_bf16=A["qkv"])
+            L.attn2_fwd(A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:], A["ctx"], A["lse"], nb, Sq, Sq,
+                        self.heads, key_mask=self_mask, causal=causal)
+            self._attn_out(W["att"], A["ctx"], h, M, A["t1"], A["st_a"], A["a"], A["a16"])
+            c, c16 = A["a"], A["a16"]
+            if W["cross"] is not None:
+                Wc = W["cross"]
+                L.gemm_bf16_nt(A["a16"], Wc["q"]["w"], L.EPI_BF16, bias=Wc["q"]["b"], out_bf16=A["qc"])
+                L.gemm_bf16_nt(enc16, Wc["kv"]["w"], L.EPI_BF16, bias=Wc["kv"]["b"], out_bf16=A["kvc"])
+                L.attn2_fwd(A["qc"], A["kvc"][:, :H], A["kvc"][:, H:], A["ctx2"], A["lse2"], nb, Sq, Skv, self.heads,
+                            key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows)
+                self._attn_out(Wc, A["ctx2"], A["a"], M, A["t2"], A["st_c"], A["c"], A["c16"])
+                c, c16 = A["c"], A["c16"]
+            L.gemm_bf16_nt(c16, W["fc1"]["w"], L.EPI_GELU, bias=W["fc1"]["b"], out_bf16=S["f16"], out2_bf16=A["u"])
+            # BertOutput with the adapter (xbert.py:438-445 -> adapter.py:97-116): s1 = dense + inp; x = LN(s1);
+            # y + inp = s1 + (x + A(x)) - x; out = LN(y + inp), same LayerNorm twice
+            L.gemm_bf16_nt(S["f16"], W["fc2"]["w"], L.EPI_RESID_F32, bias=W["fc2"]["b"], resid=c, out_f32=A["s1"])
+            L.layernorm_fwd(A["s1"], W["lng"], W["lnb"], 1e-12, M, H, y_f32=A["x"], stats=A["st_x"])
+            L.adapter_fwd(A["x"], S["tA"], self._segs(m0 + i, mode, M, False), M, z_save=A["zs"])
+            L.axpby3(A["s1"], 1.0, S["tA"], 1.0, A["x"], -1.0, out_f32=A["s2"])
+            L.layernorm_fwd(A["s2"], W["lng"], W["lnb"], 1e-12, M, H, y_f32=A["out"], y_bf16=A["out16"], stats=A["st_o"])
+            h, h16 = A["out"], A["out16"]
+        return h, h16
+
+    def _forward(self, mode: str):
+        """ALBEF.forward(train=True) up to logits[:, :-1] (albef_model.py:69-145), activations kept in self.acts[mode]."""
+        S = self.acts[mode]
+        B, N, Lq, La, H = self.B, self.N, self.Lq, self.La, self.H
+        self._vit_fwd(S, mode)
+        E, D = S["enc"], S["dec"]
+        self._embed(self.enc, self.inp["question_ids"], self.zero_tt_q, B, Lq, E["h"], E["h16"])
+        qs, _ = self._bert_fwd(self.enc, E, self.vd, mode, self.Mq, B, Lq, self.qmask8, False, S["vit"]["emb16"], self.Ni,
+                               self.Ni, None)
+        # one question's states for each of its k answers (albef_model.py:93-98)
+        L.gather_rows(qs, self.rep_idx, dst_bf16=S["enc_rep16"])
+        self._embed(self.dec, self.inp["answer_ids"], self.zero_tt_a, N, La, D["h"], D["h16"])
+        out, _ = self._bert_fwd(self.dec, D, self.vd + self.el, mode, self.Ma, N, La, self.amask8, True, S["enc_rep16"], Lq,
+                                Lq, self.qmask8_rep)
+        # BertOnlyMLMHead on the positions that predict a next token (logits[:, :-1])
+        hd = self.head
+        L.gather_rows(out, self.sel_idx, dst_f32=S["hsel"], dst_bf16=S["hsel16"])
+        L.gemm_bf16_nt(S["hsel16"], hd["t"]["w"], L.EPI_F32, bias=hd["t"]["b"], out_f32=S["tu"])
+        L.gelu_fwd(S["tu"], S["tg"])
+        L.layernorm_fwd(S["tg"], hd["lng"], hd["lnb"], 1e-12, self.R, H, y_bf16=S["ty16"], stats=S["tst"])
+        L.gemm_bf16_nt(S["ty16"], hd["w"], L.EPI_F32, bias=hd["b"], out_f32=S["logits"])
+        return S["logits"]
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _bert_bwd(self, T, S, m0: int, mode: str, M, nb, Sq, self_mask, causal, enc16, enc_rows, Skv, enc_mask, d_out,
+                  d_enc):
+        """d_out: fp32 [M,768] gradient of the tower's output (consumed); d_enc: fp32 accumulator for the encoder-side
+        states (zeroed by the caller); returns the gradient wrt the tower's embedding output (unused: embeddings frozen)."""
+        H, g = self.H, self.g
+        for i in range(len(T["layers"]) - 1, -1, -1):
+            W, A = T["layers"][i], S["layers"][i]
+            ds2, dxf, dx, ds1 = g["d1"][:M], g["d2"][:M], g["d3"][:M], g["d4"][:M]
+            L.layernorm_bwd_dx(A["s2"], A["st_o"], W["lng"], M, H, dy_f32=d_out, out_f32=ds2)
+            L.adapter_bwd(None, ds2, dxf, self._segs(m0 + i, mode, M, True), M, z_out=g["z"], dz_out=g["dz"],
+                          z_saved=A["zs"])
+            self._wgrad(m0 + i, mode, A["x"], ds2, M)
+            L.axpby3(dxf, 1.0, ds2, -1.0, out_f32=dx)                      # d x = Wd^T dz (the adapter's residual is r, not x)
+            L.layernorm_bwd_dx(A["s1"], A["st_x"], W["lng"], M, H, dy_f32=dx, dres=ds2, out_f32=ds1, out_bf16=g["b1"][:M])
+            L.gemm_bf16_nt(g["b1"][:M], W["fc2"]["wT"], L.EPI_MUL_DGELU, aux=A["u"], out_bf16=g["bI"][:M])
+            dc = d_out                                                      # reuse: d_out is dead
+            L.gemm_bf16_nt(g["bI"][:M], W["fc1"]["wT"], L.EPI_RESID_F32, resid=ds1, out_f32=dc)
+            if W["cross"] is not None:
+                Wc = W["cross"]
+                dt2 = ds2
+                L.layernorm_bwd_dx(A["t2"], A["st_c"], Wc["lng"], M, H, dy_f32=dc, out_f32=dt2, out_bf16=g["b1"][:M])
+                L.gemm_bf16_nt(g["b1"][:M], Wc["o"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:M])
+                kv_rows = A["kvc"].shape[0]
+                dq, dkv = g["b1"][:M], g["bkv"][:kv_rows]
+                L.attn2_bwd(A["qc"], A["kvc"][:, :H], A["kvc"][:, H:], A["ctx2"], A["lse2"], g["b2"][:M], g["dsum"], dq,
+                            dkv[:, :H], dkv[:, H:], nb, Sq, Skv, self.heads, key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows)
+                da = dc
+                L.gemm_bf16_nt(dq, Wc["q"]["wT"], L.EPI_RESID_F32, resid=dt2, out_f32=da)
+                L.gemm_bf16_nt(dkv, Wc["kv"]["wT"], L.EPI_RESID_F32, resid=d_enc, out_f32=d_enc)
+            else:
+                da = dc
+            dt1 = ds2
+            L.layernorm_bwd_dx(A["t1"], A["st_a"], W["att"]["lng"], M, H, dy_f32=da, out_f32=dt1, out_bf16=g["b1"][:M])
+            L.gemm_bf16_nt(g["b1"][:M], W["att"]["o"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:M])
+            dqkv = g["b3"][:M]
+            L.attn2_bwd(A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:], A["ctx"], A["lse"], g["b2"][:M],
+                        g["dsum"], dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], nb, Sq, Sq, self.heads, key_mask=self_mask,
+                        causal=causal)
+            L.gemm_bf16_nt(dqkv, W["att"]["qkv"]["wT"], L.EPI_RESID_F32, resid=dt1, out_f32=d_out)
+        return d_out
+
+    def _vit_bwd(self, S, mode: str, d_img):
+        """d_img: fp32 [Mi,768] gradient wrt image_embeds (the final norm's output)."""
+        H, g, vt, Mi = self.H, self.g, self.vit, self.Mi
+        V = S["vit"]
+        cur, oth = g["d1"][:Mi], g["d2"][:Mi]
+        L.layernorm_bwd_dx(V["out"], V["stf"], vt["ng"], Mi, H, dy_f32=d_img, out_f32=cur)
+        for i in range(self.vd - 1, -1, -1):
+            W, A = vt["blocks"][i], V["blocks"][i]
+            if i == 0:       # nothing trainable below the first adapter: weight gradients only
+                L.adapter_bwd(None, cur, None, self._segs(0, mode, Mi, True), Mi, z_out=g["z"], dz_out=g["dz"],
+                              z_saved=A["zs"])
+                self._wgrad(0, mode, A["h3"], cur, Mi)
+                break
+            L.adapter_bwd(None, cur, oth, self._segs(i, mode, Mi, True), Mi, dx_bf16=g["b1"][:Mi], z_out=g["z"],
+                          dz_out=g["dz"], z_saved=A["zs"])
+            self._wgrad(i, mode, A["h3"], cur, Mi)
+            L.gemm_bf16_nt(g["b1"][:Mi], W["fc2"]["wT"], L.EPI_MUL_DGELU, aux=A["u"], out_bf16=g["bI"][:Mi])
+            L.gemm_bf16_nt(g["bI"][:Mi], W["fc1"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:Mi])
+            L.layernorm_bwd_dx(A["h2"], A["st2"], W["n2g"], Mi, H, dy_bf16=g["b2"][:Mi], dres=oth, out_f32=cur,
+                               out_bf16=g["b1"][:Mi])
+            L.gemm_bf16_nt(g["b1"][:Mi], W["proj"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:Mi])
+            dqkv = g["b3"][:Mi]
+            L.attn2_bwd(A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:], A["ctx"], A["lse"], g["b2"][:Mi],
+                        g["dsum"], dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], self.B, self.Ni, self.Ni, self.heads)
+            L.gemm_bf16_nt(dqkv, W["qkv"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:Mi])
+            L.layernorm_bwd_dx(A["h_in"], A["st1"], W["n1g"], Mi, H, dy_bf16=g["b2"][:Mi], dres=cur, out_f32=oth)
+            cur, oth = oth, cur
+
+    def _backward(self, mode: str, teacher_logits):
+        """L = (loss + kl) / 2 of the pass `mode` (task_trainer.py:300-302 / 320-323) -> gradients of its trainable adapter."""
+        S, g, hd, H = self.acts[mode], self.g, self.head, self.H
+        L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
+                          S["loss"])
+        R = self.R
+        # LM head backward (frozen): logits = LN(gelu(dense(h))) W_emb^T
+        L.gemm_bf16_nt(g["dlogits"], hd["wT"], L.EPI_BF16, out_bf16=g["b1"][:R])
+        L.layernorm_bwd_dx(S["tg"], S["tst"], hd["lng"], R, H, dy_bf16=g["b1"][:R], out_f32=g["d1"][:R])
+        L.gelu_bwd(S["tu"], g["d1"][:R], g["d2"][:R])
+        L.cvt_f32_bf16(g["d2"][:R], g["b1"][:R])
+        L.gemm_bf16_nt(g["b1"][:R], hd["t"]["wT"], L.EPI_F32, out_f32=g["d1"][:R])
+        L.gather_rows(g["d1"][:R], self.unsel_idx, dst_f32=g["d_dec"])          # zero rows at the last position of each answer
+        g["d_rep"].zero_()
+        self._bert_bwd(self.dec, S["dec"], self.vd + self.el, mode, self.Ma, self.N, self.La, self.amask8, True,
+                       S["enc_rep16"], self.Lq, self.Lq, self.qmask8_rep, g["d_dec"], g["d_rep"])
+        # question states were repeated per answer: sum the answers of each question back (rows = [N, Lq * H])
+        L.segment_sum_rows(g["d_rep"].view(self.N, self.Lq * H), self.seg_off, g["d_qs"].view(self.B, self.Lq * H))
+        g["d_img"].zero_()
+        self._bert_bwd(self.enc, S["enc"], self.vd, mode, self.Mq, self.B, self.Lq, self.qmask8, False, S["vit"]["emb16"],
+                       self.Ni, self.Ni, None, g["d_qs"], g["d_img"])
+        self._vit_bwd(S, mode, g["d_img"])
+
+    # ------------------------------------------------------------------------------------------ train step
+    def begin_local_update(self, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,
+                           opt_adapters: Sequence[int] = (0, 1)):
+        """TaskTrainer.train prologue (task_trainer.py:36-59): teacher snapshot, fresh AdamW state and schedule."""
+        self.copy_global_to_teacher()
+        total = steps_per_epoch * num_epochs
+        self.sched = dict(total=total, warmup=int(total * warmup_ratio))
+        self.opt_adapters = tuple(opt_adapters)
+        for grp in (self.ad[0], self.ad[1]):
+            grp.m.zero_()
+            grp.v.zero_()
+            grp.g.zero_()
+        self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))       # adapter_1 is stepped at tick 2b
+        self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))       # adapter_0 at tick 2b + 1
+
+    def _adamw(self, grp: FlatGroup):
+        if not hasattr(grp, "_wdv"):
+            grp._wdv = grp.seg_wd * self.wd
+        L.adamw_flat(grp.p, grp.g, grp.m, grp.v, grp.seg_off, grp._wdv, grp.state, self.lr, self.sched["warmup"],
+                     self.sched["total"], 0.9, 0.98, self.eps)
+
+    def train_step(self, batch: Optional[Dict] = None):
+        """One DAT + MKD step; returns the device buffer {loss_0, kl_0, L_0} of the P2 pass (the reference returns loss_0)."""
+        if batch is not None:
+            self.set_batch(batch)
+        logits_g = self._forward("gating")                   # P0 == P2 forward (task_trainer.py:283-287,311-315)
+        logits_1 = self._forward("adapter_1")                # P1 (task_trainer.py:290-295)
+        self._backward("adapter_1", logits_g)                # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
+        self._backward("gating", logits_1)                   # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
+        if 1 in self.opt_adapters:
+            self._adamw(self.ad[1])
+            self.repack_adapter(1)
+        L.step_tick(self.ad[1].state, 2, 1)
+        if 0 in self.opt_adapters:
+            self._adamw(self.ad[0])
+            self.repack_adapter(0)
+        L.step_tick(self.ad[0].state, 2, 1)
+        return self.acts["gating"]["loss"]
+
+    # ------------------------------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def forward_train_logits(self, batch: Dict, mode: str):
+        """-> (loss, logits [N, La-1, V]) of ALBEF.forward(train=True) in adapter mode `mode` ('gating' | 'adapter_k')."""
+        self.set_batch(batch)
+        key = "gating" if mode == "gating" else "adapter_1"          # activation set whose buffers the pass uses
+        S = self.acts[key]
+        self.acts[mode] = S
+        try:
+            logits = self._forward(mode)
+        finally:
+            if mode != key:
+                del self.acts[mode]
+        L.lm_loss_fwd_bwd(logits, None, self.labels, self.row_w, self.V, 3.0, 0.0, None, S["loss"])
+        return S["loss"][0].clone(), logits[:, :self.V].reshape(self.N, self.La - 1, self.V).clone()
+
+    def image_embeds(self, mode_key: str = "gating"):
+        """fp32 image_embeds of the last forward in that activation set (final-norm output recomputed from its input)."""
+        V = self.acts[mode_key]["vit"]
+        out = torch.empty(self.Mi, self.H, device=self.dev)
+        L.layernorm_fwd(V["out"], self.vit["ng"], self.vit["nb"], 1e-6, self.Mi, self.H, y_f32=out)
+        return out.view(self.B, self.Ni, self.H)
+
+    # ------------------------------------------------------------------------------------------ state dict
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {n: grp.view(n) for grp in self.ad for n in grp.names}
+
+    def load_tensors(self, tensors: Dict[str, torch.Tensor]):
+        sd = self.state_dict()
+        touched = set()
+        for n, v in tensors.items():
+            sd[n].copy_(v.to(self.dev, torch.float32))
+            touched.update(a for a in range(3) if f"adapter_{a}_" in n)
+        for a in touched:
+            self.repack_adapter(a)
+
+    def comm_flat(self) -> torch.Tensor:
+        """The FedAvg payload: all adapter_1 tensors of the 30 modules back-to-back (2 236 320 floats = 8.95 MB)."""
+        return self.ad[1].p

@@ -16,13 +16,14 @@ __global__ __launch_bounds__(256) void axpby3_kernel(const float* __restrict__ a
     if (out16) reinterpret_cast<bf16x4*>(out16)[i] = cvt4(v);
 }
 
-// dst[r] = src[idx[r]] (fp32 rows of `width` floats, width % 4 == 0), optional bf16 copy
+// dst[r] = src[idx[r]] (fp32 rows of `width` floats, width % 4 == 0; idx < 0 -> a zero row), optional bf16 copy
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
                                                           float* __restrict__ dst, bf16* __restrict__ dst16, int width) {
     const int r = blockIdx.x;
-    const float* s = src + (size_t)idx[r] * width;
+    const int j = idx[r];
+    const float* s = src + (size_t)(j < 0 ? 0 : j) * width;
     for (int c = threadIdx.x * 4; c < width; c += 1024) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(s + c);
+        const f32x4 v = j < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(s + c);
         if (dst) *reinterpret_cast<f32x4*>(dst + (size_t)r * width + c) = v;
         if (dst16) *reinterpret_cast<bf16x4*>(dst16 + (size_t)r * width + c) = cvt4(v);
     }

@@ -321,7 +321,7 @@ int feddat_layernorm_bwd_full(const float* dy, const float* x, const float* stat
  * double-LayerNorm adapter variant (src/modeling/models/adapter.py:97-116): y + inp = (dense + inp) + (A(x) + x) - x. */
 int feddat_axpby3(const float* a, float alpha, const float* b, float beta, const float* c, float gamma, float* out_f32,
                   void* out_bf16, long n, hipStream_t stream);
-/* dst[r] = src[idx[r]] (rows of `width` floats; one question's states repeated for each of its k answers,
+/* dst[r] = src[idx[r]], a zero row for idx[r] < 0 (rows of `width` floats; one question's states repeated for each of its k answers,
  * albef_model.py:93-98) and its adjoint over contiguous segments: dst[s] (+)= sum of src rows [off[s], off[s+1]). */
 int feddat_gather_rows(const float* src, const int* idx, float* dst_f32, void* dst_bf16, int rows, int width,
                        hipStream_t stream);

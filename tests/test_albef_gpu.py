@@ -1,0 +1,89 @@
+"""ALBEF dual-adapter path (configs[3]) on the MI355X engine against the CPU oracle and the reference's own numbers
+(tests/golden/g10_albef_*.npz).  Tolerances as for ViLT: bf16 MFMA compute with fp32 accumulation / residual streams /
+master weights -- logits (O(1), 30 522-way) within 5e-2 abs, the scalar loss within 3e-3 relative, trainable tensors on
+the UPDATE: |ddW|.max() < 1e-3 and |ddW|.mean() <= 0.1 |dW_ref|.mean() per tensor."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import albef_oracle as A
+from tests.golden_util import load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SMALL = dict(vit_depth=2, enc_layers=3, fusion_layer=1, dec_layers=2, image=64, vocab=3072, max_pos=64)
+
+
+def _dev(b):
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import albef_engine
+    return albef_engine
+
+
+def _small_engine(eng_mod, P, B, N, q_len, a_len):
+    return eng_mod.AlbefDatEngine(P, DEV, batch=B, n_answers=N, q_len=q_len, a_len=a_len, vit_depth=SMALL["vit_depth"],
+                                  enc_layers=SMALL["enc_layers"], fusion_layer=SMALL["fusion_layer"],
+                                  dec_layers=SMALL["dec_layers"], image=SMALL["image"], vocab=SMALL["vocab"])
+
+
+def test_small_forward_three_modes_vs_reference_and_oracle(eng_mod, golden_dir):
+    g = load(golden_dir, "g10_albef_small.npz")
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    eng = _small_engine(eng_mod, P, 3, 6, 12, 5)
+    b0 = A.synthetic_batch(3, d, 500, q_len=12, a_len=5, k=[2, 1, 3], ragged=True)
+    for mode in ("gating", "adapter_1", "adapter_0"):
+        loss, logits = eng.forward_train_logits(_dev(b0), mode)
+        ref_loss, ref_logits = float(g[f"fwd.{mode}.loss"]), torch.from_numpy(g[f"fwd.{mode}.logits"])
+        assert (logits.cpu() - ref_logits).abs().max() < 5e-2, mode
+        assert abs(float(loss) - ref_loss) < 3e-3 * ref_loss, (mode, float(loss), ref_loss)
+        with torch.no_grad():
+            ol, olg = A.albef_train_forward(P, d, b0, mode)
+        assert (logits.cpu() - olg).abs().max() < 5e-2 and abs(float(loss) - float(ol)) < 3e-3 * float(ol)
+    img = eng.image_embeds("gating")
+    assert (img.cpu() - torch.from_numpy(g["fwd.gating.image_embeds"])).abs().max() < 5e-2
+
+
+def test_small_train_steps_vs_reference_and_oracle(eng_mod, golden_dir):
+    """4 train_steps on every code path (ragged questions / answers, k = [2, 1, 3], weights != 1): losses and the update of
+    every adapter_0 / adapter_1 tensor of the three towers, against the reference's run (G10) and the oracle."""
+    g = load(golden_dir, "g10_albef_small.npz")
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    P0 = {k: v.clone() for k, v in P.items()}
+    eng = _small_engine(eng_mod, P, 3, 6, 12, 5)
+    client = A.AlbefDatClient(P, d, lr=1e-4, steps_per_epoch=4)
+    eng.begin_local_update(steps_per_epoch=4)
+    for s in range(4):
+        b = A.synthetic_batch(3, d, 510 + s, q_len=12, a_len=5, k=[2, 1, 3], ragged=True)
+        ref = float(client.train_step(b))
+        out = eng.train_step(_dev(b))
+        torch.cuda.synchronize()
+        assert abs(float(out[0]) - ref) < 3e-3 * ref, (s, float(out[0]), ref)
+        assert abs(float(out[0]) - float(g["losses"][s])) < 3e-3 * ref
+        assert abs(float(out[2]) - client.last_L0) < 3e-3 * abs(client.last_L0)
+        assert abs(float(eng.acts["adapter_1"]["loss"][2]) - client.last_L1) < 3e-3 * abs(client.last_L1)
+    sd = eng.state_dict()
+    worst_max, worst_ratio = 0.0, 0.0
+    for k in A.trainable_names(P, 0) + A.trainable_names(P, 1):
+        d_ref, d_got = P[k] - P0[k], sd[k].cpu() - P0[k]
+        err, move = (d_got - d_ref).abs(), float(d_ref.abs().mean())
+        assert float(err.max()) < 1e-3, (k, float(err.max()))
+        assert float(err.mean()) <= 0.1 * move, (k, float(err.mean()), move)
+        assert float(d_got.abs().max()) > 0
+        worst_max, worst_ratio = max(worst_max, float(err.max())), max(worst_ratio, float(err.mean()) / move)
+        # and against the reference's own sampled updates
+        dw = d_got.flatten()
+        idx = torch.linspace(0, dw.numel() - 1, min(512, dw.numel())).long()
+        e2 = (dw[idx] - torch.from_numpy(g["dsamp::" + k])).abs()
+        assert float(e2.max()) < 1e-3 and float(e2.mean()) <= 0.1 * float(g["dmean::" + k]), k
+    for k in sd:
+        if "adapter_2" in k:
+            assert torch.equal(sd[k].cpu(), P[k]), k           # frozen teacher = adapter_1 at the start of the round
+    print(f"ALBEF small, 4 steps: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f}")
