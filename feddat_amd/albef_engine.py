@@ -505,6 +505,46 @@ class AlbefDatEngine:
         L.lm_loss_fwd_bwd(logits, None, self.labels, self.row_w, self.V, 3.0, 0.0, None, S["loss"])
         return S["loss"][0].clone(), logits[:, :self.V].reshape(self.N, self.La - 1, self.V).clone()
 
+    @torch.no_grad()
+    def rank_answer(self, batch: Dict, answer_ids: torch.Tensor, answer_mask: torch.Tensor, k: int, mode: str = "gating"):
+        """ALBEF.forward(train=False) -> rank_answer (albef_model.py:147-156,171-228; eval loop task_trainer.py:159-204):
+        first-token shortlist of k candidates per question out of the answer list, re-ranked by sequence likelihood.
+        The engine must have been built with n_answers = B * k and a_len = answer_ids.shape[1].
+        Returns (topk_ids [B,k] int64, topk_probs [B,k]).  The two decoder passes run on the HIP kernels; the top-k
+        selections and the k-way softmax over B x k scalars are index bookkeeping done with torch on the device."""
+        B, N, La, V = self.B, self.N, self.La, self.V
+        if N != B * k or answer_ids.shape[1] != La:
+            raise L.FeddatHipError("rank_answer: engine must be built with n_answers = B * k and a_len = answer length")
+        answer_ids, answer_mask = answer_ids.to(self.dev), answer_mask.to(self.dev)
+        key = "gating" if mode == "gating" else "adapter_1"
+        S = self.acts[key]
+        self.acts[mode] = S
+        try:
+            # pass 1: [BOS] only (later positions are padding; the causal mask keeps position 0 blind to them)
+            start = torch.full((N, La), self.pad_id, dtype=torch.int64, device=self.dev)
+            start[:, 0] = answer_ids[0, 0]
+            m0 = torch.zeros(N, La, dtype=torch.int64, device=self.dev)
+            m0[:, 0] = 1
+            self.set_batch(dict(batch, answer_ids=start, answer_mask=m0, weights=torch.ones(N, device=self.dev), k=[k] * B))
+            logits = self._forward(mode).view(N, La - 1, self.Vp)[::k, 0, :V]        # position 0 of one slot per question
+            prob_first = torch.softmax(logits, 1).index_select(1, answer_ids[:, 1])
+            topk_probs, topk_ids = prob_first.topk(k, 1)
+            # pass 2: the shortlisted answers, per-answer next-token loss
+            ids = answer_ids.index_select(0, topk_ids.reshape(-1))
+            atts = answer_mask.index_select(0, topk_ids.reshape(-1))
+            self.set_batch(dict(batch, answer_ids=ids, answer_mask=atts, weights=torch.full((N,), float(B), device=self.dev),
+                                k=[k] * B))
+            lg = self._forward(mode)
+            L.lm_loss_fwd_bwd(lg, None, self.labels, self.row_w, V, 3.0, 0.0, None, S["loss"])
+            answer_loss = S["loss"][4:4 + 2 * self.R:2].view(N, La - 1).sum(1)       # row_terms[2 r] = ce of row r (weight 1)
+        finally:
+            if mode != key:
+                del self.acts[mode]
+        log_probs = (topk_probs.reshape(-1).log() - answer_loss).view(B, k)
+        probs = torch.softmax(log_probs, -1)
+        probs, rerank = probs.topk(k, 1)
+        return torch.gather(topk_ids, 1, rerank), probs
+
     def image_embeds(self, mode_key: str = "gating"):
         """fp32 image_embeds of the last forward in that activation set (final-norm output recomputed from its input)."""
         V = self.acts[mode_key]["vit"]

@@ -87,3 +87,59 @@ def test_small_train_steps_vs_reference_and_oracle(eng_mod, golden_dir):
         if "adapter_2" in k:
             assert torch.equal(sd[k].cpu(), P[k]), k           # frozen teacher = adapter_1 at the start of the round
     print(f"ALBEF small, 4 steps: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f}")
+
+
+def test_rank_answer_eval_vs_reference_golden(eng_mod, golden_dir):
+    """ALBEF.rank_answer (albef_model.py:171-228): shortlist by first-token probability, re-rank by sequence likelihood."""
+    g = load(golden_dir, "g10_albef_small.npz")
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    k = 4
+    eng = _small_engine(eng_mod, P, 3, 3 * k, 12, 5)
+    b0 = A.synthetic_batch(3, d, 500, q_len=12, a_len=5, k=[2, 1, 3], ragged=True)
+    ev = A.synthetic_batch(3, d, 501, q_len=12, a_len=5, k=[4, 4, 3], ragged=True)
+    qb = {kk: b0[kk] for kk in ("image", "question_ids", "question_mask")}
+    ids, probs = eng.rank_answer(_dev(qb), ev["answer_ids"], ev["answer_mask"], k)
+    ref_ids, ref_probs = g["eval.topk_ids"], torch.from_numpy(g["eval.topk_probs"])
+    # ranks are only comparable where the reference's probabilities are separated by more than the bf16 noise
+    gaps = (ref_probs[:, :-1] - ref_probs[:, 1:]).min()
+    assert (probs.cpu().sort(1, descending=True).values - ref_probs).abs().max() < 2e-2
+    if float(gaps) > 4e-2:
+        assert np.array_equal(ids.cpu().numpy(), ref_ids)
+    else:
+        assert np.array_equal(np.sort(ids.cpu().numpy(), 1), np.sort(ref_ids, 1))      # same shortlist
+
+
+def test_full_size_albef_vs_reference_golden(eng_mod, golden_dir):
+    """The real architecture (ViT-B/16 at 384 x 384 = 577 tokens, BERT-base 12 + 6 layers, 30 522-way LM head), B = 2:
+    forward in two modes and 2 train_steps against the reference's own numbers (G10 full)."""
+    g = load(golden_dir, "g10_albef_full.npz")
+    d = A.AlbefDims()
+    P = A.make_params(d)
+    eng = eng_mod.AlbefDatEngine(P, DEV, batch=2, n_answers=2)
+    b0 = A.synthetic_batch(2, d, 600)
+    for mode in ("gating", "adapter_1"):
+        loss, logits = eng.forward_train_logits(_dev(b0), mode)
+        lg = logits.flatten().cpu()
+        samp = lg[torch.linspace(0, lg.numel() - 1, 4096).long()]
+        assert (samp - torch.from_numpy(g[f"fwd.{mode}.logits_samp"])).abs().max() < 8e-2, mode
+        assert abs(float(lg.norm()) - float(g[f"fwd.{mode}.logits_norm"])) < 5e-3 * float(g[f"fwd.{mode}.logits_norm"])
+        assert abs(float(loss) - float(g[f"fwd.{mode}.loss"])) < 3e-3 * float(g[f"fwd.{mode}.loss"])
+    eng.begin_local_update(steps_per_epoch=2, num_epochs=1)
+    for s in range(2):
+        out = eng.train_step(_dev(A.synthetic_batch(2, d, 610 + s)))
+        ref = float(g["losses"][s])
+        assert abs(float(out[0]) - ref) < 3e-3 * ref, (s, float(out[0]), ref)
+    sd = eng.state_dict()
+    worst_max, worst_ratio, n = 0.0, 0.0, 0
+    for gk in [k for k in g if k.startswith("dsamp::")]:
+        k = gk.split("::", 1)[1]
+        dw = (sd[k].cpu() - P[k]).flatten()
+        idx = torch.linspace(0, dw.numel() - 1, min(256, dw.numel())).long()
+        err = (dw[idx] - torch.from_numpy(g[gk])).abs()
+        move = float(g["dmean::" + k])
+        assert float(err.max()) < 1e-3, (k, float(err.max()))
+        assert float(err.mean()) <= 0.15 * move + 1e-9, (k, float(err.mean()), move)
+        worst_max, worst_ratio, n = max(worst_max, float(err.max())), max(worst_ratio, float(err.mean()) / max(move, 1e-12)), n + 1
+    assert n == 2 * 4 * 30
+    print(f"ALBEF full size, 2 steps: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f} over {n} tensors")
