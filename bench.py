@@ -177,6 +177,60 @@ def cpu_baseline(params_cpu, batches_cpu, B, res, task, timed_steps=3):
                        f"(best of the sweep)")
 
 
+def bench_albef(args, world, rank, dev, dist):
+    """configs[3]: one ALBEF dual-adapter + MKD train_step per step (eager launches: this engine has no graph capture yet);
+    with N clients the timed region ends with the FedAvg all-reduce of the 8.95 MB adapter_1 payload."""
+    from feddat_amd import albef_engine, albef_spec
+    from feddat_amd.fedavg import allreduce_average
+    B = args.batch
+    params = albef_spec.random_init(seed=0, image=args.res)
+    eng = albef_engine.AlbefDatEngine(params, dev, batch=B, n_answers=B, image=args.res)
+    batches = [albef_spec.synthetic_batch(B, 1234 + 100 * rank + i, image=args.res, device=dev) for i in range(2)]
+    eng.begin_local_update(steps_per_epoch=max(args.steps + args.warmup, 40))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        eng.train_step(batches[i % 2])
+    if dist is not None:
+        allreduce_average(eng, world)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(batches[i % 2])
+    if dist is not None:
+        allreduce_average(eng, world)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss = float(eng.acts["gating"]["loss"][0])
+    if not (loss == loss):
+        raise RuntimeError("non-finite loss")
+    if rank == 0:
+        Ni = eng.Ni
+        # executed FLOPs per sample: 2 ViT forwards + 2 backwards (dX only, weight grads of the adapters only) dominate
+        vit_fwd = 12 * (2.0 * Ni * 768 * (3 * 768 + 768 + 2 * 3072) + 4.0 * Ni * Ni * 768)
+        flops = 2 * vit_fwd + 2 * (vit_fwd * 11 / 12 + 12 * 4.0 * Ni * Ni * 768 * 1.5)
+        sps = world * B * args.steps / dt
+        print(json.dumps({
+            "metric": "VQA samples/sec, ALBEF dual-adapter local step", "value": round(sps, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[3]: ALBEF (ViT-B/16 577 tokens + BERT-base 12 + 6 layers) dual-adapter + MKD, "
+                                   f"batch={B}/client, {args.res}x{args.res}, 25-token questions, one 4-token answer each",
+                       "clients": world, "hip_graph": False, "last_loss_0": round(loss, 4)},
+            "mfma_frac_vit_flops_only": round(flops * B * args.steps / dt / PEAK_BF16, 4)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +238,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--res", type=int, default=384)
+    ap.add_argument("--workload", default="vilt", choices=["vilt", "albef"],
+                    help="vilt = configs[1] / configs[2] (the headline metric); albef = configs[3]: ALBEF (ViT-B/16 + BERT-base) "
+                         "dual-adapter + MKD step, 25-token questions, one 4-token answer per question")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -224,6 +281,8 @@ def main():
     from feddat_amd import engine, lib as L, vilt_spec
     from feddat_amd.fedavg import allreduce_average
     dev = torch.device("cuda", local)
+    if args.workload == "albef":
+        return bench_albef(args, world, rank, dev, dist)
     B, res = args.batch, args.res
     tasks = [f"client{r}" for r in range(world)]
     task = tasks[rank]

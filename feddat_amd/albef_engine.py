@@ -30,7 +30,8 @@ ADAPTER_TENSORS = ("down.weight", "down.bias", "up.weight", "up.bias")
 class AlbefDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], device, batch: int, n_answers: int, q_len: int = 25, a_len: int = 4,
                  vit_depth: int = 12, enc_layers: int = 12, fusion_layer: int = 6, dec_layers: int = 6, image: int = 384,
-                 vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0):
+                 vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0,
+                 max_pos: int = 512):
         L.load()
         self.dev = dev = torch.device(device)
         self.B, self.N, self.Lq, self.La = batch, n_answers, q_len, a_len
@@ -241,6 +242,9 @@ class AlbefDatEngine:
             if tuple(src.shape) != tuple(self.inp[k].shape):
                 raise L.FeddatHipError(f"engine built for {k} {tuple(self.inp[k].shape)}, got {tuple(src.shape)}")
             self.inp[k].copy_(src, non_blocking=True)
+        for k in ("question_ids", "answer_ids"):        # an out-of-range id would fault in the embedding gather; host
+            if not batch[k].is_cuda and int(batch[k].max()) >= self.V:          # batches are checked (device ones: no sync)
+                raise L.FeddatHipError("token id outside the vocabulary")
         ks = list(batch["k"])
         if len(ks) != self.B or sum(ks) != self.N:
             raise L.FeddatHipError("k must list the answers per question and sum to the engine's n_answers")

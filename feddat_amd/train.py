@@ -151,11 +151,48 @@ class TaskTrainer:
         return [s, s0, s1]
 
 
+class AlbefTaskTrainer(TaskTrainer):
+    """The same trainer driving the ALBEF model (encoder_name albef_no_distill: task_trainer.py:250-264,296-297,316-317;
+    eval with answer ranking :159-204).  Batches are the tokenised dicts of feddat_amd.albef_spec.synthetic_batch."""
+
+    def train(self, model, *unused):
+        eng = model.engine
+        optimizer = self.create_optimizer(model, self.args.optimizer_mode)
+        eng.lr, eng.eps, eng.wd = optimizer.lr, optimizer.eps, optimizer.weight_decay
+        eng.begin_local_update(steps_per_epoch=len(self.vqa_train_dataloader), num_epochs=self.num_epochs,
+                               warmup_ratio=self.warmup_ratio, opt_adapters=optimizer.adapters)
+        model.adapter_requires_grad[2] = False
+        for epoch in range(self.local_epochs):
+            for step, batch in enumerate(self.vqa_train_dataloader):
+                if self.args.debug > 0 and step > self.args.debug:
+                    break
+                self.train_step(model, step, batch, optimizer, None, hooks=None, epoch=epoch)
+        return 0.0, model
+
+    def train_step(self, model, step, batch, optimizer=None, scheduler=None, hooks=None, epoch=None):
+        out = model.engine.train_step(batch)
+        model.activate_gating()
+        model.set_active_adapter("adapter_0")
+        return out[0]
+
+    @torch.no_grad()
+    def eval_one_loader(self, model, loader) -> float:
+        """task_trainer.py:159-204: the top re-ranked answer must be one of the ground-truth answer indices."""
+        hit, seen = 0, 0
+        for batch in loader:
+            ids, probs = model(self.task_key, dict(batch, train=False))
+            pred = ids.gather(1, probs.argmax(1, keepdim=True)).squeeze(1).cpu()
+            for p, gt in zip(pred.tolist(), batch["gts"]):
+                hit += int(p in set(int(x) for x in gt))
+                seen += 1
+        return 100.0 * hit / max(seen, 1)
+
+
 # -------------------------------------------------------------------------------------------------------------
 def build_parser() -> argparse.ArgumentParser:
     """Same flags as src/train/main.py:262-323 (unused ones are accepted and ignored) + synthetic-data knobs."""
     p = argparse.ArgumentParser()
-    p.add_argument("--encoder_name", default="vilt", choices=["vilt"])
+    p.add_argument("--encoder_name", default="vilt", choices=["vilt", "albef_no_distill"])
     p.add_argument("--portion", default=1.0, type=float)
     p.add_argument("--optimizer_mode", default="dat", type=str)
     p.add_argument("--pretrained_model_name", default=None, type=str)
@@ -189,6 +226,8 @@ def build_parser() -> argparse.ArgumentParser:
                         "(heterogeneous len(loader), e.g. 40,50,60,70,80,45,55,65 for 8 clients)")
     p.add_argument("--image_size", type=int, default=384)
     p.add_argument("--num_layers", type=int, default=12)
+    p.add_argument("--albef_dims", type=str, default="",
+                   help="ALBEF only: override depths for quick runs, e.g. vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2")
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
     p.add_argument("--save_every", type=int, default=0,
                    help="write <output_dir>/round state every N rounds (0 = never, like the reference); "
@@ -232,16 +271,32 @@ def main(argv=None):
     steps_list = [int(x) for x in str(args.synthetic_steps).split(",")]
     steps_of = {t: steps_list[i % len(steps_list)] for i, t in enumerate(tasks)}
     dev = torch.device("cuda", local)
-    params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)    # stand-in for from_pretrained
-    model = create_vilt_continual_learner_model(params, tasks, dev, args.batch_size, args.image_size,
-                                                args.num_layers, args.lr)
+    albef = "albef" in args.encoder_name
+    if albef:
+        from . import albef_spec
+        from .albef_modeling import create_albef_continual_learner_model
+        dims = {k: int(v) for k, v in (kv.split("=") for kv in args.albef_dims.split(",") if kv)}
+        params = albef_spec.random_init(seed=args.seed, image=args.image_size, **dims)   # stand-in for ALBEF.pth
+        model = create_albef_continual_learner_model(params, dev, args.batch_size, args.batch_size, lr=args.lr,
+                                                     image=args.image_size, **dims)
+        Trainer = AlbefTaskTrainer
+    else:
+        params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)    # stand-in for from_pretrained
+        model = create_vilt_continual_learner_model(params, tasks, dev, args.batch_size, args.image_size,
+                                                    args.num_layers, args.lr)
+        Trainer = TaskTrainer
     eng = model.engine
     # personal parameters per client (main.py:440-450): head + adapter_0 + adapter_2
     def personal(sd):
         return {n: v.clone() for n, v in sd.items() if ("task" in n or "adapter_0" in n or "adapter_2" in n)}
     personal_params = {t: personal(model.state_dict()) for t in my_tasks}
-    data = {t: [vilt_spec.synthetic_batch(args.batch_size, args.image_size, args.seed + 1000 * ti + s, device=dev)
-                for s in range(steps_of[t])] for ti, t in enumerate(tasks) if t in my_tasks}
+    def make_batch(seed):
+        if albef:
+            return albef_spec.synthetic_batch(args.batch_size, seed, image=args.image_size, vocab=dims.get("vocab", 30522),
+                                              device=dev)
+        return vilt_spec.synthetic_batch(args.batch_size, args.image_size, seed, device=dev)
+    data = {t: [make_batch(args.seed + 1000 * ti + s) for s in range(steps_of[t])] for ti, t in enumerate(tasks)
+            if t in my_tasks}
     server_flat = eng.comm_flat().clone()
     acc = torch.zeros_like(server_flat)
     comm_names = model.comm_state_dict_names
@@ -265,7 +320,7 @@ def main(argv=None):
             eng.repack_adapter(1)
             model.load_state_dict(personal_params[task_key])        # main.py:473-478
             model.adapter_requires_grad = dict(server_flags)
-            trainer = TaskTrainer(args, task_key, data[task_key], data[task_key][:2], log)
+            trainer = Trainer(args, task_key, data[task_key], data[task_key][:2], log)
             trainer.train(model, comm_round)
             personal_params[task_key] = personal(model.state_dict())     # main.py:493-497
             # local pre-sum in client order, then (if distributed) one all-reduce: main.py:50-65
@@ -284,12 +339,12 @@ def main(argv=None):
                 dist.barrier()          # every rank's personal files are on disk before round.json appears
             if rank == 0:
                 flags_after = dict(server_flags)
-                if comm_round % 5 == 0 or comm_round == args.comm_rounds - 1:
+                if (comm_round % 5 == 0 or comm_round == args.comm_rounds - 1) and not albef:
                     flags_after.update({0: False, 1: True})         # the eval below leaves the server in this state
                 checkpoint.save_federation(args.output_dir, {n: sd[n] for n in comm_names}, {}, comm_round,
                                            server_flags=flags_after)
-        if comm_round % 5 == 0 or comm_round == args.comm_rounds - 1:   # main.py:520
-            for task_key in my_tasks:
+        if (comm_round % 5 == 0 or comm_round == args.comm_rounds - 1) and not albef:   # main.py:520 (ALBEF: the synthetic
+            for task_key in my_tasks:                                                     # stand-in has no answer list)
                 eng.comm_flat().copy_(server_flat)
                 model.load_state_dict(personal_params[task_key])
                 model.after_load()

@@ -143,3 +143,36 @@ def test_full_size_albef_vs_reference_golden(eng_mod, golden_dir):
         worst_max, worst_ratio, n = max(worst_max, float(err.max())), max(worst_ratio, float(err.mean()) / max(move, 1e-12)), n + 1
     assert n == 2 * 4 * 30
     print(f"ALBEF full size, 2 steps: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f} over {n} tensors")
+
+
+def test_albef_api_mirror_and_federated_main(tmp_path):
+    """The drop-in mirrors: ALBEFContinualLearner mode switches + forward (albef.py:139-193), and feddat_amd.train.main with
+    --encoder_name albef_no_distill (train_albef.sh): 2 clients, 1 round, FedAvg of the 30-module adapter_1 payload."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import albef_modeling, albef_spec, train
+    dims = dict(vit_depth=2, enc_layers=3, fusion_layer=1, dec_layers=2, vocab=3072, max_pos=64)
+    P = albef_spec.random_init(seed=3, image=64, **dims)
+    m = albef_modeling.create_albef_continual_learner_model(P, DEV, 2, 2, q_len=10, a_len=4, image=64, **dims)
+    assert len(m.comm_state_dict_names) == 4 * (2 + 3 + 2) and all("adapter_1" in n for n in m.comm_state_dict_names)
+    b = albef_spec.synthetic_batch(2, 9, image=64, q_len=10, a_len=4, vocab=3072, device=DEV)
+    outs = {}
+    for gating, active in ((True, "adapter_0"), (False, "adapter_1"), (False, "adapter_0")):
+        (m.activate_gating if gating else m.deactivate_gating)()
+        m.set_active_adapter(active)
+        loss, logits = m("art", dict(b, train=True))
+        assert logits.shape == (2, 3, 3072) and torch.isfinite(logits).all() and float(loss) > 0
+        outs[(gating, active)] = logits.clone()
+    assert not torch.equal(outs[(False, "adapter_1")], outs[(False, "adapter_0")])
+    assert m.optimizer_adapters() == (0,)                  # set_active_adapter('adapter_0') froze adapter_1 (adapter.py:66-75)
+    common = ["--encoder_name", "albef_no_distill", "--ordered_cl_tasks", "art,gqa", "--image_size", "64", "--batch_size", "2",
+              "--synthetic_steps", "2", "--comm_rounds", "1", "--albef_dims",
+              "vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2,vocab=3072,max_pos=64", "--save_every", "1",
+              "--output_dir", str(tmp_path / "albef")]
+    model = train.main(common)
+    sd = model.state_dict()
+    from safetensors.torch import load_file
+    srv = load_file(str(tmp_path / "albef" / "server_adapter.safetensors"))
+    assert len(srv) == 28 and all(torch.equal(v, sd[k].cpu()) for k, v in srv.items())
+    init = albef_spec.random_init(seed=42, image=64, **dims)
+    assert max(float((sd[k].cpu() - init[k]).abs().max()) for k in srv) > 0       # the averaged adapter moved
