@@ -178,8 +178,7 @@ def cpu_baseline(params_cpu, batches_cpu, B, res, task, timed_steps=3):
 
 
 def bench_albef(args, world, rank, dev, dist):
-    """configs[3]: one ALBEF dual-adapter + MKD train_step per step (eager launches: this engine has no graph capture yet);
-    with N clients the timed region ends with the FedAvg all-reduce of the 8.95 MB adapter_1 payload."""
+    """configs[3]: one ALBEF dual-adapter + MKD train_step per step (one hipGraph replay); with N clients the timed region ends with the FedAvg all-reduce of the 8.95 MB adapter_1 payload."""
     from feddat_amd import albef_engine, albef_spec
     from feddat_amd.fedavg import allreduce_average
     B = args.batch
@@ -193,14 +192,15 @@ def bench_albef(args, world, rank, dev, dist):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    use_graph = not args.no_graph
     for i in range(args.warmup):
-        eng.train_step(batches[i % 2])
+        eng.train_step(batches[i % 2], use_graph=use_graph)
     if dist is not None:
         allreduce_average(eng, world)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.train_step(batches[i % 2])
+        eng.train_step(batches[i % 2], use_graph=use_graph)
     if dist is not None:
         allreduce_average(eng, world)
     barrier()
@@ -224,7 +224,7 @@ def bench_albef(args, world, rank, dev, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[3]: ALBEF (ViT-B/16 577 tokens + BERT-base 12 + 6 layers) dual-adapter + MKD, "
                                    f"batch={B}/client, {args.res}x{args.res}, 25-token questions, one 4-token answer each",
-                       "clients": world, "hip_graph": False, "last_loss_0": round(loss, 4)},
+                       "clients": world, "hip_graph": use_graph, "last_loss_0": round(loss, 4)},
             "mfma_frac_vit_flops_only": round(flops * B * args.steps / dt / PEAK_BF16, 4)}), flush=True)
     if dist is not None:
         dist.barrier()

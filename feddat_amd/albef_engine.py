@@ -129,6 +129,7 @@ class AlbefDatEngine:
             self.repack_adapter(a)
         self.sched = dict(warmup=1, total=2)
         self.opt_adapters = (0, 1)
+        self.graph = None
         self._segs_cache: Dict = {}
         self.wpart = torch.empty(L.adapter_wgrad_workspace_elems(1), device=dev)
         self._alloc()
@@ -468,6 +469,7 @@ class AlbefDatEngine:
             grp.g.zero_()
         self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))       # adapter_1 is stepped at tick 2b
         self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))       # adapter_0 at tick 2b + 1
+        self.graph = None
 
     def _adamw(self, grp: FlatGroup):
         if not hasattr(grp, "_wdv"):
@@ -475,10 +477,7 @@ class AlbefDatEngine:
         L.adamw_flat(grp.p, grp.g, grp.m, grp.v, grp.seg_off, grp._wdv, grp.state, self.lr, self.sched["warmup"],
                      self.sched["total"], 0.9, 0.98, self.eps)
 
-    def train_step(self, batch: Optional[Dict] = None):
-        """One DAT + MKD step; returns the device buffer {loss_0, kl_0, L_0} of the P2 pass (the reference returns loss_0)."""
-        if batch is not None:
-            self.set_batch(batch)
+    def _step_kernels(self):
         logits_g = self._forward("gating")                   # P0 == P2 forward (task_trainer.py:283-287,311-315)
         logits_1 = self._forward("adapter_1")                # P1 (task_trainer.py:290-295)
         self._backward("adapter_1", logits_g)                # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
@@ -491,7 +490,45 @@ class AlbefDatEngine:
             self._adamw(self.ad[0])
             self.repack_adapter(0)
         L.step_tick(self.ad[0].state, 2, 1)
+
+    def train_step(self, batch: Optional[Dict] = None, use_graph: bool = False):
+        """One DAT + MKD step; returns the device buffer {loss_0, kl_0, L_0} of the P2 pass (the reference returns loss_0).
+        use_graph: replay the ~3000 launches of a step as one hipGraph (the BERT towers' launches are tiny: eager mode is
+        host-bound)."""
+        if batch is not None:
+            self.set_batch(batch)
+        if not use_graph:
+            self._step_kernels()
+        else:
+            if self.graph is None:
+                self._capture()
+            self.graph.replay()
         return self.acts["gating"]["loss"]
+
+    def _capture(self):
+        """Capture the whole step into one hipGraph (static buffers; schedule and Adam counters live on the device); the
+        optimizer state is saved / restored around the warm-up + capture run so that capturing does not advance training."""
+        groups = [self.ad[0], self.ad[1]]
+        saved = [(g.p.clone(), g.m.clone(), g.v.clone(), g.state.clone()) for g in groups]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._step_kernels()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            self._step_kernels()
+        torch.cuda.synchronize()
+        for g, (p, m, v, st) in zip(groups, saved):
+            g.p.copy_(p)
+            g.m.copy_(m)
+            g.v.copy_(v)
+            g.state.copy_(st)
+        for a in (0, 1):
+            self.repack_adapter(a)
+        torch.cuda.synchronize()
+        self.graph = graph
 
     # ------------------------------------------------------------------------------------------ inference
     @torch.no_grad()

@@ -17,7 +17,9 @@ def short(n):
 
 
 # 1. kernel-trace --stats summary of one bench run
-st = "gpurun_out/prof_r1/step_kernel_stats.csv"
+st = f"gpurun_out/prof_{tag}/trace/step_kernel_stats.csv"
+if not os.path.exists(st):
+    st = "gpurun_out/prof_r1/step_kernel_stats.csv"
 if os.path.exists(st):
     rows = list(csv.DictReader(open(st)))
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
@@ -33,8 +35,10 @@ if os.path.exists(st):
 
 # 2. PMC passes: per-kernel averages
 out = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
-    p = f"gpurun_out/{d}/p_counter_collection.csv"
+for d in ("pmc_sq_wave_cycles", "pmc_fetch_size", "pmc_write_size", "pmc_sq", "pmc_fetch", "pmc_write"):
+    p = f"gpurun_out/prof_{tag}/{d}/p_counter_collection.csv"
+    if not os.path.exists(p):
+        p = f"gpurun_out/{d}/p_counter_collection.csv" if tag == "r01" else p
     if not os.path.exists(p):
         continue
     per_dispatch = collections.defaultdict(lambda: collections.defaultdict(float))
