@@ -217,6 +217,11 @@ class ViltDatEngine:
         self.wpart = f32(L.adapter_wgrad_workspace_elems(2))
         self._segs_cache: Dict = {}
         self.graph = None
+        self.ctx = L.Context(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        self._layer_structs: Dict = {}
+        # True: one composite C-ABI call per middle layer (feddat_vilt_layer_fwd / _bwd); False: the same kernel sequence
+        # issued op by op from here (what tools/step_breakdown.py brackets with events)
+        self.use_layer_calls = True
         self.sched = dict(warmup=1, total=2)
         self.opt_adapters = (0, 1)
         self.task = self.tasks[0]
@@ -349,10 +354,17 @@ class ViltDatEngine:
         else:
             L.adapter_fwd(l0["h3"], self.h_out, self._segs(0, True, False), R2, z_save=self.zsave[0])
         for i in range(1, self.nl - 1):
-            a = self.act[i]
-            self._layer_body(i, a["h_in"], R2, 2 * B, a["qkv"], a["ctx"], a["lse"], a["h2"], a["h3"], st1=a["st1"],
-                             st2=a["st2"], u=a["u"], mask=m2, ln1_done=True)
-            adapter_then_ln1(a["h3"], i, False)
+            # one C-ABI call per layer (feddat_vilt_layer_fwd): ViltLayer body + adapter + the next layer's layernorm_before
+            if not self.use_layer_calls:
+                a = self.act[i]
+                self._layer_body(i, a["h_in"], R2, 2 * B, a["qkv"], a["ctx"], a["lse"], a["h2"], a["h3"], st1=a["st1"],
+                                 st2=a["st2"], u=a["u"], mask=m2, ln1_done=True)
+                adapter_then_ln1(a["h3"], i, False)
+                continue
+            Wn = self.layers[i + 1]
+            W, A, _ = self._layer_struct(i)
+            L.vilt_layer_fwd(self.ctx, W, A, 2 * B, self.S, self.heads, self._segs(i, False, False), key_mask=m2,
+                             ln1_done=True, next_ln_g=Wn["ln1g"], next_ln_b=Wn["ln1b"])
         if self.nl > 1:
             self._top_layer_fwd(m2)
             self._pool(self.top["h_out"], 2 * B, x_stride=self.H)
@@ -489,21 +501,27 @@ class ViltDatEngine:
         else:
             L.scatter_cls_rows(self.dcls, cur, None, nb, self.S, H)
         for i in range(top - 1, 0, -1):
-            a, W = self.act[i], self.layers[i]
-            # adapter: dh3 (fp32 in `oth`, bf16 copy in dh16), z/dz for the weight gradients
-            L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
-                          dz_out=self.dz, z_saved=self.zsave[i])
-            self._adapter_wgrads(i, a["h3"], 0, cur)
-            # FFN2^T (+ gelu'), FFN1^T, LN2 backward (+ residual)
-            L.gemm_bf16_nt(self.dh16, W["w2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
-            L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
-            L.layernorm_bwd_dx(a["h2"], a["st2"], W["ln2g"], R2, H, dy_bf16=self.dx16, dres=oth, out_f32=cur,
-                               out_bf16=self.dh16)
-            # attention-out^T, attention backward, QKV^T, LN1 backward (+ residual)
-            L.gemm_bf16_nt(self.dh16, W["woT"], L.EPI_BF16, out_bf16=self.dctx)
-            L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=m2)
-            L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
-            L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
+            # one C-ABI call per layer (feddat_vilt_layer_bwd): adapter backward + its weight gradients, FFN2^T (. gelu'),
+            # FFN1^T, LN2 backward (+ residual), attention-out^T, attention backward, QKV^T, LN1 backward (+ residual)
+            if not self.use_layer_calls:
+                a, W = self.act[i], self.layers[i]
+                L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
+                              dz_out=self.dz, z_saved=self.zsave[i])
+                self._adapter_wgrads(i, a["h3"], 0, cur)
+                L.gemm_bf16_nt(self.dh16, W["w2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
+                L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
+                L.layernorm_bwd_dx(a["h2"], a["st2"], W["ln2g"], R2, H, dy_bf16=self.dx16, dres=oth, out_f32=cur,
+                                   out_bf16=self.dh16)
+                L.gemm_bf16_nt(self.dh16, W["woT"], L.EPI_BF16, out_bf16=self.dctx)
+                L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=m2)
+                L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
+                L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
+                cur, oth = oth, cur
+                continue
+            W, A, _ = self._layer_struct(i)
+            G = self._grad_struct(cur, oth)
+            L.vilt_layer_bwd(self.ctx, W, A, G, nb, self.S, self.heads, self._segs(i, False, True),
+                             self._wgrad_segs(i, self.act[i]["h3"], 0, cur), self.wpart, key_mask=m2)
             cur, oth = oth, cur
         # layer 0: weight gradients only (nothing trainable below)
         L.adapter_bwd(None, cur, None, self._segs(0, True, True), R2, z_out=self.z, dz_out=self.dz,
@@ -540,10 +558,30 @@ class ViltDatEngine:
         L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
         L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
 
-    def _adapter_wgrads(self, layer: int, x, x_delta_s: int, dy):
-        """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146)
-        for adapter_0 (rows [0,R)) and adapter_1 (rows [R,2R)): exact fp32 MFMA, split over tokens, deterministic
-        reduction straight into the flat gradient buffers."""
+    def _layer_struct(self, i: int):
+        """ctypes views of layer i's frozen weights and static activation buffers for the composite entry points."""
+        if i not in self._layer_structs:
+            Wd, a = self.layers[i], self.act[i]
+            R2 = 2 * self.R
+            W = L._fill(L.ViltLayerWeights, wqkv=Wd["wqkv"], wo=Wd["wo"], w1=Wd["w1"], w2=Wd["w2"], wqkvT=Wd["wqkvT"],
+                        woT=Wd["woT"], w1T=Wd["w1T"], w2T=Wd["w2T"], bqkv=Wd["bqkv"], bo=Wd["bo"], b1=Wd["b1"], b2=Wd["b2"],
+                        ln1_g=Wd["ln1g"], ln1_b=Wd["ln1b"], ln2_g=Wd["ln2g"], ln2_b=Wd["ln2b"])
+            W.ln_eps = self.ln_eps
+            nxt = self.act[i + 1] if i + 1 < self.nl else None
+            A = L._fill(L.ViltLayerActs, h_in=a["h_in"], st1=a["st1"], qkv=a["qkv"], ctx=a["ctx"], lse=a["lse"], h2=a["h2"],
+                        st2=a["st2"], u=a["u"], h3=a["h3"], z_save=self.zsave[i], h_out=nxt["h_in"] if nxt else self.h_out,
+                        x16=self.x16[:R2], f16=self.f16[:R2], st1_next=nxt["st1"] if nxt else None)
+            self._layer_structs[i] = (W, A, None)
+        return self._layer_structs[i]
+
+    def _grad_struct(self, cur, oth):
+        key = ("G", cur.data_ptr())
+        if key not in self._layer_structs:      # dh3 and dh_in share `oth`: dh3 is dead before dh_in is written
+            self._layer_structs[key] = L._fill(L.ViltLayerGrads, dh_out=cur, dh_in=oth, dh3=oth, dh16=self.dh16, dU=self.dU,
+                                               dx16=self.dx16, dctx=self.dctx, dqkv=self.dqkv, z=self.z, dz=self.dz)
+        return self._layer_structs[key]
+
+    def _wgrad_segs(self, layer: int, x, x_delta_s: int, dy):
         key = ("wg", layer, x.data_ptr(), dy.data_ptr(), self.opt_adapters)
         if key not in self._segs_cache:
             R, n = self.R, self.ad_layer_numel
@@ -553,7 +591,13 @@ class ViltDatEngine:
                     segs.append(dict(x=x[xrow0:], dy=dy[row0:], z=self.z[row0:], dz=self.dz[row0:],
                                      grad=self.ad[a].g[layer * n:(layer + 1) * n], rows=R, scale=sc))
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
-        segs = self._segs_cache[key]
+        return self._segs_cache[key]
+
+    def _adapter_wgrads(self, layer: int, x, x_delta_s: int, dy):
+        """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146)
+        for adapter_0 (rows [0,R)) and adapter_1 (rows [R,2R)): exact fp32 MFMA, split over tokens, deterministic
+        reduction straight into the flat gradient buffers."""
+        segs = self._wgrad_segs(layer, x, x_delta_s, dy)
         if segs is not None:
             L.adapter_wgrad(segs, self.wpart)
 

@@ -30,6 +30,29 @@ class WgradSeg(C.Structure):
     _fields_ = [("x", vp), ("dy", vp), ("z", vp), ("dz", vp), ("grad", vp), ("rows", i32), ("scale", f32)]
 
 
+class ViltLayerWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("wqkv", "wo", "w1", "w2", "wqkvT", "woT", "w1T", "w2T", "bqkv", "bo", "b1", "b2", "ln1_g",
+                                  "ln1_b", "ln2_g", "ln2_b")] + [("ln_eps", f32)]
+
+
+class ViltLayerActs(C.Structure):
+    _fields_ = [(n, vp) for n in ("h_in", "st1", "qkv", "ctx", "lse", "h2", "st2", "u", "h3", "z_save", "h_out", "x16", "f16",
+                                  "st1_next")]
+
+
+class ViltLayerGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("dh_out", "dh_in", "dh3", "dh16", "dU", "dx16", "dctx", "dqkv", "z", "dz")]
+
+
+def _fill(struct, **tensors):
+    """ctypes struct of device pointers from tensors (None -> NULL); keeps the tensors alive on the struct."""
+    s = struct()
+    s._keep = tensors
+    for k, t in tensors.items():
+        setattr(s, k, (t.data_ptr() if isinstance(t, torch.Tensor) else t) if t is not None else None)
+    return s
+
+
 _SIGS = {
     "feddat_abi_version": [],
     "feddat_ctx_create": [i32, C.POINTER(vp)],
@@ -59,6 +82,10 @@ _SIGS = {
     "feddat_adapter_pack_strided": [vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "feddat_adapter_wgrad_workspace_elems": [i32],
     "feddat_adapter_wgrad": [C.POINTER(WgradSeg), i32, vp, i64, i32, i32, vp],
+    "feddat_vilt_layer_fwd": [vp, C.POINTER(ViltLayerWeights), C.POINTER(ViltLayerActs), i32, i32, i32, vp, i32,
+                              C.POINTER(AdapterSeg), i32, vp, vp, vp],
+    "feddat_vilt_layer_bwd": [vp, C.POINTER(ViltLayerWeights), C.POINTER(ViltLayerActs), C.POINTER(ViltLayerGrads), i32, i32,
+                              i32, vp, C.POINTER(AdapterSeg), i32, C.POINTER(WgradSeg), i32, vp, i64, vp],
     "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
@@ -350,6 +377,19 @@ def adapter_pack(wd, wu, wd16, wdT16, wu16, wuT16, H=768, r=48):
     _dev(wd, wu)
     _chk(load().feddat_adapter_pack(_p(wd), _p(wu), _p(wd16), _p(wdT16), _p(wu16), _p(wuT16), H, r, _stream()),
          "feddat_adapter_pack")
+
+
+def vilt_layer_fwd(ctx: "Context", W, A, nb, S, heads, segs_arr, *, key_mask=None, ln1_done=False, next_ln_g=None,
+                   next_ln_b=None):
+    """One ViltLayer + Adaptered_ViltOutput forward as ONE C-ABI call (W / A: ViltLayerWeights / ViltLayerActs structs)."""
+    _chk(load().feddat_vilt_layer_fwd(ctx._h, C.byref(W), C.byref(A), nb, S, heads, _p(key_mask), int(ln1_done), segs_arr,
+                                      len(segs_arr), _p(next_ln_g), _p(next_ln_b), _stream()), "feddat_vilt_layer_fwd")
+
+
+def vilt_layer_bwd(ctx: "Context", W, A, G, nb, S, heads, segs_arr, wsegs_arr, partials, *, key_mask=None):
+    _chk(load().feddat_vilt_layer_bwd(ctx._h, C.byref(W), C.byref(A), C.byref(G), nb, S, heads, _p(key_mask), segs_arr,
+                                      len(segs_arr), wsegs_arr, 0 if wsegs_arr is None else len(wsegs_arr), _p(partials),
+                                      0 if partials is None else partials.numel(), _stream()), "feddat_vilt_layer_bwd")
 
 
 def sgemm_f32(A, sa_i, sa_k, B, sb_k, sb_j, I, J, K, out, *, ldo=None, ksplit=1, alpha=1.0, bias_j=None,

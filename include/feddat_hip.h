@@ -191,6 +191,60 @@ int feddat_adapter_pack_strided(const float* wd, const float* wu, long stride_f3
                                 hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Composite: one HF ViltLayer with the reference's Adaptered_ViltOutput as ONE call (what feddat_amd/engine.py sequences
+ * per layer).  Forward = transformers ViltLayer.forward as reached from src/modeling/vilt.py:127 with
+ * src/modeling/adaptered_output.py:73-78 in place of ViltOutput; backward = dX through the frozen weights + the trainable
+ * adapter's weight gradients (autograd of task_trainer.py:302,323).  rows = nb * S; every pointer is a device buffer owned
+ * by the caller (bf16 as void*), hidden size = 64 * heads, bottleneck 48, S <= 320.
+ *   weights: bf16 [out,in] operands, their [in,out] transposes (backward only), fp32 biases / LayerNorm.
+ *   acts:    h_in (in) ... h3, z_save (saved for the backward), h_out = adapter output = the next layer's h_in; x16 / f16 are
+ *            bf16 scratch ([rows,768] / [rows,3072]); with next_ln_g / next_ln_b the next layer's layernorm_before is fused
+ *            into the adapter kernel: x16 then holds it and st1_next its row statistics (pass ln1_done = 1 to that layer).
+ *   grads:   dh_out (in; destroyed) -> dh_in (out); dh3 .. dz are scratch of the shapes noted.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void *wqkv, *wo, *w1, *w2;          /* bf16 [2304,768], [768,768], [3072,768], [768,3072] */
+    const void *wqkvT, *woT, *w1T, *w2T;      /* bf16 transposes (backward) */
+    const float *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float ln_eps;
+} feddat_vilt_layer_weights;
+typedef struct {
+    const float* h_in;   /* fp32 [rows,768] */
+    float* st1;          /* fp32 [rows,2]  LN1 mean / rstd */
+    void* qkv;           /* bf16 [rows,2304] */
+    void* ctx;           /* bf16 [rows,768] */
+    float* lse;          /* fp32 [nb,heads,S] */
+    float* h2;           /* fp32 [rows,768] */
+    float* st2;          /* fp32 [rows,2] */
+    void* u;             /* bf16 [rows,3072] pre-GELU */
+    float* h3;           /* fp32 [rows,768] adapter input */
+    float* z_save;       /* fp32 [rows,2,48] or NULL (the backward then recomputes from h3) */
+    float* h_out;        /* fp32 [rows,768] */
+    void* x16;           /* bf16 [rows,768] scratch / LN1 input operand */
+    void* f16;           /* bf16 [rows,3072] scratch */
+    float* st1_next;     /* fp32 [rows,2] or NULL */
+} feddat_vilt_layer_acts;
+typedef struct {
+    float* dh_out;       /* fp32 [rows,768] in (destroyed) */
+    float* dh_in;        /* fp32 [rows,768] out */
+    float* dh3;          /* fp32 [rows,768] */
+    void* dh16;          /* bf16 [rows,768] */
+    void* dU;            /* bf16 [rows,3072] */
+    void* dx16;          /* bf16 [rows,768] */
+    void* dctx;          /* bf16 [rows,768] */
+    void* dqkv;          /* bf16 [rows,2304] */
+    float* z;            /* fp32 [rows,48] */
+    float* dz;           /* fp32 [rows,48] */
+} feddat_vilt_layer_grads;
+int feddat_vilt_layer_fwd(feddat_ctx* ctx, const feddat_vilt_layer_weights* W, const feddat_vilt_layer_acts* A, int nb,
+                          int S, int heads, const uint8_t* key_mask, int ln1_done, const feddat_adapter_seg* segs, int nseg,
+                          const float* next_ln_g, const float* next_ln_b, hipStream_t stream);
+int feddat_vilt_layer_bwd(feddat_ctx* ctx, const feddat_vilt_layer_weights* W, const feddat_vilt_layer_acts* A,
+                          const feddat_vilt_layer_grads* G, int nb, int S, int heads, const uint8_t* key_mask,
+                          const feddat_adapter_seg* segs, int nseg, const feddat_wgrad_seg* wsegs, int nwseg,
+                          float* wgrad_partials, long wgrad_partials_elems, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Small exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 with arbitrary strides and split-K partial sums:
  *   for split s: D_s[i][j] = alpha * sum_{k in chunk s} A[i*sa_i + k*sa_k] * B[k*sb_k + j*sb_j]
  *   out[s*out_split_stride + i*ldo + j] = D_s[i][j] (+ bias_j[j] if s == 0 and bias_j) .

@@ -232,3 +232,21 @@ def test_unusual_shapes_train_steps(eng_mod, B, res, layers, text_len, graph):
     names = O.trainable_names(P, "art", 0) + [n for n in O.trainable_names(P, "art", 1) if "adapter_1" in n]
     # B = 1: per-element gradients are single-sample, more of them sit at the noise floor of the bf16 forward
     assert_update_parity(names, eng.state_dict(), P, P0, 1e-3, REL_MEAN if B > 1 else 2 * REL_MEAN)
+
+
+def test_composite_layer_calls_equal_the_op_by_op_sequence(eng_mod):
+    """feddat_vilt_layer_fwd / feddat_vilt_layer_bwd (one C-ABI call per layer) issue the same kernels in the same order as
+    the op-by-op sequencing: bit-identical training."""
+    d = O.ViltDims(layers=4)
+    finals = []
+    for use_calls in (True, False):
+        P = O.make_params(d, ["art"], bias_std=0.02)
+        eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=3, res=224, layers=4)
+        eng.use_layer_calls = use_calls
+        eng.begin_local_update("art", steps_per_epoch=3)
+        for s in range(3):
+            eng.train_step(_to_dev(O.synthetic_batch(3, 224, 300 + s)))
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in eng.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k

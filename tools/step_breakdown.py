@@ -46,6 +46,7 @@ def measure(eng, L, batches, steps=3, detail=True, plug_s=0.03):
     for n in names:
         setattr(L, n, wrap(n))
     empties, tot_ev = [], []
+    layer_calls, eng.use_layer_calls = getattr(eng, "use_layer_calls", False), False      # op-by-op: every kernel bracketed
     try:
         eng.train_step(batches[0])
         rec.clear()
@@ -64,6 +65,7 @@ def measure(eng, L, batches, steps=3, detail=True, plug_s=0.03):
             tot_ev.append((s0, s1))
         torch.cuda.synchronize()
     finally:
+        eng.use_layer_calls = layer_calls
         for n in names:
             setattr(L, n, orig[n])
     empty_ms = sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
