@@ -31,6 +31,7 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldb, ldr, ldaux, ldo32, ldo16, ldo2;
     int epi;
+    int nostore;   // tools/ ablation (debug flag 16): the bf16 epilogues do everything but their global stores
 };
 
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, int ld, int row0, int rows_max, int k0,
@@ -314,7 +315,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int m = mbase + i * 16 + srow[p];
-            if (m < m_end) *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
+            if (m < m_end && !(g.nostore & 1)) *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
         }
     };
 #pragma unroll
@@ -328,13 +329,15 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const bf16x4 u = *reinterpret_cast<const bf16x4*>(wr + j * 32);
-                val[j] = val[j] * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
+                if (!(g.nostore & 2)) val[j] = val[j] * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
+                else val[j] = val[j] * f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
             }
         }
         if (EPI == FEDDAT_EPI_GELU) {
             if (g.out2_bf16) put(g.out2_bf16, g.ldo2, i, val);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) val[j] = gelu4_pk(val[j]);
+            for (int j = 0; j < 6; ++j)
+                if (!(g.nostore & 2)) val[j] = gelu4_pk(val[j]);
         }
         put(g.out_bf16, g.ldo16, i, val);
     }
@@ -820,6 +823,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;
     g.ldo32 = ldo32; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
+    g.nostore = ((fd_debug_flags() & 16) ? 1 : 0) | ((fd_debug_flags() & 4) ? 2 : 0);   // 4: ablate the GELU math
     if (use_v2) {
         GemmArgsV2 a2;
         a2.g = g;
