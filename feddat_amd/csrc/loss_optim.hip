@@ -75,13 +75,17 @@ __device__ __forceinline__ float poly_lambda(int t, int warmup, int total) {
     return 1.0f - (float)(t - warmup) / (float)(total - warmup);
 }
 
+// VEC = 4: every thread owns 4 consecutive parameters (one 16-byte access per array; the host checks that all segment
+// offsets are multiples of 4 so a quad never straddles two weight-decay groups); VEC = 1: the general element-wise form.
+// The per-element arithmetic is identical in both (bit-identical results).
+template <int VEC>
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, long n,
                                                          const long* __restrict__ seg_off,
                                                          const float* __restrict__ seg_wd, int nseg,
                                                          const int* __restrict__ state, float base_lr, int warmup,
                                                          int total, float beta1, float beta2, float eps) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (i >= n) return;
     const int sched_t = state[0];
     const int t = state[1] + 1;
@@ -92,18 +96,42 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
         const int mid = (lo + hi + 1) >> 1;
         if (seg_off[mid] <= i) lo = mid; else hi = mid - 1;
     }
-    const float wd = seg_wd[lo];
+    float wd[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) wd[e] = seg_wd[lo];
+    if (VEC > 1 && lo + 1 < nseg && seg_off[lo + 1] < i + VEC) {       // the quad straddles a tensor boundary (rare)
+        for (int e = 1; e < VEC; ++e) {
+            int s2 = lo;
+            while (s2 + 1 < nseg && seg_off[s2 + 1] <= i + e) ++s2;
+            wd[e] = seg_wd[s2];
+        }
+    }
     const float bc1 = 1.0f - powf(beta1, (float)t);
     const float bc2 = 1.0f - powf(beta2, (float)t);
-    const float gi = g[i];
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);   // lerp_(grad, 1 - beta1)
-    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    pi -= (lr / bc1) * (mi / denom);
-    p[i] = pi;
-    m[i] = mi;
-    v[i] = vi;
+    float gi[VEC], pi[VEC], mi[VEC], vi[VEC];
+    if (VEC == 4) {
+        *reinterpret_cast<f32x4*>(gi) = *reinterpret_cast<const f32x4*>(g + i);
+        *reinterpret_cast<f32x4*>(pi) = *reinterpret_cast<const f32x4*>(p + i);
+        *reinterpret_cast<f32x4*>(mi) = *reinterpret_cast<const f32x4*>(m + i);
+        *reinterpret_cast<f32x4*>(vi) = *reinterpret_cast<const f32x4*>(v + i);
+    } else {
+        gi[0] = g[i]; pi[0] = p[i]; mi[0] = m[i]; vi[0] = v[i];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        pi[e] = pi[e] * (1.0f - lr * wd[e]);
+        mi[e] = mi[e] + (gi[e] - mi[e]) * (1.0f - beta1);   // lerp_(grad, 1 - beta1)
+        vi[e] = vi[e] * beta2 + (1.0f - beta2) * gi[e] * gi[e];
+        const float denom = sqrtf(vi[e]) / sqrtf(bc2) + eps;
+        pi[e] -= (lr / bc1) * (mi[e] / denom);
+    }
+    if (VEC == 4) {
+        *reinterpret_cast<f32x4*>(p + i) = *reinterpret_cast<const f32x4*>(pi);
+        *reinterpret_cast<f32x4*>(m + i) = *reinterpret_cast<const f32x4*>(mi);
+        *reinterpret_cast<f32x4*>(v + i) = *reinterpret_cast<const f32x4*>(vi);
+    } else {
+        p[i] = pi[0]; m[i] = mi[0]; v[i] = vi[0];
+    }
 }
 
 __global__ void step_tick_kernel(int* state, int d_sched, int d_adam) {
@@ -138,8 +166,15 @@ extern "C" int feddat_adamw_flat(float* p, const float* g, float* m, float* v, l
                                  const float* seg_wd, int nseg, const int* state, float base_lr, int warmup, int total,
                                  float beta1, float beta2, float eps, hipStream_t stream) {
     FD_CHECK_ARG(p && g && m && v && n > 0 && seg_off && seg_wd && nseg > 0 && state && total > warmup);
-    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n,
-                       seg_off, seg_wd, nseg, state, base_lr, warmup, total, beta1, beta2, eps);
+    // quads of 4 consecutive parameters per thread when n % 4 == 0 and the buffers are 16-byte aligned (a quad that
+    // straddles a tensor boundary looks its weight decays up per element)
+    const bool quads = (n % 4 == 0) && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    if (quads)
+        hipLaunchKernelGGL(adamw_flat_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n,
+                           seg_off, seg_wd, nseg, state, base_lr, warmup, total, beta1, beta2, eps);
+    else
+        hipLaunchKernelGGL(adamw_flat_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n,
+                           seg_off, seg_wd, nseg, state, base_lr, warmup, total, beta1, beta2, eps);
     FD_LAUNCH_RET();
 }
 

@@ -369,10 +369,11 @@ def test_loss_vs_reference_golden(L, golden_dir):
 
 
 # ------------------------------------------------------------------ K6 AdamW + schedule
-def test_adamw_flat_vs_oracle(L):
+@pytest.mark.parametrize("shapes", [[(48, 768), (48,), (1536,), (768,)],        # quad-aligned tensors (the engine's layouts)
+                                    [(47, 3), (7,), (1530,), (10,)]])           # tensor boundaries inside quads, n % 4 == 0
+def test_adamw_flat_vs_oracle(L, shapes):
     g = torch.Generator().manual_seed(5)
     names = ["w.weight", "w.bias", "clf_norm0.weight", "x.LayerNorm.weight"]
-    shapes = [(48, 768), (48,), (1536,), (768,)]
     P = {n: torch.randn(s, generator=g) * 0.05 for n, s in zip(names, shapes)}
     offs = np.cumsum([0] + [int(np.prod(s)) for s in shapes])
     flat = torch.cat([P[n].flatten() for n in names]).to(DEV)
