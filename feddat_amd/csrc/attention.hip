@@ -309,6 +309,169 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     }
 }
 
+// Backward in ONE block per (sample, head) for S_pad <= 192 (the benchmark's S = 185): Q, dO and K live in LDS once,
+// the probabilities are computed once (5 matmul units instead of the 7 of the two-role kernel, one exp per score instead of
+// two) and every operand is read from HBM once (145 MB instead of 236 MB per launch at configs[1]).
+//   phase A: wave w owns key tile w (16 keys; V fragments straight from HBM): for all queries S = Q K^T, P, dP = dO V^T,
+//            dS = P (dP - D);  dV += P^T dO, dK += dS^T Q;  dS^T goes to LDS as bf16 panels [q tile][key][16 q];
+//   phase B: wave w owns query tile w: dQ = sum over keys dS K, the dS operand read back transposed from the panels.
+// 2 NKS waves per block; LDS = 3 S_pad x 128 B + S_pad^2 x 2 B + 3 S_pad x 4 B  (144 KiB at S_pad = 192).
+template <int NKS>
+__global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv,
+                                                                     const uint8_t* __restrict__ kmask,
+                                                                     const bf16* __restrict__ ctx,
+                                                                     const float* __restrict__ lse,
+                                                                     const bf16* __restrict__ dctx,
+                                                                     bf16* __restrict__ dqkv, int S, int heads) {
+    constexpr int S_pad = NKS * 32, NT = NKS * 2, NTHR = NKS * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Gs = Qs + S_pad * ROWB;
+    char* Ks = Gs + S_pad * ROWB;
+    char* Pn = Ks + S_pad * ROWB;                  // dS^T panels: [NT q tiles][S_pad keys][16 q] bf16 (32-byte rows)
+    float* Dv = reinterpret_cast<float*>(Pn + NT * S_pad * 32);
+    float* Ls = Dv + S_pad;
+    float* kvalid = Ls + S_pad;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int H = heads * D;
+    const long ld = 3L * H;
+    const bf16* base = qkv + (size_t)b * S * ld + h * D;
+    const bf16* gO = ctx + (size_t)b * S * H + h * D;
+    const bf16* gG = dctx + (size_t)b * S * H + h * D;
+    bf16* dq_base = dqkv + (size_t)b * S * ld + h * D;
+    const int g = lane >> 4, i16 = lane & 15;
+    for (int k = tid; k < S_pad; k += NTHR) {
+        Ls[k] = k < S ? lse[((size_t)b * heads + h) * S + k] * LOG2E : 0.f;
+        kvalid[k] = (k < S && (!kmask || kmask[(size_t)b * S + k])) ? 1.f : 0.f;
+    }
+    for (int idx = tid; idx < S_pad * 8; idx += NTHR) {             // Q, K -> LDS
+        const int row = idx >> 3, chunk = idx & 7;
+        bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, kv = qv;
+        if (row < S) {
+            qv = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + chunk * 8);
+            kv = *reinterpret_cast<const bf16x8*>(base + H + (size_t)row * ld + chunk * 8);
+        }
+        *reinterpret_cast<bf16x8*>(Qs + sw_off(row, chunk)) = qv;
+        *reinterpret_cast<bf16x8*>(Ks + sw_off(row, chunk)) = kv;
+    }
+    for (int idx = tid; idx < S_pad * 8; idx += NTHR) {             // dO -> LDS, D[q] = sum_d dO[q][d] O[q][d]
+        const int row = idx >> 3, chunk = idx & 7;
+        bf16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
+        float part = 0.f;
+        if (row < S) {
+            gv = *reinterpret_cast<const bf16x8*>(gG + (size_t)row * H + chunk * 8);
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(gO + (size_t)row * H + chunk * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)gv[e] * (float)ov[e];
+        }
+        *reinterpret_cast<bf16x8*>(Gs + sw_off(row, chunk)) = gv;
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (chunk == 0) Dv[row] = part;
+    }
+    __syncthreads();
+
+    // ---------------- phase A: this wave's key tile ----------------
+    {
+        const int kt = wave;
+        const int key = kt * 16 + i16;
+        const bf16x8 kf0 = row_frag(Ks, key, g), kf1 = row_frag(Ks, key, 4 + g);
+        const bf16x8 vf0 = gload_frag(base + 2 * H, ld, key, S, g), vf1 = gload_frag(base + 2 * H, ld, key, S, 4 + g);
+        const float kv = kvalid[key];
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (kt * 16 < S) {
+#pragma unroll
+            for (int qs = 0; qs < NKS; ++qs) {
+                if (qs * 32 >= S) break;
+                f32x4 p[2], ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int qrow = (2 * qs + t) * 16;
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc = mfma16x32(row_frag(Qs, qrow + i16, g), kf0, sc);       // S: rows = queries qrow + 4g + e, col = key i16
+                    sc = mfma16x32(row_frag(Qs, qrow + i16, 4 + g), kf1, sc);
+                    dp = mfma16x32(row_frag(Gs, qrow + i16, g), vf0, dp);
+                    dp = mfma16x32(row_frag(Gs, qrow + i16, 4 + g), vf1, dp);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qrow + 4 * g);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + qrow + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = kv * __builtin_amdgcn_exp2f(sc[e] * (0.125f * LOG2E) - l4[e]);
+                        p[t][e] = pe;
+                        ds[t][e] = pe * (dp[e] - d4[e]);          // the 1/8 of dS is applied to dK / dQ at the end
+                    }
+                    // dS^T panel of query tile 2 qs + t: row = key, 4 consecutive queries 4g .. 4g+3 (8 bytes)
+                    *reinterpret_cast<bf16x4*>(Pn + ((2 * qs + t) * S_pad + key) * 32 + g * 8) = cvt4(ds[t]);
+                }
+                const bf16x8 pb = cvt8(p[0], p[1]);
+                const bf16x8 dsb = cvt8(ds[0], ds[1]);
+                const int r0a = (2 * qs) * 16 + 4 * g, r0b = (2 * qs + 1) * 16 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma16x32(tr_frag8(Gs, r0a, r0b, dt * 16, lane), pb, dv[dt]);
+                    dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
+                }
+            }
+            if (key < S) {
+                bf16* ok = dq_base + (size_t)key * ld + H;
+                bf16* ov = dq_base + (size_t)key * ld + 2 * H;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<bf16x4*>(ok + dt * 16 + 4 * g) = cvt4(dk[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
+                    *reinterpret_cast<bf16x4*>(ov + dt * 16 + 4 * g) = cvt4(dv[dt]);
+                }
+            }
+        } else {
+            // key tile beyond S: its panel rows must still be defined (phase B reads all S_pad keys)
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt)
+                *reinterpret_cast<bf16x4*>(Pn + (qt * S_pad + key) * 32 + g * 8) = bf16x4{0, 0, 0, 0};
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase B: this wave's query tile ----------------
+    {
+        const int qt = wave;
+        if (qt * 16 >= S) return;
+        const char* panel = Pn + qt * S_pad * 32;
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks * 32 >= S) break;
+            // dS operand: lane (g, i16 = query) needs keys 32 ks + 4g .. +3 and 32 ks + 16 + 4g .. +3 of its query: a
+            // transposed read of the 4 x 16 blocks of the panel (32-byte rows, 16 queries wide)
+            const int i = lane & 15;
+            auto tr = [&](int r0) {
+                const char* pp = panel + (r0 + (i >> 2)) * 32 + ((i & 3) << 3);
+                return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pp);
+            };
+            const bf16x4 a4 = tr(ks * 32 + 4 * g), b4 = tr(ks * 32 + 16 + 4 * g);
+            const bf16x8 dsb = bf16x8{a4[0], a4[1], a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};
+            const int r0a = ks * 32 + 4 * g, r0b = ks * 32 + 16 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
+        }
+        const int q = qt * 16 + i16;
+        if (q < S) {
+            bf16* oq = dq_base + (size_t)q * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
+        }
+    }
+}
+
 template <typename K>
 int set_lds(K kern, int bytes) {
     return fd_set_max_lds((const void*)kern, bytes) == FEDDAT_OK ? 0 : 1;
@@ -354,6 +517,23 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
                                const void* dctx, void* dqkv, int B, int S, int heads, hipStream_t stream) {
     FD_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && B > 0 && S > 0 && S <= 320 && heads > 0);
     const int nks = (S + 31) / 32;
+    if (nks <= 6 && !(fd_debug_flags() & 2)) {        // one block per (sample, head): operands and probabilities once
+        const int sp = nks * 32;
+        const int ldsf = 3 * sp * ROWB + sp * sp * 2 + 3 * sp * 4;
+#define ATTN_BWD_F(N)                                                                                          \
+    case N:                                                                                                    \
+        if (set_lds(attn_bwd_fused_kernel<N>, 3 * (N) * 32 * ROWB + (N) * 32 * (N) * 32 * 2 + 3 * (N) * 32 * 4))  \
+            return FEDDAT_ELAUNCH;                                                                             \
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(B * heads), dim3((N) * 128), ldsf, stream,           \
+                           (const bf16*)qkv, key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads); \
+        break;
+        switch (nks) {
+            ATTN_BWD_F(1) ATTN_BWD_F(2) ATTN_BWD_F(3) ATTN_BWD_F(4) ATTN_BWD_F(5) ATTN_BWD_F(6)
+            default: return FEDDAT_EINVAL;
+        }
+#undef ATTN_BWD_F
+        FD_LAUNCH_RET();
+    }
     const int lds = nks * 32 * ROWB * 2 + nks * 32 * 4 * 3;
 #define NKS_MAX_LDS_B(N) ((N) * 32 * ROWB * 2 + (N) * 32 * 4 * 3)
 #define ATTN_BWD(N)                                                                                           \
@@ -377,6 +557,10 @@ int fd_prepare_attn_kernels() {
     if (set_lds(attn_bwd_kernel<N>, (N) * 32 * ROWB * 2 + (N) * 32 * 4 * 3)) return FEDDAT_ELAUNCH;
     PREP(1) PREP(2) PREP(3) PREP(4) PREP(5) PREP(6) PREP(7) PREP(8) PREP(9) PREP(10)
 #undef PREP
+#define PREPF(N)                                                                                                      \
+    if (set_lds(attn_bwd_fused_kernel<N>, 3 * (N) * 32 * ROWB + (N) * 32 * (N) * 32 * 2 + 3 * (N) * 32 * 4)) return FEDDAT_ELAUNCH;
+    PREPF(1) PREPF(2) PREPF(3) PREPF(4) PREPF(5) PREPF(6)
+#undef PREPF
     return FEDDAT_OK;
 }
 
