@@ -241,6 +241,9 @@ def main():
     ap.add_argument("--workload", default="vilt", choices=["vilt", "albef"],
                     help="vilt = configs[1] / configs[2] (the headline metric); albef = configs[3]: ALBEF (ViT-B/16 + BERT-base) "
                          "dual-adapter + MKD step, 25-token questions, one 4-token answer per question")
+    ap.add_argument("--fp8", action="store_true",
+                    help="configs[4]: e4m3 MFMA for the QKV / FFN1 forward products of the frozen backbone (bf16 adapters); "
+                         "quoted at --batch 64")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -288,7 +291,7 @@ def main():
     task = tasks[rank]
     # identical frozen backbone + server adapter on every client (seed 0); heterogeneous data per client
     params = vilt_spec.random_init(12, tasks, seed=0, device="cpu")
-    eng = engine.ViltDatEngine(params, [task], dev, batch=B, res=res, layers=12)
+    eng = engine.ViltDatEngine(params, [task], dev, batch=B, res=res, layers=12, fp8=args.fp8)
     nb = 4
     batches = [vilt_spec.synthetic_batch(B, res, 1234 + 100 * rank + i, device=dev) for i in range(nb)]
     steps_per_epoch = max(args.steps + args.warmup, 40)
@@ -349,8 +352,10 @@ def main():
             "metric": "VQA samples/sec, ViLT-B/32 dual-adapter local step", "value": round(sps, 2),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, bf16 MFMA, batch=32/client, "
+            "vs_baseline": None, "dtype": "fp8(e4m3)+bf16" if args.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": ("configs[4]: ViLT-B/32 FedDAT, fp8 (e4m3) MFMA for the frozen QKV / FFN1 forward products, "
+                                    f"bf16 elsewhere, batch={B}/client, " if args.fp8 else
+                                    f"configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, bf16 MFMA, batch={B}/client, ") +
                                    "384x384 synthetic + 40-token questions, MKD on"
                                    + (f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else ""),
                        "batch_per_client": B, "seq_len": S, "clients": world, "hip_graph": use_graph,

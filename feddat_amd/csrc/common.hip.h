@@ -132,6 +132,14 @@ __device__ __forceinline__ bf16x4 cvt4(const f32x4 a) {
 __device__ __forceinline__ f32x4 mfma16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// fp8 (OCP e4m3 on gfx950) form of the same product: a 16-byte fragment read carries 16 contraction slots per lane = two
+// K = 32 instructions (slots 0-7, then 8-15; A and B are split the same way, which is all the contraction needs).
+typedef long i64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma16x64_fp8(bf16x8 a, bf16x8 b, f32x4 c) {
+    const i64x2 a2 = __builtin_bit_cast(i64x2, a), b2 = __builtin_bit_cast(i64x2, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[0], b2[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[1], b2[1], c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x4 mfma16x4_f32(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

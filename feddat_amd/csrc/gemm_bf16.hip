@@ -32,6 +32,8 @@ struct GemmArgs {
     int lda, ldb, ldr, ldaux, ldo32, ldo16, ldo2;
     int epi;
     int nostore;   // tools/ ablation (debug flag 16): the bf16 epilogues do everything but their global stores
+    const float* sa;   // fp8 operands: per-row scale of A [M] and per-row scale of B [N] (acc * sa[m] * sw[n]); else null
+    const float* sw;
 };
 
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, int ld, int row0, int rows_max, int k0,
@@ -318,11 +320,22 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
             if (m < m_end && !(g.nostore & 1)) *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
         }
     };
+    f32x4 sw4[6];
+    if (g.sw) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sw4[j] = *reinterpret_cast<const f32x4*>(g.sw + nbase + j * 16 + fg * 4);
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         f32x4 val[6];
+        if (g.sw) {          // fp8 operands: dequantise the accumulators (per-row scale of A x per-channel scale of B)
+            const float sa = g.sa[min(mbase + i * 16 + frow, m_end - 1)];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) val[j] = acc[i][j] + bias4[j];
+            for (int j = 0; j < 6; ++j) val[j] = acc[i][j] * (sw4[j] * f32x4{sa, sa, sa, sa}) + bias4[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) val[j] = acc[i][j] + bias4[j];
+        }
         if (EPI == FEDDAT_EPI_MUL_DGELU) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(stg + srow[p] * V2_EPI_LD16 + sc8[p] * 16) = ux[i][p];
@@ -437,7 +450,7 @@ struct V2State {
     int l_tile, l_kt;     // tile index / k-tile of the next staging load
 };
 
-template <int EPI, int WM>
+template <int EPI, int WM, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     using Cfg = V2Cfg<WM>;
     constexpr int NP = Cfg::NP;
@@ -605,7 +618,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16x32(fb[ks][j], fa[ks][i], acc[i][j]);
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = FP8 ? mfma16x64_fp8(fb[ks][j], fa[ks][i], acc[i][j]) : mfma16x32(fb[ks][j], fa[ks][i], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);     // MFMAs first: the write's lgkmcnt must not gate them
                 if (ks * WM + i < NP) {                // compile-time: straight-line code, so the compiler's vmcnt /
                     lwrite_piece(ks * WM + i, wstage); // lgkmcnt counts stay exact (a runtime branch here degrades
@@ -752,7 +766,7 @@ extern "C" int feddat_gemm_bf16_nt_skinny(const void* A, int lda, const void* B,
     }
     const int ksplit = skinny_ksplit(N, K);
     FD_CHECK_ARG(workspace_elems >= (long)ksplit * M * N);
-    GemmArgs g;
+    GemmArgs g{};
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.bias = bias; g.resid = resid; g.aux = (const bf16*)aux;
     g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;
@@ -784,6 +798,55 @@ int fd_prepare_gemm_kernels() {
             if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
                 return FEDDAT_ELAUNCH;
     return fd_set_max_lds((const void*)gemm_nt_kernel, 4 * TILE_BYTES);
+}
+
+// fp8 (e4m3) operands on the same persistent kernel: byte for byte the data movement of a bf16 product with K / 2
+// "elements" (128 fp8 per 128-byte LDS row); only the MFMA (two K = 32 fp8 instructions per 16-byte fragment) and the
+// dequantising epilogue differ.
+extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb,
+                                  const float* b_scale, int M, int N, int K, int epi, const float* bias, void* out_bf16,
+                                  int ldo16, void* out2_bf16, int ldo2, hipStream_t stream) {
+    FD_CHECK_ARG(A8 && B8 && a_scale && b_scale && out_bf16 && M >= 1024 && N > 0 && N % V2_BN == 0 && K > 0 && K % 128 == 0);
+    FD_CHECK_ARG(epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU);
+    FD_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
+    FD_CHECK_ARG(!out2_bf16 || (ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0));
+    GemmArgsV2 a2;
+    GemmArgs& g = a2.g;
+    g = GemmArgs{};
+    g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.bias = bias; g.sa = a_scale; g.sw = b_scale;
+    g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
+    g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
+    a2.dbg = 0;
+    int n_cu = 0;
+    if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+    const int tiles_n = N / V2_BN;
+    auto plan = [&](int BMx, GemmArgsV2& o) {
+        int nmt = (M + BMx - 1) / BMx;
+        o.nx = 1;
+        if ((size_t)N * K > (3u << 20) && tiles_n % 2 == 0 && nmt * tiles_n > n_cu) {
+            o.nx = 2;
+            nmt = (nmt + 3) & ~3;
+        }
+        const int bm = (M + nmt - 1) / nmt;
+        o.bm = bm;
+        o.tiles_m = o.nx == 1 ? (M + bm - 1) / bm : nmt;
+        o.tm_per = o.tiles_m / (8 / o.nx);
+        o.tn_per = tiles_n / o.nx;
+        return (o.tiles_m * tiles_n + n_cu - 1) / n_cu;
+    };
+    GemmArgsV2 a3 = a2, a4 = a2;
+    const int rounds3 = plan(192, a3), rounds4 = plan(256, a4);
+    const bool wm4 = rounds4 * 12 < rounds3 * 10;
+    a2 = wm4 ? a4 : a3;
+    using KernelFn = void (*)(GemmArgsV2);
+    KernelFn kern;
+    if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true>;
+    else kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true>;
+    const int lds_bytes = wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS;
+    if (fd_set_max_lds((const void*)kern, lds_bytes) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+    const int total = a2.tiles_m * tiles_n;
+    hipLaunchKernelGGL(kern, dim3(total < n_cu ? total : n_cu), dim3(512), lds_bytes, stream, a2);
+    FD_LAUNCH_RET();
 }
 
 extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
@@ -818,7 +881,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         if (epi == FEDDAT_EPI_GELU && out2_bf16) FD_CHECK_ARG(ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0);
         if (epi == FEDDAT_EPI_MUL_DGELU) FD_CHECK_ARG(ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0);
     }
-    GemmArgs g;
+    GemmArgs g{};
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.bias = bias; g.resid = resid; g.aux = (const bf16*)aux;
     g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;

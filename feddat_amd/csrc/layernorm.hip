@@ -10,7 +10,9 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long x_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, int rows, int H, bf16* __restrict__ y16,
-                                                     float* __restrict__ y32, float* __restrict__ stats) {
+                                                     float* __restrict__ y32, float* __restrict__ stats,
+                                                     unsigned char* __restrict__ y8 = nullptr,
+                                                     float* __restrict__ y8_scale = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -55,6 +57,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g4[e] + b4[e];
             if (y16) *reinterpret_cast<bf16x4*>(y16 + (size_t)row * H + i * 4) = cvt4(o);
             if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * H + i * 4) = o;
+            v[c] = o;
+        }
+    }
+    if (!y8) return;
+    // fp8 (e4m3) copy with a per-row scale: y8 = round(y / s), s = max|y| / 448 (the fp8 GEMM multiplies s back in)
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + c * 64 < nc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[c][e]));
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) y8_scale[row] = sc;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, pk, true);
+            *reinterpret_cast<int*>(y8 + (size_t)row * H + i * 4) = pk;
         }
     }
 }
@@ -152,6 +176,55 @@ extern "C" int feddat_layernorm_fwd(const float* x, long x_stride, const float* 
                        rows, H, (bf16*)y_bf16, y_f32, stats)
     if (H <= 768) LN_FWD(3); else if (H <= 1536) LN_FWD(6); else LN_FWD(8);
 #undef LN_FWD
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_layernorm_fwd_fp8(const float* x, long x_stride, const float* gamma, const float* beta, float eps,
+                                        int rows, int H, void* y_fp8, float* y_scale, void* y_bf16, float* stats,
+                                        hipStream_t stream) {
+    FD_CHECK_ARG(x && gamma && beta && rows > 0 && H > 0 && H % 4 == 0 && H <= 2048 && x_stride % 4 == 0);
+    FD_CHECK_ARG(y_fp8 && y_scale);
+#define LN_FWD8(MC)                                                                                              \
+    hipLaunchKernelGGL(ln_fwd_kernel<MC>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, x_stride, gamma, beta, eps, \
+                       rows, H, (bf16*)y_bf16, (float*)nullptr, stats, (unsigned char*)y_fp8, y_scale)
+    if (H <= 768) LN_FWD8(3); else if (H <= 1536) LN_FWD8(6); else LN_FWD8(8);
+#undef LN_FWD8
+    FD_LAUNCH_RET();
+}
+
+// x fp32 [rows, cols] (row stride ld) -> e4m3 [rows, cols] + per-row scale (amax / 448): frozen weights (per output
+// channel) at load time, or any activation
+namespace {
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __restrict__ x, long ld, int cols,
+                                                             unsigned char* __restrict__ y, float* __restrict__ scale) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (size_t)row * ld;
+    float amax = 0.f;
+    for (int c = tid * 4; c < cols; c += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (tid == 0) scale[row] = sc;
+    for (int c = tid * 4; c < cols; c += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, pk, true);
+        *reinterpret_cast<int*>(y + (size_t)row * cols + c) = pk;
+    }
+}
+}  // namespace
+
+extern "C" int feddat_quant_rows_fp8(const float* x, long ld, int rows, int cols, void* y_fp8, float* scale,
+                                     hipStream_t stream) {
+    FD_CHECK_ARG(x && y_fp8 && scale && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && ld >= cols);
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(rows), dim3(256), 0, stream, x, ld, cols, (unsigned char*)y_fp8, scale);
     FD_LAUNCH_RET();
 }
 

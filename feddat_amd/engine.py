@@ -65,7 +65,11 @@ class FlatGroup:
 class ViltDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], tasks: Sequence[str], device, batch: int, res: int,
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
-                 weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16):
+                 weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False):
+        """fp8=True (BASELINE.json configs[4]): the QKV and FFN1 products of the frozen backbone's FORWARD run on fp8 MFMA
+        (e4m3 weights with per-output-channel scales, quantised once here; activations quantised per token row by the
+        LayerNorm kernel that produces them); everything else -- adapters, attention, the other two linears whose inputs
+        are not LayerNorm outputs, the whole backward -- stays bf16 / fp32."""
         L.load()
         self.dev = torch.device(device)
         self.tasks = list(tasks)
@@ -78,6 +82,7 @@ class ViltDatEngine:
         self.S = text_len + 1 + self.np
         self.R = batch * self.S
         self.lr, self.wd, self.eps = lr, weight_decay, adam_eps
+        self.fp8 = bool(fp8)
         self.ksplit = wgrad_splits
         self.ln_eps = 1e-12
         dev = self.dev
@@ -95,6 +100,12 @@ class ViltDatEngine:
             out = torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev)
             L.transpose_f32_bf16(w, out, w.shape[0], w.shape[1])
             return out
+
+        def fp8_of(w):  # [N,K] fp32 -> e4m3 [N,K] + per-output-channel scale [N]
+            w8 = torch.empty(w.shape, dtype=torch.uint8, device=dev)
+            sc = torch.empty(w.shape[0], device=dev)
+            L.quant_rows_fp8(w.contiguous(), w8, sc)
+            return w8, sc
 
         # ---------------- frozen backbone (bf16 weights + their transposes for the dX products) --------------
         e = ENC + "embeddings."
@@ -120,8 +131,12 @@ class ViltDatEngine:
             bqkv = torch.cat([P(Lp + f"attention.attention.{n}.bias") for n in ("query", "key", "value")]).contiguous()
             wo, w1, w2 = P(Lp + "attention.output.dense.weight"), P(Lp + "intermediate.dense.weight"), \
                 P(Lp + "output.layer.dense.weight")
+            extra = {}
+            if self.fp8:
+                extra["wqkv8"], extra["sqkv"] = fp8_of(wqkv)
+                extra["w18"], extra["s1"] = fp8_of(w1)
             self.layers.append(dict(
-                wqkv=bf16_of(wqkv), wqkvT=bf16_T(wqkv), bqkv=bqkv,
+                extra, wqkv=bf16_of(wqkv), wqkvT=bf16_T(wqkv), bqkv=bqkv,
                 wo=bf16_of(wo), woT=bf16_T(wo), bo=P(Lp + "attention.output.dense.bias"),
                 w1=bf16_of(w1), w1T=bf16_T(w1), b1=P(Lp + "intermediate.dense.bias"),
                 w2=bf16_of(w2), w2T=bf16_T(w2), b2=P(Lp + "output.layer.dense.bias"),
@@ -171,6 +186,9 @@ class ViltDatEngine:
         self.proj = f32(B * self.np, H)
         self.h0 = f32(R, H)
         self.x16 = b16(R2, H)          # LN output (GEMM operand), transient
+        if self.fp8:                   # LN output as e4m3 + per-row scale (operand of the fp8 products)
+            self.x8 = torch.empty(R2, H, dtype=torch.uint8, device=dev)
+            self.xs = f32(R2)
         self.f16 = b16(R2, I)          # gelu(u), transient
         # layer 0 (shared body, R rows): only h3 is kept
         self.l0 = dict(qkv=b16(R, 3 * H), ctx=b16(R, H), lse=f32(B, self.heads, self.S), h2=f32(R, H), h3=f32(R, H))
@@ -325,6 +343,17 @@ class ViltDatEngine:
         Adaptered_ViltOutput dense+residual (adaptered_output.py:74-76); returns the adapter input in h3."""
         W, H = self.layers[i], self.H
         x16, f16 = self.x16[:rows], self.f16[:rows]
+        if self._fp8_rows(rows):           # fp8 MFMA for the two products fed by a LayerNorm
+            x8, xs = self.x8[:rows], self.xs[:rows]
+            L.layernorm_fwd_fp8(h_in, W["ln1g"], W["ln1b"], self.ln_eps, rows, H, x8, xs, stats=st1)
+            L.gemm_fp8_nt(x8, xs, W["wqkv8"], W["sqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=qkv)
+            L.attn_fwd(qkv, ctx, lse, nb, self.S, self.heads, key_mask=mask)
+            L.gemm_bf16_nt(ctx, W["wo"], L.EPI_RESID_F32, bias=W["bo"], resid=h_in, out_f32=h2)
+            L.layernorm_fwd_fp8(h2, W["ln2g"], W["ln2b"], self.ln_eps, rows, H, x8, xs, stats=st2)
+            L.gemm_fp8_nt(x8, xs, W["w18"], W["s1"], L.EPI_GELU, bias=W["b1"], out_bf16=f16,
+                          out2_bf16=u if u is not None else self.dU[:rows])
+            L.gemm_bf16_nt(f16, W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=h2, out_f32=h3)
+            return
         if not ln1_done:     # otherwise x16 / st1 were written by the previous layer's fused adapter + LN kernel
             L.layernorm_fwd(h_in, W["ln1g"], W["ln1b"], self.ln_eps, rows, H, y_bf16=x16, stats=st1)
         L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=qkv)
@@ -333,6 +362,10 @@ class ViltDatEngine:
         L.layernorm_fwd(h2, W["ln2g"], W["ln2b"], self.ln_eps, rows, H, y_bf16=x16, stats=st2)
         L.gemm_bf16_nt(x16, W["w1"], L.EPI_GELU, bias=W["b1"], out_bf16=f16, out2_bf16=u)
         L.gemm_bf16_nt(f16, W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=h2, out_f32=h3)
+
+    def _fp8_rows(self, rows: int) -> bool:
+        """fp8 products are used where feddat_gemm_fp8_nt applies (M >= 1024); smaller launches stay bf16."""
+        return self.fp8 and rows >= 1024
 
     def _forward_dual(self):
         """Shared embeddings + layer-0 body, then both passes (gated | adapter_1) batched through layers 1..L-1."""
@@ -347,6 +380,9 @@ class ViltDatEngine:
             """Adapter of layer i fused with layer i+1's layernorm_before (its bf16 output and row statistics go
             where that layer's LN kernel would have put them)."""
             nx, Wn = self.act[i + 1], self.layers[i + 1]
+            if self._fp8_rows(R2):      # the next layer quantises its own LayerNorm output (feddat_layernorm_fwd_fp8)
+                L.adapter_fwd(x, nx["h_in"], self._segs(i, first, False), R2, z_save=self.zsave[i])
+                return
             L.adapter_fwd_ln(x, nx["h_in"], self._segs(i, first, False), R2, Wn["ln1g"], Wn["ln1b"], self.ln_eps,
                              self.x16[:R2], nx["st1"], z_save=self.zsave[i])
         if self.nl > 1:
@@ -355,7 +391,7 @@ class ViltDatEngine:
             L.adapter_fwd(l0["h3"], self.h_out, self._segs(0, True, False), R2, z_save=self.zsave[0])
         for i in range(1, self.nl - 1):
             # one C-ABI call per layer (feddat_vilt_layer_fwd): ViltLayer body + adapter + the next layer's layernorm_before
-            if not self.use_layer_calls:
+            if not self.use_layer_calls or self.fp8:
                 a = self.act[i]
                 self._layer_body(i, a["h_in"], R2, 2 * B, a["qkv"], a["ctx"], a["lse"], a["h2"], a["h3"], st1=a["st1"],
                                  st2=a["st2"], u=a["u"], mask=m2, ln1_done=True)
@@ -400,7 +436,12 @@ class ViltDatEngine:
         a, W, H, t = self.act[i], self.layers[i], self.H, self.top
         R2, nb = 2 * self.R, 2 * self.B
         x16 = self.x16[:R2]       # LN1 of this layer: written by the previous layer's fused adapter + LN kernel
-        L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
+        if self._fp8_rows(R2):
+            L.layernorm_fwd_fp8(a["h_in"], W["ln1g"], W["ln1b"], self.ln_eps, R2, H, self.x8[:R2], self.xs[:R2],
+                                stats=a["st1"])
+            L.gemm_fp8_nt(self.x8[:R2], self.xs[:R2], W["wqkv8"], W["sqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
+        else:
+            L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
         L.attn_fwd(a["qkv"], a["ctx"], a["lse"], nb, self.S, self.heads, key_mask=mask)
         L.gemm_bf16_nt(self._cls_rows(a["ctx"], nb), W["wo"], L.EPI_RESID_F32, bias=W["bo"],
                        resid=self._cls_rows(a["h_in"], nb), out_f32=t["h2"], skinny_workspace=self._skinny_ws())

@@ -65,6 +65,9 @@ _SIGS = {
     "feddat_fedavg_allreduce": [vp, vp, vp, i64, f32, f32, vp],
     "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
     "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
+    "feddat_gemm_fp8_nt": [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp],
+    "feddat_quant_rows_fp8": [vp, i64, i32, i32, vp, vp, vp],
+    "feddat_layernorm_fwd_fp8": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
     "feddat_gemm_bf16_nt_skinny": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32,
                                    vp, i64, vp],
     "feddat_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
@@ -254,6 +257,29 @@ def gemm_bf16_nt(A, B, epi, *, bias=None, resid=None, aux=None, out_f32=None, ou
                                     ld(resid), _p(aux), ld(aux), _p(out_f32), ld(out_f32), _p(out_bf16),
                                     ld(out_bf16), _p(out2_bf16), ld(out2_bf16), _stream())
     _chk(rc, "feddat_gemm_bf16_nt")
+
+
+def gemm_fp8_nt(A8, a_scale, B8, b_scale, epi, *, bias=None, out_bf16=None, out2_bf16=None):
+    """C = (A8 @ B8^T) * a_scale[:, None] * b_scale[None, :] (+ bias; epilogue EPI_BF16 or EPI_GELU); A8 / B8: e4m3 bytes as
+    uint8 / float8 tensors [M,K] / [N,K]."""
+    _dev(A8, B8, a_scale, b_scale, out_bf16)
+    M, K = A8.shape
+    N = B8.shape[0]
+    _chk(load().feddat_gemm_fp8_nt(_p(A8), A8.stride(0), _p(a_scale), _p(B8), B8.stride(0), _p(b_scale), M, N, K, epi,
+                                   _p(bias), _p(out_bf16), out_bf16.stride(0), _p(out2_bf16),
+                                   0 if out2_bf16 is None else out2_bf16.stride(0), _stream()), "feddat_gemm_fp8_nt")
+
+
+def quant_rows_fp8(x, y8, scale):
+    _dev(x, y8, scale)
+    _chk(load().feddat_quant_rows_fp8(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(y8), _p(scale), _stream()),
+         "feddat_quant_rows_fp8")
+
+
+def layernorm_fwd_fp8(x, gamma, beta, eps, rows, H, y_fp8, y_scale, *, y_bf16=None, stats=None, x_stride=None):
+    _dev(x, y_fp8, y_scale)
+    _chk(load().feddat_layernorm_fwd_fp8(_p(x), H if x_stride is None else x_stride, _p(gamma), _p(beta), eps, rows, H,
+                                         _p(y_fp8), _p(y_scale), _p(y_bf16), _p(stats), _stream()), "feddat_layernorm_fwd_fp8")
 
 
 def attn_fwd(qkv, ctx, lse, B, S, heads, key_mask=None):

@@ -65,6 +65,18 @@ int feddat_set_debug_flags(int flags);
 int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
                         const float* bias, const float* resid, int ldr, const void* aux, int ldaux, float* out_f32,
                         int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream);
+/* configs[4]: fp8 (OCP e4m3) MFMA for frozen linears.  A8 [M,K] and B8 [N,K] are e4m3 with per-row scales (a_scale [M],
+ * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias, epilogue BF16 or GELU as above).
+ * Same persistent kernel and data movement as the bf16 form (128 fp8 per 128-byte LDS row), v_mfma_f32_16x16x32_fp8_fp8.
+ * Requirements: M >= 1024, N % 192 == 0, K % 128 == 0, lda / ldb % 16 == 0, 16-byte aligned outputs.
+ * feddat_quant_rows_fp8: fp32 [rows, cols] -> e4m3 + per-row scale amax / 448 (weights at load time; any activation);
+ * feddat_layernorm_fwd_fp8: LayerNorm whose output leaves as e4m3 + per-row scale (optionally also bf16). */
+int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb, const float* b_scale, int M,
+                       int N, int K, int epi, const float* bias, void* out_bf16, int ldo16, void* out2_bf16, int ldo2,
+                       hipStream_t stream);
+int feddat_quant_rows_fp8(const float* x, long ld, int rows, int cols, void* y_fp8, float* scale, hipStream_t stream);
+int feddat_layernorm_fwd_fp8(const float* x, long x_stride, const float* gamma, const float* beta, float eps, int rows,
+                             int H, void* y_fp8, float* y_scale, void* y_bf16, float* stats, hipStream_t stream);
 /* The same product for M <= 64 rows (the top ViLT layer only needs its 2B token-0 rows behind the attention, because the
  * pooler reads hidden_states[:, 0] only: vilt.py:127): split over (N/64) x ksplit blocks into fp32 partials in
  * `workspace` (feddat_gemm_skinny_workspace_elems(M, N, K) floats), summed in a fixed order by a second kernel that

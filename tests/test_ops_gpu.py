@@ -712,3 +712,67 @@ def test_attn2_fwd_bwd_vs_fp32_reference(L, B, Sq, Skv, heads, causal, masked):
                       (dkv[:, :H], kr.grad.transpose(1, 2).reshape(B * Skv, H)),
                       (dkv[:, H:], vr.grad.transpose(1, 2).reshape(B * Skv, H))):
         assert rel_err(got, want) < 2e-2, rel_err(got, want)
+
+
+# ------------------------------------------------------------------ configs[4]: fp8 (e4m3) frozen linears
+def _fp8_deq(y8, scale):
+    return y8.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+@pytest.mark.parametrize("rows,cols", [(2304, 768), (37, 3072)])
+def test_quant_rows_fp8(L, rows, cols):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, cols, generator=g) * torch.rand(rows, 1, generator=g) * 3).to(DEV)
+    x[3] = 0.0                                                     # an all-zero row must not divide by zero
+    y8 = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(rows, device=DEV)
+    L.quant_rows_fp8(x, y8, sc)
+    amax = x.abs().amax(1)
+    assert torch.allclose(sc, torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)), rtol=1e-6)
+    ref8 = (x / sc[:, None]).to(torch.float8_e4m3fn)               # torch's own round-to-nearest-even e4m3 conversion
+    assert torch.equal(y8.view(torch.float8_e4m3fn).float(), ref8.float())
+    assert (_fp8_deq(y8, sc) - x).abs().max() <= (amax.max() / 448.0) * 16 + 1e-6     # half an ulp at the top binade
+
+
+def test_layernorm_fwd_fp8(L):
+    rows, H = 500, 768
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(rows, H, generator=g) * 2).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV), (0.1 * torch.randn(H, generator=g)).to(DEV)
+    y8 = torch.empty(rows, H, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(rows, device=DEV)
+    y16 = torch.empty(rows, H, dtype=torch.bfloat16, device=DEV)
+    st = torch.empty(rows, 2, device=DEV)
+    L.layernorm_fwd_fp8(x, gamma, beta, 1e-12, rows, H, y8, sc, y_bf16=y16, stats=st)
+    ref = F.layer_norm(x, (H,), gamma, beta, 1e-12)
+    assert rel_err(y16, ref) < 1e-2
+    assert torch.allclose(sc, ref.abs().amax(1) / 448.0, rtol=1e-4)
+    assert torch.equal(y8.view(torch.float8_e4m3fn).float(), (ref / sc[:, None]).to(torch.float8_e4m3fn).float()) or \
+        (_fp8_deq(y8, sc) - ref).abs().max() < 0.07 * ref.abs().max()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(11840, 2304, 768, 0), (11840, 3072, 768, 2), (5920, 3072, 768, 2), (1200, 192, 256, 0)])
+def test_gemm_fp8_vs_fp32_on_the_dequantised_operands(L, M, N, K, epi):
+    """The kernel's own arithmetic: e4m3 x e4m3 products are exact in fp32, so against an fp32 product of the dequantised
+    operands only the accumulation order and the bf16 output rounding differ."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    A8, sa = torch.empty(M, K, dtype=torch.uint8, device=DEV), torch.empty(M, device=DEV)
+    W8, sw = torch.empty(N, K, dtype=torch.uint8, device=DEV), torch.empty(N, device=DEV)
+    L.quant_rows_fp8(A, A8, sa)
+    L.quant_rows_fp8(W, W8, sw)
+    ref = _fp8_deq(A8, sa) @ _fp8_deq(W8, sw).t() + bias
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    if epi == 0:
+        L.gemm_fp8_nt(A8, sa, W8, sw, L.EPI_BF16, bias=bias, out_bf16=out)
+        assert rel_err(out, ref) < 1e-2
+    else:
+        u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        L.gemm_fp8_nt(A8, sa, W8, sw, L.EPI_GELU, bias=bias, out_bf16=out, out2_bf16=u)
+        assert rel_err(u, ref) < 1e-2 and rel_err(out, F.gelu(ref)) < 1e-2
+    # and how far fp8 operands are from the fp32 product itself (the precision cost of configs[4], reported not bounded tightly)
+    full = A @ W.t() + bias
+    print(f"fp8 ({M},{N},{K}): rel err vs fp32 operands {rel_err(ref, full):.4f}")
+    assert rel_err(ref, full) < 0.08
