@@ -36,20 +36,39 @@ __device__ __forceinline__ bf16x8 tr_frag8(const char* m, int r0a, int r0b, int 
     const bf16x4 b = tr_frag(m, r0b, c0, lane);
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
-// cooperative, row-contiguous load of rows [r0, r0 + 64) of one head's [S][64] bf16 slice into swizzled LDS (zero beyond S)
+// cooperative, row-contiguous load of rows [r0, r0 + ROWS) of one head's [S][64] bf16 slice into swizzled LDS (zero beyond S)
+template <int ROWS>
 __device__ __forceinline__ void load_rows(const bf16* __restrict__ src, long ld, int r0, int S, char* dst, int tid) {
-    for (int idx = tid; idx < BLK * 8; idx += 256) {
+#pragma unroll
+    for (int idx = tid; idx < ROWS * 8; idx += 256) {
         const int row = idx >> 3, chunk = idx & 7;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (r0 + row < S) v = *reinterpret_cast<const bf16x8*>(src + (size_t)(r0 + row) * ld + chunk * 8);
         *reinterpret_cast<bf16x8*>(dst + sw_off(row, chunk)) = v;
     }
 }
-// the block's [64][64] result, written by the waves in accumulator layout (row 16 w + i16, cols 16 dt + 4 g ..), leaves
-// LDS row-contiguously
-__device__ __forceinline__ void put_acc(char* stg, int wave, int lane, const f32x4 (&o)[4], float mul) {
+// the same for one streamed 64-row chunk, split in two: the loads of chunk j + 1 are issued (into registers) before the
+// products on chunk j and land in LDS after them
+__device__ __forceinline__ void chunk_fetch(const bf16* __restrict__ src, long ld, int r0, int S, int tid, bf16x8 (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i, chunk = tid & 7;
+        v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (r0 + row < S) v[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)(r0 + row) * ld + chunk * 8);
+    }
+}
+__device__ __forceinline__ void chunk_commit(char* dst, int tid, const bf16x8 (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i, chunk = tid & 7;
+        *reinterpret_cast<bf16x8*>(dst + sw_off(row, chunk)) = v[i];
+    }
+}
+// a wave's [16][64] result tile in accumulator layout (row rowbase + i16, cols 16 dt + 4 g ..) goes to the staging tile,
+// which then leaves LDS row-contiguously
+__device__ __forceinline__ void put_acc(char* stg, int rowbase, int lane, const f32x4 (&o)[4], float mul) {
     const int g = lane >> 4, i16 = lane & 15;
-    const int row = wave * 16 + i16;
+    const int row = rowbase + i16;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
         const int col = dt * 16 + 4 * g;
@@ -57,8 +76,10 @@ __device__ __forceinline__ void put_acc(char* stg, int wave, int lane, const f32
             cvt4(o[dt] * f32x4{mul, mul, mul, mul});
     }
 }
+template <int ROWS>
 __device__ __forceinline__ void store_rows(bf16* __restrict__ dst, long ld, int r0, int S, const char* stg, int tid) {
-    for (int idx = tid; idx < BLK * 8; idx += 256) {
+#pragma unroll
+    for (int idx = tid; idx < ROWS * 8; idx += 256) {
         const int row = idx >> 3, chunk = idx & 7;
         if (r0 + row < S)
             *reinterpret_cast<bf16x8*>(dst + (size_t)(r0 + row) * ld + chunk * 8) =
@@ -80,101 +101,148 @@ struct Attn2Args {
     bf16 *dq, *dk, *dv;  long lddq, lddk, lddv;
 };
 
+// All three kernels are templated on QT = 16-row tiles per wave on the block's own side (block = 64 QT rows): every
+// fragment of the streamed side read from LDS feeds QT MFMAs.  With QT = 1 a chunk costs the CU's one LDS pipe ~2x the
+// cycles its four MFMA pipes need (4 waves x (8 ds_read_b128 + 16 ds_read_b64_tr) against 16 MFMAs per wave); QT = 2 is
+// used for long sequences (577 image tokens), QT = 1 for the <= 64-row text streams.
+template <int QT>
 __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
-    __shared__ __attribute__((aligned(16))) char Qs[BLK * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
+    constexpr int QB = BLK * QT;
+    __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
     __shared__ float mask_add[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int q0 = qb * BLK;
+    const int q0 = qb * QB;
     const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
-    load_rows(Q, a.ldq, q0, a.Sq, Qs, tid);
+    const int kend = a.causal ? min(a.Skv, q0 + QB) : a.Skv;
+    bf16x8 kpre[2], vpre[2];
+    chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
+    chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
+    load_rows<QB>(Q, a.ldq, q0, a.Sq, Qs, tid);
     __syncthreads();
-    const bf16x8 qf0 = row_frag(Qs, wave * 16 + i16, g), qf1 = row_frag(Qs, wave * 16 + i16, 4 + g);
-    const int qi = q0 + wave * 16 + i16;          // this lane's query
-    float m = -INFINITY, l = 0.f;
-    f32x4 o[4];
+    bf16x8 qf0[QT], qf1[QT];
+    int qi[QT];                                    // this lane's queries
+    float m[QT], l[QT];
+    f32x4 o[QT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kend = a.causal ? min(a.Skv, q0 + BLK) : a.Skv;
+    for (int t = 0; t < QT; ++t) {
+        const int qrow = (wave * QT + t) * 16 + i16;
+        qf0[t] = row_frag(Qs, qrow, g);
+        qf1[t] = row_frag(Qs, qrow, 4 + g);
+        qi[t] = q0 + qrow;
+        m[t] = -INFINITY;
+        l[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int k0 = 0; k0 < kend; k0 += BLK) {
         __syncthreads();
-        load_rows(K, a.ldk, k0, a.Skv, Ks, tid);
-        load_rows(V, a.ldv, k0, a.Skv, Vs, tid);
+        chunk_commit(Ks, tid, kpre);
+        chunk_commit(Vs, tid, vpre);
         if (tid < BLK) {
             const int kk = k0 + tid;
             mask_add[tid] = (kk < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + kk])) ? 0.f : -INFINITY;
         }
+        if (k0 + BLK < kend) {
+            chunk_fetch(K, a.ldk, k0 + BLK, a.Skv, tid, kpre);
+            chunk_fetch(V, a.ldv, k0 + BLK, a.Skv, tid, vpre);
+        }
         __syncthreads();
-        f32x4 s[4];
-        float cmx = -INFINITY;
+        f32x4 s[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            t = mfma16x32(row_frag(Ks, kt * 16 + i16, g), qf0, t);        // S^T: rows = keys kt*16 + 4g + e, col = query i16
-            t = mfma16x32(row_frag(Ks, kt * 16 + i16, 4 + g), qf1, t);
+            const bf16x8 kf0 = row_frag(Ks, kt * 16 + i16, g), kf1 = row_frag(Ks, kt * 16 + i16, 4 + g);
             const f32x4 ma = *reinterpret_cast<const f32x4*>(mask_add + kt * 16 + 4 * g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = t[e] * SC + ma[e];
-                if (a.causal && k0 + kt * 16 + 4 * g + e > qi) x = -INFINITY;
-                t[e] = x;
-                cmx = fmaxf(cmx, x);
+            for (int t = 0; t < QT; ++t) {
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                x = mfma16x32(kf0, qf0[t], x);            // S^T: rows = keys kt*16 + 4g + e, col = query i16
+                x = mfma16x32(kf1, qf1[t], x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = x[e] * SC + ma[e];
+                    if (a.causal && k0 + kt * 16 + 4 * g + e > qi[t]) y = -INFINITY;
+                    x[e] = y;
+                }
+                s[t][kt] = x;
             }
-            s[kt] = t;
         }
-        cmx = fmaxf(cmx, __shfl_xor(cmx, 16, 64));
-        cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
-        const float m_new = fmaxf(m, cmx);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;         // a fully masked prefix contributes nothing
-        const float alpha = __builtin_amdgcn_exp2f(m - m_use);         // m = -inf -> 0
-        float csum = 0.f;
+        bf16x8 pb[QT][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int t = 0; t < QT; ++t) {
+            float cmx = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - m_use);
-                csum += s[kt][e];
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cmx = fmaxf(cmx, s[t][kt][e]);
+            cmx = fmaxf(cmx, __shfl_xor(cmx, 16, 64));
+            cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
+            const float m_new = fmaxf(m[t], cmx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;         // a fully masked prefix contributes nothing
+            const float alpha = __builtin_amdgcn_exp2f(m[t] - m_use);     // m = -inf -> 0
+            float csum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[t][kt][e] = __builtin_amdgcn_exp2f(s[t][kt][e] - m_use);
+                    csum += s[t][kt][e];
+                }
+            csum += __shfl_xor(csum, 16, 64);
+            csum += __shfl_xor(csum, 32, 64);
+            l[t] = l[t] * alpha + csum;
+            m[t] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[t][dt] = o[t][dt] * f32x4{alpha, alpha, alpha, alpha};
+            pb[t][0] = cvt8(s[t][0], s[t][1]);
+            pb[t][1] = cvt8(s[t][2], s[t][3]);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {                             // O^T[d][q] += V^T[d][key] P^T[key][q]
+                const bf16x8 vt = tr_frag8(Vs, st * 32 + 4 * g, st * 32 + 16 + 4 * g, dt * 16, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o[t][dt] = mfma16x32(vt, pb[t][st], o[t][dt]);
             }
-        csum += __shfl_xor(csum, 16, 64);
-        csum += __shfl_xor(csum, 32, 64);
-        l = l * alpha + csum;
-        m = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * f32x4{alpha, alpha, alpha, alpha};
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const bf16x8 pb = cvt8(s[2 * st], s[2 * st + 1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)                               // O^T[d][q] += V^T[d][key] P^T[key][q]
-                o[dt] = mfma16x32(tr_frag8(Vs, st * 32 + 4 * g, st * 32 + 16 + 4 * g, dt * 16, lane), pb, o[dt]);
-        }
     }
     __syncthreads();                                                     // Qs is reused as the output staging tile
-    put_acc(Qs, wave, lane, o, l > 0.f ? 1.0f / l : 0.f);
-    if (g == 0 && qi < a.Sq && a.lse)
-        a.lse[((size_t)b * a.heads + h) * a.Sq + qi] = l > 0.f ? m * (1.0f / LOG2E) + __logf(l) : -INFINITY;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        put_acc(Qs, (wave * QT + t) * 16, lane, o[t], l[t] > 0.f ? 1.0f / l[t] : 0.f);
+        if (g == 0 && qi[t] < a.Sq && a.lse)
+            a.lse[((size_t)b * a.heads + h) * a.Sq + qi[t]] =
+                l[t] > 0.f ? m[t] * (1.0f / LOG2E) + __logf(l[t]) : -INFINITY;
+    }
     __syncthreads();
-    store_rows(a.o + (size_t)b * a.sq_b * a.ldo + h * D, a.ldo, q0, a.Sq, Qs, tid);
+    store_rows<QB>(a.o + (size_t)b * a.sq_b * a.ldo + h * D, a.ldo, q0, a.Sq, Qs, tid);
 }
 
-// dQ (and D = rowsum(dO * O)) of one 64-query block: K / V stream through LDS.
+// dQ (and D = rowsum(dO * O)) of one 64 QT-query block: K / V stream through LDS.
+template <int QT>
 __global__ __launch_bounds__(256) void attn2_bwd_dq_kernel(Attn2Args a) {
-    __shared__ __attribute__((aligned(16))) char Qs[BLK * ROWB], Gs[BLK * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
-    __shared__ float Dv[BLK], kvalid[BLK];
+    constexpr int QB = BLK * QT;
+    __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Gs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
+    __shared__ float Dv[QB], kvalid[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int q0 = qb * BLK;
+    const int q0 = qb * QB;
     const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
     const bf16* O = a.o + (size_t)b * a.sq_b * a.ldo + h * D;
     const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
-    load_rows(Q, a.ldq, q0, a.Sq, Qs, tid);
-    for (int idx = tid; idx < BLK * 8; idx += 256) {          // dO -> LDS, D[q] = sum_d dO[q][d] O[q][d]
+    const int kend = a.causal ? min(a.Skv, q0 + QB) : a.Skv;
+    bf16x8 kpre[2], vpre[2];
+    chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
+    chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
+    load_rows<QB>(Q, a.ldq, q0, a.Sq, Qs, tid);
+#pragma unroll
+    for (int idx = tid; idx < QB * 8; idx += 256) {          // dO -> LDS, D[q] = sum_d dO[q][d] O[q][d]
         const int row = idx >> 3, chunk = idx & 7;
         bf16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
         float part = 0.f;
@@ -194,129 +262,188 @@ __global__ __launch_bounds__(256) void attn2_bwd_dq_kernel(Attn2Args a) {
         }
     }
     __syncthreads();
-    const int qrow = wave * 16 + i16, qi = q0 + qrow;
-    const bf16x8 qf0 = row_frag(Qs, qrow, g), qf1 = row_frag(Qs, qrow, 4 + g);
-    const bf16x8 gf0 = row_frag(Gs, qrow, g), gf1 = row_frag(Gs, qrow, 4 + g);
-    const float dq_ = Dv[qrow];
-    const float lq = qi < a.Sq ? a.lse[((size_t)b * a.heads + h) * a.Sq + qi] * LOG2E : 0.f;
-    f32x4 dq[4];
+    bf16x8 qf0[QT], qf1[QT], gf0[QT], gf1[QT];
+    int qi[QT];
+    float dq_[QT], lq[QT];
+    f32x4 dq[QT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kend = a.causal ? min(a.Skv, q0 + BLK) : a.Skv;
+    for (int t = 0; t < QT; ++t) {
+        const int qrow = (wave * QT + t) * 16 + i16;
+        qi[t] = q0 + qrow;
+        qf0[t] = row_frag(Qs, qrow, g);
+        qf1[t] = row_frag(Qs, qrow, 4 + g);
+        gf0[t] = row_frag(Gs, qrow, g);
+        gf1[t] = row_frag(Gs, qrow, 4 + g);
+        dq_[t] = Dv[qrow];
+        lq[t] = qi[t] < a.Sq ? a.lse[((size_t)b * a.heads + h) * a.Sq + qi[t]] * LOG2E : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int k0 = 0; k0 < kend; k0 += BLK) {
         __syncthreads();
-        load_rows(K, a.ldk, k0, a.Skv, Ks, tid);
-        load_rows(V, a.ldv, k0, a.Skv, Vs, tid);
+        chunk_commit(Ks, tid, kpre);
+        chunk_commit(Vs, tid, vpre);
         if (tid < BLK) {
             const int kk = k0 + tid;
             kvalid[tid] = (kk < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + kk])) ? 1.f : 0.f;
         }
+        if (k0 + BLK < kend) {
+            chunk_fetch(K, a.ldk, k0 + BLK, a.Skv, tid, kpre);
+            chunk_fetch(V, a.ldv, k0 + BLK, a.Skv, tid, vpre);
+        }
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f32x4 ds[2];
+            f32x4 ds[QT][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int krow = (2 * ks + t) * 16;
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                sc = mfma16x32(row_frag(Ks, krow + i16, g), qf0, sc);
-                sc = mfma16x32(row_frag(Ks, krow + i16, 4 + g), qf1, sc);
-                dp = mfma16x32(row_frag(Vs, krow + i16, g), gf0, dp);
-                dp = mfma16x32(row_frag(Vs, krow + i16, 4 + g), gf1, dp);
+            for (int tt = 0; tt < 2; ++tt) {
+                const int krow = (2 * ks + tt) * 16;
+                const bf16x8 kf0 = row_frag(Ks, krow + i16, g), kf1 = row_frag(Ks, krow + i16, 4 + g);
+                const bf16x8 vf0 = row_frag(Vs, krow + i16, g), vf1 = row_frag(Vs, krow + i16, 4 + g);
                 const f32x4 kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pe = kv4[e] * __builtin_amdgcn_exp2f(sc[e] * SC - lq);
-                    if (a.causal && k0 + krow + 4 * g + e > qi) pe = 0.f;
-                    ds[t][e] = pe * (dp[e] - dq_);                     // the 1/8 of dS is applied at the end
+                for (int t = 0; t < QT; ++t) {
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc = mfma16x32(kf0, qf0[t], sc);
+                    sc = mfma16x32(kf1, qf1[t], sc);
+                    dp = mfma16x32(vf0, gf0[t], dp);
+                    dp = mfma16x32(vf1, gf1[t], dp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pe = kv4[e] * __builtin_amdgcn_exp2f(sc[e] * SC - lq[t]);
+                        if (a.causal && k0 + krow + 4 * g + e > qi[t]) pe = 0.f;
+                        ds[t][tt][e] = pe * (dp[e] - dq_[t]);              // the 1/8 of dS is applied at the end
+                    }
                 }
             }
-            const bf16x8 dsb = cvt8(ds[0], ds[1]);
+            bf16x8 dsb[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) dsb[t] = cvt8(ds[t][0], ds[t][1]);
             const int r0a = (2 * ks) * 16 + 4 * g, r0b = (2 * ks + 1) * 16 + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kt = tr_frag8(Ks, r0a, r0b, dt * 16, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) dq[t][dt] = mfma16x32(kt, dsb[t], dq[t][dt]);
+            }
         }
     }
     __syncthreads();
-    put_acc(Qs, wave, lane, dq, 0.125f);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) put_acc(Qs, (wave * QT + t) * 16, lane, dq[t], 0.125f);
     __syncthreads();
-    store_rows(a.dq + (size_t)b * a.sq_b * a.lddq + h * D, a.lddq, q0, a.Sq, Qs, tid);
+    store_rows<QB>(a.dq + (size_t)b * a.sq_b * a.lddq + h * D, a.lddq, q0, a.Sq, Qs, tid);
 }
 
-// dK, dV of one 64-key block: Q / dO (and their LSE / D) stream through LDS.
+// dK, dV of one 64 QT-key block: Q / dO (and their LSE / D) stream through LDS.
+template <int QT>
 __global__ __launch_bounds__(256) void attn2_bwd_dkv_kernel(Attn2Args a) {
-    __shared__ __attribute__((aligned(16))) char Ks[BLK * ROWB], Vs[BLK * ROWB], Qs[BLK * ROWB], Gs[BLK * ROWB];
+    constexpr int KB = BLK * QT;
+    __shared__ __attribute__((aligned(16))) char Ks[KB * ROWB], Vs[KB * ROWB], Qs[BLK * ROWB], Gs[BLK * ROWB];
     __shared__ float Ls[BLK], Dv[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int k0 = kb * BLK;
+    const int k0 = kb * KB;
     const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
     const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
-    load_rows(K, a.ldk, k0, a.Skv, Ks, tid);
-    load_rows(V, a.ldv, k0, a.Skv, Vs, tid);
+    const int qstart = a.causal ? k0 : 0;                    // queries before the block's first key see none of it
+    bf16x8 qpre[2], gpre[2];
+    chunk_fetch(Q, a.ldq, qstart, a.Sq, tid, qpre);
+    chunk_fetch(G, a.lddo, qstart, a.Sq, tid, gpre);
+    load_rows<KB>(K, a.ldk, k0, a.Skv, Ks, tid);
+    load_rows<KB>(V, a.ldv, k0, a.Skv, Vs, tid);
     __syncthreads();
-    const int krow = wave * 16 + i16, key = k0 + krow;
-    const bf16x8 kf0 = row_frag(Ks, krow, g), kf1 = row_frag(Ks, krow, 4 + g);
-    const bf16x8 vf0 = row_frag(Vs, krow, g), vf1 = row_frag(Vs, krow, 4 + g);
-    const float kv = (key < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + key])) ? 1.f : 0.f;
-    f32x4 dv[4], dk[4];
+    bf16x8 kf0[QT], kf1[QT], vf0[QT], vf1[QT];
+    int key[QT];
+    float kv[QT];
+    f32x4 dv[QT][4], dk[QT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < QT; ++t) {
+        const int krow = (wave * QT + t) * 16 + i16;
+        key[t] = k0 + krow;
+        kf0[t] = row_frag(Ks, krow, g);
+        kf1[t] = row_frag(Ks, krow, 4 + g);
+        vf0[t] = row_frag(Vs, krow, g);
+        vf1[t] = row_frag(Vs, krow, 4 + g);
+        kv[t] = (key[t] < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + key[t]])) ? 1.f : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    const int qstart = a.causal ? (k0 / BLK) * BLK : 0;              // queries before the block's first key see none of it
     for (int q0 = qstart; q0 < a.Sq; q0 += BLK) {
         __syncthreads();
-        load_rows(Q, a.ldq, q0, a.Sq, Qs, tid);
-        load_rows(G, a.lddo, q0, a.Sq, Gs, tid);
+        chunk_commit(Qs, tid, qpre);
+        chunk_commit(Gs, tid, gpre);
         if (tid < BLK) {
             const int qq = q0 + tid;
             const size_t si = ((size_t)b * a.heads + h) * a.Sq + qq;
             Ls[tid] = qq < a.Sq ? a.lse[si] * LOG2E : INFINITY;          // rows past Sq: p = exp2(-inf) = 0
             Dv[tid] = qq < a.Sq ? a.dsum[si] : 0.f;
         }
+        if (q0 + BLK < a.Sq) {
+            chunk_fetch(Q, a.ldq, q0 + BLK, a.Sq, tid, qpre);
+            chunk_fetch(G, a.lddo, q0 + BLK, a.Sq, tid, gpre);
+        }
         __syncthreads();
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            f32x4 p[2], ds[2];
+            f32x4 p[QT][2], ds[QT][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int qrow = (2 * qs + t) * 16;
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                sc = mfma16x32(row_frag(Qs, qrow + i16, g), kf0, sc);     // S: rows = queries qrow + 4g + e, col = key i16
-                sc = mfma16x32(row_frag(Qs, qrow + i16, 4 + g), kf1, sc);
-                dp = mfma16x32(row_frag(Gs, qrow + i16, g), vf0, dp);
-                dp = mfma16x32(row_frag(Gs, qrow + i16, 4 + g), vf1, dp);
+            for (int tt = 0; tt < 2; ++tt) {
+                const int qrow = (2 * qs + tt) * 16;
+                const bf16x8 qa = row_frag(Qs, qrow + i16, g), qb2 = row_frag(Qs, qrow + i16, 4 + g);
+                const bf16x8 ga = row_frag(Gs, qrow + i16, g), gb2 = row_frag(Gs, qrow + i16, 4 + g);
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qrow + 4 * g);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + qrow + 4 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pe = kv * __builtin_amdgcn_exp2f(sc[e] * SC - l4[e]);
-                    if (a.causal && key > q0 + qrow + 4 * g + e) pe = 0.f;
-                    p[t][e] = pe;
-                    ds[t][e] = pe * (dp[e] - d4[e]);
+                for (int t = 0; t < QT; ++t) {
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc = mfma16x32(qa, kf0[t], sc);                     // S: rows = queries qrow + 4g + e, col = key i16
+                    sc = mfma16x32(qb2, kf1[t], sc);
+                    dp = mfma16x32(ga, vf0[t], dp);
+                    dp = mfma16x32(gb2, vf1[t], dp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pe = kv[t] * __builtin_amdgcn_exp2f(sc[e] * SC - l4[e]);
+                        if (a.causal && key[t] > q0 + qrow + 4 * g + e) pe = 0.f;
+                        p[t][tt][e] = pe;
+                        ds[t][tt][e] = pe * (dp[e] - d4[e]);
+                    }
                 }
             }
-            const bf16x8 pb = cvt8(p[0], p[1]);
-            const bf16x8 dsb = cvt8(ds[0], ds[1]);
+            bf16x8 pb[QT], dsb[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                pb[t] = cvt8(p[t][0], p[t][1]);
+                dsb[t] = cvt8(ds[t][0], ds[t][1]);
+            }
             const int r0a = (2 * qs) * 16 + 4 * g, r0b = (2 * qs + 1) * 16 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = mfma16x32(tr_frag8(Gs, r0a, r0b, dt * 16, lane), pb, dv[dt]);
-                dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
+                const bf16x8 gt = tr_frag8(Gs, r0a, r0b, dt * 16, lane);
+                const bf16x8 qt = tr_frag8(Qs, r0a, r0b, dt * 16, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    dv[t][dt] = mfma16x32(gt, pb[t], dv[t][dt]);
+                    dk[t][dt] = mfma16x32(qt, dsb[t], dk[t][dt]);
+                }
             }
         }
     }
+    __syncthreads();                                         // K / V fragments live in registers: their tiles are the staging
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        put_acc(Ks, (wave * QT + t) * 16, lane, dk[t], 0.125f);
+        put_acc(Vs, (wave * QT + t) * 16, lane, dv[t], 1.0f);
+    }
     __syncthreads();
-    put_acc(Qs, wave, lane, dk, 0.125f);
-    put_acc(Gs, wave, lane, dv, 1.0f);
-    __syncthreads();
-    store_rows(a.dk + (size_t)b * a.skv_b * a.lddk + h * D, a.lddk, k0, a.Skv, Qs, tid);
-    store_rows(a.dv + (size_t)b * a.skv_b * a.lddv + h * D, a.lddv, k0, a.Skv, Gs, tid);
+    store_rows<KB>(a.dk + (size_t)b * a.skv_b * a.lddk + h * D, a.lddk, k0, a.Skv, Ks, tid);
+    store_rows<KB>(a.dv + (size_t)b * a.skv_b * a.lddv + h * D, a.lddv, k0, a.Skv, Vs, tid);
 }
 
 int check(const Attn2Args& a, int B) {
@@ -338,7 +465,8 @@ extern "C" int feddat_attn2_fwd(const void* q, long ldq, const void* k, long ldk
     a.o = (bf16*)ctx; a.ldo = ldo; a.lse = lse;
     const int rc = check(a, B);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn2_fwd_kernel, dim3((Sq + BLK - 1) / BLK, heads, B), dim3(256), 0, stream, a);
+    if (Sq > BLK) hipLaunchKernelGGL(attn2_fwd_kernel<2>, dim3((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn2_fwd_kernel<1>, dim3(1, heads, B), dim3(256), 0, stream, a);
     FD_LAUNCH_RET();
 }
 
@@ -357,7 +485,9 @@ extern "C" int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk
     const int rc = check(a, B);
     if (rc) return rc;
     FD_CHECK_ARG(lse && dctx && dsum_ws && dq && dk && dv && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0);
-    hipLaunchKernelGGL(attn2_bwd_dq_kernel, dim3((Sq + BLK - 1) / BLK, heads, B), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(attn2_bwd_dkv_kernel, dim3((Skv + BLK - 1) / BLK, heads, B), dim3(256), 0, stream, a);
+    if (Sq > BLK) hipLaunchKernelGGL(attn2_bwd_dq_kernel<2>, dim3((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn2_bwd_dq_kernel<1>, dim3(1, heads, B), dim3(256), 0, stream, a);
+    if (Skv > BLK) hipLaunchKernelGGL(attn2_bwd_dkv_kernel<2>, dim3((Skv + 2 * BLK - 1) / (2 * BLK), heads, B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn2_bwd_dkv_kernel<1>, dim3(1, heads, B), dim3(256), 0, stream, a);
     FD_LAUNCH_RET();
 }

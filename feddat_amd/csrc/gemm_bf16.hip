@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 struct GemmArgs {
@@ -182,6 +183,106 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------------------------
+// "mid": the products with few rows (M < 1024: the 800-row text streams and 128-row answer streams of the ALBEF path,
+// its LM head).  With so few tiles a block's k-loop is a chain of dependent L2 / HBM round trips, so the kernel is built
+// for LATENCY: 64 x 64 tiles (4x the blocks of the 128 x 128 kernel, whose 2-stage loop took one full round trip per
+// 64-deep k-tile) and R k-tiles in flight per block IN REGISTERS (global_load_dwordx4 -> ds_write_b128 into a 2-slot LDS
+// image; an LDS-DMA ring was tried first: the CU retires only ~1 KB of global_load_lds per 60-100 cycles, 0.46 us per
+// k-tile with one block per CU and 1.2 us with two).  4 waves (2 x 2), wave tile 32 x 32; same swizzled LDS image,
+// fragment layout and epilogues as gemm_nt_kernel.  The loop body is unrolled R times so the register sets are static;
+// k-tiles past the end are clamped re-loads whose MFMAs are skipped.
+constexpr int MID_R = 6;
+constexpr int MID_LDS = 2 * (64 * 128 + 64 * 128);
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_mid_kernel(GemmArgs g) {
+    constexpr int A_BYTES = 64 * 128, SLOT = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 slots x (A 8 KiB, B 8 KiB)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = g.N / 64;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * 64, n0 = tn * 64;
+
+    // this thread's four 16-byte pieces of a k-tile: rows r0, r0 + 32 of A and of B, logical chunk c
+    const int r0 = tid >> 3, c = tid & 7;
+    const bf16* pa[2];
+    const bf16* pb[2];
+    int lofs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = r0 + 32 * i;
+        pa[i] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + c * 8;
+        pb[i] = g.B + (size_t)(n0 + r) * g.ldb + c * 8;
+        lofs[i] = r * 128 + ((c ^ (r & 7)) << 4);
+    }
+    const int nk = g.K / BK;
+    u32x4 regs[MID_R][4];
+    auto load = [&](int set, int kt) {
+        const int k0 = (kt < nk ? kt : nk - 1) * BK;
+        regs[set][0] = *reinterpret_cast<const u32x4*>(pa[0] + k0);
+        regs[set][1] = *reinterpret_cast<const u32x4*>(pa[1] + k0);
+        regs[set][2] = *reinterpret_cast<const u32x4*>(pb[0] + k0);
+        regs[set][3] = *reinterpret_cast<const u32x4*>(pb[1] + k0);
+    };
+    auto to_lds = [&](int set, int slot) {
+        char* base = smem + slot * SLOT;
+        *reinterpret_cast<u32x4*>(base + lofs[0]) = regs[set][0];
+        *reinterpret_cast<u32x4*>(base + lofs[1]) = regs[set][1];
+        *reinterpret_cast<u32x4*>(base + A_BYTES + lofs[0]) = regs[set][2];
+        *reinterpret_cast<u32x4*>(base + A_BYTES + lofs[1]) = regs[set][3];
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int r = 0; r < MID_R; ++r) load(r, r);
+    to_lds(0, 0);
+    load(0, MID_R);
+    __syncthreads();
+
+    const int frow = lane & 15, fg = lane >> 4;
+    for (int kt0 = 0; kt0 < nk; kt0 += MID_R) {
+#pragma unroll
+        for (int r = 0; r < MID_R; ++r) {
+            const int kt = kt0 + r;
+            // k-tile kt + 1 (register set (r + 1) % R) goes into the slot read one iteration ago, its set is refilled
+            to_lds((r + 1) % MID_R, (kt + 1) & 1);
+            load((r + 1) % MID_R, kt + 1 + MID_R);
+            if (kt < nk) {
+                const char* ta = smem + (kt & 1) * SLOT;
+                const char* tb = ta + A_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 fa[2], fb[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i] = read_frag(ta, wm * 32 + i * 16 + frow, ks * 4 + fg);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[j] = read_frag(tb, wn * 32 + j * 16 + frow, ks * 4 + fg);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16x32(fb[j], fa[i], acc[i][j]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    tile_epilogue_dispatch<2, 2>(g, acc, m0 + wm * 32, n0 + wn * 32, g.M, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // v2: persistent ping-pong kernel.  192 x 192 x 64 tile, 8 waves (4 x 2, 48 x 96 per wave), one block per CU.
 //   * M-tile height is a runtime value <= 192 (rows beyond it are clamped on load, masked on store): with
 //     bm = 185 = one sample's tokens the 11840-row activations of configs[1] split into exactly 64 x (N / 192) tiles
@@ -218,7 +319,6 @@ template <int WM> struct V2Cfg {
     static constexpr int NP = WM + 3;                        // staging pieces per wave and k-tile (A: WM, B: 3)
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgsV2 {
     GemmArgs g;
@@ -797,6 +897,7 @@ int fd_prepare_gemm_kernels() {
         for (int e = 0; e < 5; ++e)
             if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
                 return FEDDAT_ELAUNCH;
+    if (fd_set_max_lds((const void*)gemm_nt_mid_kernel, MID_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     return fd_set_max_lds((const void*)gemm_nt_kernel, 4 * TILE_BYTES);
 }
 
@@ -855,7 +956,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
                                    hipStream_t stream) {
     FD_CHECK_ARG(A && B && M > 0 && N > 0 && K > 0);
     const bool use_v2 = (N % V2_BN == 0) && (K % BK == 0) && (M >= 1024);
-    FD_CHECK_ARG((N % BN == 0 || use_v2) && K % BK == 0);
+    FD_CHECK_ARG((N % BN == 0 || use_v2 || (M < 1024 && N % 64 == 0)) && K % BK == 0);
     FD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K);
     switch (epi) {
         case FEDDAT_EPI_BF16: FD_CHECK_ARG(out_bf16 && ldo16 % 4 == 0); break;
@@ -868,12 +969,6 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             break;
         case FEDDAT_EPI_F32: FD_CHECK_ARG(out_f32 && ldo32 % 4 == 0); break;
         default: return FEDDAT_EINVAL;
-    }
-    if (use_v2) {      // 16-byte bf16 stores / aux loads of the persistent kernel's epilogue
-        if (epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU)
-            FD_CHECK_ARG(ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
-        if (epi == FEDDAT_EPI_GELU && out2_bf16) FD_CHECK_ARG(ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0);
-        if (epi == FEDDAT_EPI_MUL_DGELU) FD_CHECK_ARG(ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0);
     }
     if (use_v2) {      // 16-byte bf16 stores / aux loads of the persistent kernel's epilogue
         if (epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU)
@@ -925,6 +1020,14 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         int grid = total < n_cu ? total : n_cu;
         if ((dbg >> 8) > 0 && (dbg >> 8) < grid) grid = dbg >> 8;      // ablation: cap the number of persistent blocks
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, a2);
+        FD_LAUNCH_RET();
+    }
+    // few rows and too few 128 x 128 tiles to fill the chip: the latency-oriented small-tile kernel
+    const bool v1_ok = N % BN == 0;
+    if (M < 1024 && N % 64 == 0 && (!v1_ok || ((M + BM - 1) / BM) * (N / BN) < 150) && !(fd_debug_flags() & 128)) {
+        const int tm = (M + 63) / 64;
+        if (fd_set_max_lds((const void*)gemm_nt_mid_kernel, MID_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+        hipLaunchKernelGGL(gemm_nt_mid_kernel, dim3(tm * (N / 64)), dim3(256), MID_LDS, stream, g);
         FD_LAUNCH_RET();
     }
     const int tiles = ((M + BM - 1) / BM) * (N / BN);

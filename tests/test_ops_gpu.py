@@ -54,7 +54,11 @@ def test_probe_tr16_layout(L):
 
 
 # ------------------------------------------------------------------ K1 GEMM
-@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (5920, 768, 3072), (11840, 2304, 768),
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64),       # M < 1024: the small-tile ring kernel (64 x 64 tiles)
+                                   (800, 768, 3072), (800, 3072, 768),    # ... ALBEF text-stream shapes; the second on 64 x 128 tiles
+                                   (100, 192, 128), (96, 30592, 768),     # ... N % 128 != 0; the LM-head product
+                                   (1200, 256, 192), (1030, 640, 64),     # M >= 1024, N % 192 != 0: the 128 x 128 kernel
+                                   (5920, 768, 3072), (11840, 2304, 768),
                                    (11840, 3072, 768),    # the only production shape on the 256 x 192 (WM = 4) tiles
                                    (11849, 3072, 768)])   # the same plan with a ragged last M tile
 def test_gemm_epilogues(L, M, N, K):
@@ -673,6 +677,8 @@ def test_fedavg_allreduce_through_the_c_abi_single_rank(L):
     (5, 7, 7, 12, True, True),           # decoder: causal + padded answers
     (5, 7, 25, 12, False, True),         # decoder -> question cross-attention
     (1, 130, 200, 2, True, False),       # causal across chunk boundaries
+    (2, 300, 130, 2, True, True),        # 128-row blocks, ragged last block, causal + mask, Sq > Skv
+    (2, 64, 65, 3, False, True),         # Sq on the 64-row kernel, Skv just over it
 ])
 def test_attn2_fwd_bwd_vs_fp32_reference(L, B, Sq, Skv, heads, causal, masked):
     g = torch.Generator().manual_seed(Sq * 1000 + Skv)
