@@ -105,8 +105,8 @@ struct Attn2Args {
 // fragment of the streamed side read from LDS feeds QT MFMAs.  With QT = 1 a chunk costs the CU's one LDS pipe ~2x the
 // cycles its four MFMA pipes need (4 waves x (8 ds_read_b128 + 16 ds_read_b64_tr) against 16 MFMAs per wave); QT = 2 is
 // used for long sequences (577 image tokens), QT = 1 for the <= 64-row text streams.
-template <int QT>
-__global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
+template <int QT, bool CAUSAL>
+__global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
     constexpr int QB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
     __shared__ float mask_add[BLK];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
     const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
-    const int kend = a.causal ? min(a.Skv, q0 + QB) : a.Skv;
+    const int kend = CAUSAL ? min(a.Skv, q0 + QB) : a.Skv;
     bf16x8 kpre[2], vpre[2];
     chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
     chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float y = x[e] * SC + ma[e];
-                    if (a.causal && k0 + kt * 16 + 4 * g + e > qi[t]) y = -INFINITY;
+                    if (CAUSAL && k0 + kt * 16 + 4 * g + e > qi[t]) y = -INFINITY;
                     x[e] = y;
                 }
                 s[t][kt] = x;
@@ -180,9 +180,19 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
                 for (int e = 0; e < 4; ++e) cmx = fmaxf(cmx, s[t][kt][e]);
             cmx = fmaxf(cmx, __shfl_xor(cmx, 16, 64));
             cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
-            const float m_new = fmaxf(m[t], cmx);
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;         // a fully masked prefix contributes nothing
-            const float alpha = __builtin_amdgcn_exp2f(m[t] - m_use);     // m = -inf -> 0
+            // lazy running maximum: the reference point m only moves when the chunk's maximum exceeds it by more than 2^8
+            // (probabilities stay <= 256, exact in fp32 / same relative rounding in bf16), so the rescale of l and of the 16
+            // accumulator registers is skipped (wave-uniformly) in most chunks; o / l and the LSE do not depend on m
+            const bool move = cmx > m[t] + 8.0f;                            // m = -inf: any finite score moves it
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                const float m_upd = move ? cmx : m[t];
+                const float alpha = m_upd == m[t] ? 1.0f : __builtin_amdgcn_exp2f(m[t] - m_upd);   // m = -inf -> 0
+                l[t] *= alpha;
+                m[t] = m_upd;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[t][dt] = o[t][dt] * f32x4{alpha, alpha, alpha, alpha};
+            }
+            const float m_use = m[t] == -INFINITY ? 0.f : m[t];           // a fully masked prefix contributes nothing
             float csum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -193,10 +203,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
                 }
             csum += __shfl_xor(csum, 16, 64);
             csum += __shfl_xor(csum, 32, 64);
-            l[t] = l[t] * alpha + csum;
-            m[t] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[t][dt] = o[t][dt] * f32x4{alpha, alpha, alpha, alpha};
+            l[t] += csum;
             pb[t][0] = cvt8(s[t][0], s[t][1]);
             pb[t][1] = cvt8(s[t][2], s[t][3]);
         }
@@ -222,8 +229,8 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args a) {
 }
 
 // dQ (and D = rowsum(dO * O)) of one 64 QT-query block: K / V stream through LDS.
-template <int QT>
-__global__ __launch_bounds__(256) void attn2_bwd_dq_kernel(Attn2Args a) {
+template <int QT, bool CAUSAL>
+__global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
     constexpr int QB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Gs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
     __shared__ float Dv[QB], kvalid[BLK];
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_dq_kernel(Attn2Args a) {
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
     const bf16* O = a.o + (size_t)b * a.sq_b * a.ldo + h * D;
     const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
-    const int kend = a.causal ? min(a.Skv, q0 + QB) : a.Skv;
+    const int kend = CAUSAL ? min(a.Skv, q0 + QB) : a.Skv;
     bf16x8 kpre[2], vpre[2];
     chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
     chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_dq_kernel(Attn2Args a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float pe = kv4[e] * __builtin_amdgcn_exp2f(sc[e] * SC - lq[t]);
-                        if (a.causal && k0 + krow + 4 * g + e > qi[t]) pe = 0.f;
+                        if (CAUSAL && k0 + krow + 4 * g + e > qi[t]) pe = 0.f;
                         ds[t][tt][e] = pe * (dp[e] - dq_[t]);              // the 1/8 of dS is applied at the end
                     }
                 }
@@ -336,8 +343,8 @@ __global__ __launch_bounds__(256) void attn2_bwd_dq_kernel(Attn2Args a) {
 }
 
 // dK, dV of one 64 QT-key block: Q / dO (and their LSE / D) stream through LDS.
-template <int QT>
-__global__ __launch_bounds__(256) void attn2_bwd_dkv_kernel(Attn2Args a) {
+template <int QT, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
     constexpr int KB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Ks[KB * ROWB], Vs[KB * ROWB], Qs[BLK * ROWB], Gs[BLK * ROWB];
     __shared__ float Ls[BLK], Dv[BLK];
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_dkv_kernel(Attn2Args a) {
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
     const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
-    const int qstart = a.causal ? k0 : 0;                    // queries before the block's first key see none of it
+    const int qstart = CAUSAL ? k0 : 0;                    // queries before the block's first key see none of it
     bf16x8 qpre[2], gpre[2];
     chunk_fetch(Q, a.ldq, qstart, a.Sq, tid, qpre);
     chunk_fetch(G, a.lddo, qstart, a.Sq, tid, gpre);
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_dkv_kernel(Attn2Args a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float pe = kv[t] * __builtin_amdgcn_exp2f(sc[e] * SC - l4[e]);
-                        if (a.causal && key[t] > q0 + qrow + 4 * g + e) pe = 0.f;
+                        if (CAUSAL && key[t] > q0 + qrow + 4 * g + e) pe = 0.f;
                         p[t][tt][e] = pe;
                         ds[t][tt][e] = pe * (dp[e] - d4[e]);
                     }
@@ -465,8 +472,14 @@ extern "C" int feddat_attn2_fwd(const void* q, long ldq, const void* k, long ldk
     a.o = (bf16*)ctx; a.ldo = ldo; a.lse = lse;
     const int rc = check(a, B);
     if (rc) return rc;
-    if (Sq > BLK) hipLaunchKernelGGL(attn2_fwd_kernel<2>, dim3((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn2_fwd_kernel<1>, dim3(1, heads, B), dim3(256), 0, stream, a);
+    const dim3 grid2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), grid1((Sq + BLK - 1) / BLK, heads, B);
+    if (Sq > BLK && !(fd_debug_flags() & 256)) {
+        if (causal) hipLaunchKernelGGL((attn2_fwd_kernel<2, true>), grid2, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_fwd_kernel<2, false>), grid2, dim3(256), 0, stream, a);
+    } else {
+        if (causal) hipLaunchKernelGGL((attn2_fwd_kernel<1, true>), grid1, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_fwd_kernel<1, false>), grid1, dim3(256), 0, stream, a);
+    }
     FD_LAUNCH_RET();
 }
 
@@ -485,9 +498,21 @@ extern "C" int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk
     const int rc = check(a, B);
     if (rc) return rc;
     FD_CHECK_ARG(lse && dctx && dsum_ws && dq && dk && dv && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0);
-    if (Sq > BLK) hipLaunchKernelGGL(attn2_bwd_dq_kernel<2>, dim3((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn2_bwd_dq_kernel<1>, dim3(1, heads, B), dim3(256), 0, stream, a);
-    if (Skv > BLK) hipLaunchKernelGGL(attn2_bwd_dkv_kernel<2>, dim3((Skv + 2 * BLK - 1) / (2 * BLK), heads, B), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn2_bwd_dkv_kernel<1>, dim3(1, heads, B), dim3(256), 0, stream, a);
+    const dim3 gq2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), gk2((Skv + 2 * BLK - 1) / (2 * BLK), heads, B),
+        g1((Sq + BLK - 1) / BLK, heads, B), g1k((Skv + BLK - 1) / BLK, heads, B);
+    if (Sq > BLK && !(fd_debug_flags() & 256)) {
+        if (causal) hipLaunchKernelGGL((attn2_bwd_dq_kernel<2, true>), gq2, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_bwd_dq_kernel<2, false>), gq2, dim3(256), 0, stream, a);
+    } else {
+        if (causal) hipLaunchKernelGGL((attn2_bwd_dq_kernel<1, true>), g1, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_bwd_dq_kernel<1, false>), g1, dim3(256), 0, stream, a);
+    }
+    if (Skv > BLK && !(fd_debug_flags() & 256)) {
+        if (causal) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<2, true>), gk2, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<2, false>), gk2, dim3(256), 0, stream, a);
+    } else {
+        if (causal) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<1, true>), g1k, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<1, false>), g1k, dim3(256), 0, stream, a);
+    }
     FD_LAUNCH_RET();
 }
