@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradLaunch L) {   // 3 b
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the token loop must not be divergent
     const int g = lane >> 4, i16 = lane & 15;
-    const int chunk = blockIdx.x, blk = blockIdx.y;
+    // token block = fast grid index: consecutive workgroups go to consecutive XCDs and NBLK % 8 == 0, so the 12 column
+    // chunks of one token range share an XCD and its L2 serves 11 of their 12 reads of z / dz
+    const int blk = blockIdx.x, chunk = blockIdx.y;
     const int prob = blockIdx.z;            // 2 * seg + which (0: dW_down = dz^T x, 1: dW_up^T = z^T dy)
     const feddat_wgrad_seg& sg = L.seg[prob >> 1];
     const bool up = prob & 1;
@@ -183,7 +185,7 @@ extern "C" int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, floa
         L.seg[s] = segs[s];
     }
     if (nseg == 1) L.seg[1] = L.seg[0];
-    hipLaunchKernelGGL(wgrad_kernel, dim3(NCH, NBLK, 2 * nseg), dim3(256), 0, stream, L);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(NBLK, NCH, 2 * nseg), dim3(256), 0, stream, L);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((PSTRIDE + 255) / 256, nseg), dim3(256), 0, stream, L);
     FD_LAUNCH_RET();
 }

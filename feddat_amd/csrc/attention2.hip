@@ -473,7 +473,7 @@ extern "C" int feddat_attn2_fwd(const void* q, long ldq, const void* k, long ldk
     const int rc = check(a, B);
     if (rc) return rc;
     const dim3 grid2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), grid1((Sq + BLK - 1) / BLK, heads, B);
-    if (Sq > BLK && !(fd_debug_flags() & 256)) {
+    if (Sq > BLK) {
         if (causal) hipLaunchKernelGGL((attn2_fwd_kernel<2, true>), grid2, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((attn2_fwd_kernel<2, false>), grid2, dim3(256), 0, stream, a);
     } else {
@@ -500,14 +500,14 @@ extern "C" int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk
     FD_CHECK_ARG(lse && dctx && dsum_ws && dq && dk && dv && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0);
     const dim3 gq2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), gk2((Skv + 2 * BLK - 1) / (2 * BLK), heads, B),
         g1((Sq + BLK - 1) / BLK, heads, B), g1k((Skv + BLK - 1) / BLK, heads, B);
-    if (Sq > BLK && !(fd_debug_flags() & 256)) {
+    if (Sq > BLK) {
         if (causal) hipLaunchKernelGGL((attn2_bwd_dq_kernel<2, true>), gq2, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((attn2_bwd_dq_kernel<2, false>), gq2, dim3(256), 0, stream, a);
     } else {
         if (causal) hipLaunchKernelGGL((attn2_bwd_dq_kernel<1, true>), g1, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((attn2_bwd_dq_kernel<1, false>), g1, dim3(256), 0, stream, a);
     }
-    if (Skv > BLK && !(fd_debug_flags() & 256)) {
+    if (Skv > BLK) {
         if (causal) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<2, true>), gk2, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<2, false>), gk2, dim3(256), 0, stream, a);
     } else {

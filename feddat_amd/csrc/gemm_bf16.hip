@@ -1010,6 +1010,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         const int rounds3 = plan(192, a3), rounds4 = plan(256, a4);
         // a 256-row tile costs about 1.2x a 192-row tile (48 vs 36 MFMAs per k-tile and wave, L phase 20 vs 18 reads)
         bool wm4 = rounds4 * 12 < rounds3 * 10;
+        if (epi == FEDDAT_EPI_MUL_DGELU) wm4 = false;      // its 256-row instantiation spills (180 B of scratch per lane and tile)
         if (dbg & 32) wm4 = false;
         if (dbg & 64) wm4 = true;
         a2 = wm4 ? a4 : a3;

@@ -11,7 +11,6 @@ from feddat_amd import lib as L  # noqa: E402
 
 dev = "cuda:0"
 reps = int(os.environ.get("REPS", "20"))
-L.set_debug_flags(int(os.environ.get("FLAGS", "0")))
 for B, Sq, Skv, heads in [(32, 577, 577, 12), (32, 25, 577, 12)]:
     H = heads * 64
     qkv = torch.randn(B * Skv, 3 * H, device=dev).bfloat16()
