@@ -2,21 +2,37 @@
 //     dW_down[r][c] = sum_t dz[t][r] * x[t][c]          db_down[r] = sum_t dz[t][r]
 //     dW_up  [c][r] = s * sum_t dy[t][c] * z[t][r]      db_up  [c] = s * sum_t dy[t][c]
 // Both are "small^T x big" products contracted over the tokens: small = [T,48], big = [T,768], fp32.
-// Exact-fp32 MFMA (v_mfma_f32_16x16x4_f32; its operands are one dword per lane, (index, token) = (lane & 15,
-// lane >> 4), so the token-major activations are consumed as they lie in HBM, no transposes).  A wave owns 64
-// columns x all 48 bottleneck units for a range of tokens: one float4 load of `big` feeds 4 interleaved column
-// tiles, 3 dword loads of `small` feed the 3 r-tiles -> 12 MFMAs per 4 tokens.  The 4 waves of a block own 4
-// consecutive token ranges and are summed through LDS; the 16 blocks per column chunk leave 16 partials that
-// the (deterministic) reduce kernel folds straight into the flat gradient buffer [wd | bd | wu | bu].
-// HBM-bound in bytes (x and dy are each read once: 2 x T x 768 x 4 B), MFMA-f32-bound in time (1/16 of bf16 rate).
+// bf16 MFMA 16x16x32 on split operands (every fp32 value = bf16 head + bf16 remainder, three products per pair: fp32
+// accuracy to ~2^-16 relative per product, fp32 accumulation; details at the loop): lane (index, token group) =
+// (lane & 15, lane >> 4) holds 8 consecutive tokens of its index, so the token-major activations are consumed as they
+// lie in HBM, no transposes.  A wave owns 64 columns x all 48 bottleneck units for a range of tokens: 8 float4 loads of
+// `big` feed 4 interleaved column tiles, 24 dword loads of `small` feed the 3 r-tiles -> 36 MFMAs per 32 tokens.  The 4
+// waves of a block own 4 consecutive token ranges and are summed through LDS; the NBLK blocks per column chunk leave NBLK
+// partials that the (deterministic) reduce kernel folds straight into the flat gradient buffer [wd | bd | wu | bu].
+// HBM-bound in bytes (x and dy are each read once: 2 x T x 768 x 4 B).
 #include "common.hip.h"
 
 namespace {
 
 constexpr int H = 768, R = 48, NRT = 3, CW = 64;          // columns per wave
 constexpr int NCH = H / CW;                                 // 12 column chunks
-constexpr int NBLK = 16;                                    // token-split blocks per column chunk
+constexpr int NBLK = 10;                                    // token-split blocks per column chunk: 12 x 10 x 4 problems = 480 blocks
 constexpr int PSTRIDE = R * H + R + H;                      // one partial: [out r x c | colsum_small | colsum_big]
+
+// x[0..7] (fp32) -> head = bf16(x) (round to nearest even: the remainder is zero-mean and <= 2^-9 |x|, so the dropped
+// remainder x remainder product is ~2^-18 relative; truncated heads left a one-signed 2^-14 bias), rest = bf16(x - head)
+__device__ __forceinline__ void split_bf16x2(const float (&x)[8], bf16x8& head, bf16x8& rest) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    head = cvt8(f32x4{x[0], x[1], x[2], x[3]}, f32x4{x[4], x[5], x[6], x[7]});
+    const u32x4_t hp = __builtin_bit_cast(u32x4_t, head);
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r[2 * k] = x[2 * k] - __uint_as_float(hp[k] << 16);
+        r[2 * k + 1] = x[2 * k + 1] - __uint_as_float(hp[k] & 0xffff0000u);
+    }
+    rest = cvt8(f32x4{r[0], r[1], r[2], r[3]}, f32x4{r[4], r[5], r[6], r[7]});
+}
 
 struct WgradLaunch {
     feddat_wgrad_seg seg[2];
@@ -24,13 +40,12 @@ struct WgradLaunch {
     int nseg;
 };
 
-__global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradLaunch L) {   // 3 blocks per CU: all 768 blocks resident
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 blocks per CU (225 registers, no scratch): 480 blocks = one round
     __shared__ __attribute__((aligned(16))) float red[3][64][NRT * 4 * 4 + 4];  // waves 1..3 -> wave 0
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the token loop must not be divergent
     const int g = lane >> 4, i16 = lane & 15;
-    // token block = fast grid index: consecutive workgroups go to consecutive XCDs and NBLK % 8 == 0, so the 12 column
-    // chunks of one token range share an XCD and its L2 serves 11 of their 12 reads of z / dz
+    // token block = fast grid index
     const int blk = blockIdx.x, chunk = blockIdx.y;
     const int prob = blockIdx.z;            // 2 * seg + which (0: dW_down = dz^T x, 1: dW_up^T = z^T dy)
     const feddat_wgrad_seg& sg = L.seg[prob >> 1];
@@ -40,7 +55,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradLaunch L) {   // 3 b
     const float alpha = up ? sg.scale : 1.0f;
     const int T = sg.rows;
     int tps = (T + NBLK * 4 - 1) / (NBLK * 4);
-    tps = (tps + 3) & ~3;
+    tps = (tps + 7) & ~7;
     const int t_begin = (blk * 4 + wave) * tps;
     const int t_end = min(T, t_begin + tps);
     const int c0 = chunk * CW;
@@ -52,35 +67,69 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradLaunch L) {   // 3 b
         for (int v = 0; v < 4; ++v) acc[rt][v] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     float ssum[NRT] = {0.f, 0.f, 0.f};
-    // U groups of 4 tokens per round, all loads of a round issued before its MFMAs: 8 x (16 + 3 x 4) bytes per lane in
-    // flight (with one group per iteration the loop ran at HBM latency, 1.5 TB/s)
-    constexpr int U = 4;
-    for (int t0 = t_begin; t0 < t_end; t0 += 4 * U) {
-        f32x4 b4[U];
-        float s[U][NRT];
+    // 32 tokens per round.  Lane (i16, g) holds tokens t0 + 8 g .. + 7 of its 4 columns (one float4 per token) and of
+    // its bottleneck unit per r-tile: exactly the K = 32 operand layout of the bf16 MFMA, no transposes.  Every fp32
+    // value is split into its bf16 rounding and the bf16-rounded remainder (x = h + l to 2^-17 relative) and the
+    // product is h h' + h l' + l h' on the bf16 pipe: 9 bf16 MFMAs (16 clk each) replace 24 fp32 MFMAs (32 clk each)
+    // per (r-tile, column tile, 32 tokens); the fp32 form made this kernel MFMA-bound at 1/16 of the bf16 rate.
+    // Accumulation stays fp32; the bias gradients (column sums) are exact fp32 adds.
+    // the loads of round j + 1 are issued before the products of round j (addresses clamped into the wave's range, values
+    // masked: the loop stays branch-free and the compiler's vmcnt counts exact)
+    f32x4 braw[8];
+    float sraw[8][NRT];
+    auto load_round = [&](int t0, f32x4 (&bq)[8], float (&sq)[8][NRT]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = t0 + 4 * u + g;
+        for (int e = 0; e < 8; ++e) {
+            const int t = t0 + 8 * g + e;
             const int tc = t < t_end ? t : t_begin;
-            b4[u] = *reinterpret_cast<const f32x4*>(big + (size_t)tc * H + c0 + 4 * i16);
+            bq[e] = *reinterpret_cast<const f32x4*>(big + (size_t)tc * H + c0 + 4 * i16);
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) s[u][rt] = sm[(size_t)tc * R + rt * 16 + i16];
+            for (int rt = 0; rt < NRT; ++rt) sq[e][rt] = sm[(size_t)tc * R + rt * 16 + i16];
+        }
+    };
+    load_round(t_begin, braw, sraw);
+    for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+        f32x4 bnext[8];
+        float snext[8][NRT];
+        load_round(t0 + 32, bnext, snext);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (t0 + 8 * g + e >= t_end) {
+                braw[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) sraw[e][rt] = 0.f;
+            }
+            bsum = bsum + braw[e];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) ssum[rt] += sraw[e][rt];
+        }
+        bf16x8 sh[NRT], sl[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = sraw[e][rt];
+            split_bf16x2(x, sh[rt], sl[rt]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = t0 + 4 * u + g < t_end;
-            if (!ok) {
-                b4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < 4; ++v) {
+            float x[8];
 #pragma unroll
-                for (int rt = 0; rt < NRT; ++rt) s[u][rt] = 0.f;
-            }
-            bsum = bsum + b4[u];
+            for (int e = 0; e < 8; ++e) x[e] = braw[e][v];
+            bf16x8 bh, bl;
+            split_bf16x2(x, bh, bl);
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                ssum[rt] += s[u][rt];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[rt][v] = mfma16x4_f32(s[u][rt], b4[u][v], acc[rt][v]);
+                acc[rt][v] = mfma16x32(sl[rt], bh, acc[rt][v]);
+                acc[rt][v] = mfma16x32(sh[rt], bl, acc[rt][v]);
+                acc[rt][v] = mfma16x32(sh[rt], bh, acc[rt][v]);
             }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            braw[e] = bnext[e];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) sraw[e][rt] = snext[e][rt];
         }
     }
     // column sums: reduce over the 4 token slots (g) of the wave

@@ -548,11 +548,12 @@ def test_adapter_fwd_with_fused_layernorm(L, golden_dir):
     """feddat_adapter_fwd_ln = feddat_adapter_fwd followed by feddat_layernorm_fwd on its output (incl. a ragged tail)."""
     g, par = _golden_adapter(L, golden_dir)
     T = 1000 + 7
-    x = torch.randn(T, 768, device=DEV)
+    x = torch.randn(T, 768, generator=torch.Generator().manual_seed(11)).to(DEV)
     h = 16 * 31 + 5
     segs = L.make_segs([dict(row_begin=0, row_end=h, adapters=[dict(par[0], scale=0.5), dict(par[2], scale=0.5)]),
                         dict(row_begin=h, row_end=T, adapters=[dict(par[1], scale=1.0)])])
-    gamma, beta = torch.randn(768, device=DEV), torch.randn(768, device=DEV)
+    gg = torch.Generator().manual_seed(12)
+    gamma, beta = torch.randn(768, generator=gg).to(DEV), torch.randn(768, generator=gg).to(DEV)
     out_a, out_b = torch.zeros_like(x), torch.zeros_like(x)
     y_a = torch.zeros(T, 768, dtype=torch.bfloat16, device=DEV)
     y_b = torch.zeros_like(y_a)
@@ -562,7 +563,8 @@ def test_adapter_fwd_with_fused_layernorm(L, golden_dir):
     L.adapter_fwd_ln(x, out_b, segs, T, gamma, beta, 1e-12, y_b, st_b)
     assert torch.equal(out_a, out_b)
     assert (st_a - st_b).abs().max() < 1e-4 * st_a.abs().max()
-    assert (y_a.float() - y_b.float()).abs().max() <= 2 ** -6          # one bf16 ulp at |y| < 4 from summation order
+    dy_ = (y_a.float() - y_b.float()).abs()                              # at most one bf16 ulp (summation order of the stats)
+    assert bool((dy_ <= torch.maximum(y_a.float().abs(), y_b.float().abs()) * 2 ** -7 + 1e-30).all())
     assert ((y_a.float() - y_b.float()).abs() > 0).float().mean() < 0.02
 
 
