@@ -131,7 +131,8 @@ class AlbefDatEngine:
         self.opt_adapters = (0, 1)
         self.graph = None
         self._segs_cache: Dict = {}
-        self.wpart = torch.empty(L.adapter_wgrad_workspace_elems(1), device=dev)
+        self.wpart = {m: torch.empty(L.adapter_wgrad_workspace_elems(1), device=dev) for m in ("gating", "adapter_1")}
+        self.side = None           # second stream of train_step (created lazily on the engine's device)
         self._alloc()
 
     # ------------------------------------------------------------------------------------------ buffers
@@ -159,12 +160,11 @@ class AlbefDatEngine:
         self.unsel_idx = torch.full((self.Ma,), -1, dtype=torch.int32, device=dev)
         self.labels = torch.zeros(self.R, dtype=torch.int64, device=dev)
         self.row_w = f32(self.R)
-        self.patches = b16(B * (self.Ni - 1), 3 * self.P * self.P)
-        self.proj = f32(B * (self.Ni - 1), H)
 
         def vit_set():
             Mi = self.Mi
-            return dict(h0=f32(Mi, H), st0=f32(Mi, 2), x16=b16(Mi, H), f16=b16(Mi, I),
+            return dict(patches=b16(B * (self.Ni - 1), 3 * self.P * self.P), proj=f32(B * (self.Ni - 1), H),
+                        h0=f32(Mi, H), st0=f32(Mi, 2), x16=b16(Mi, H), f16=b16(Mi, I),
                         blocks=[dict(h_in=f32(Mi, H) if i else None, st1=f32(Mi, 2), qkv=b16(Mi, 3 * H), ctx=b16(Mi, H),
                                      lse=f32(self.B, self.heads, self.Ni), h2=f32(Mi, H), st2=f32(Mi, 2), u=b16(Mi, I),
                                      h3=f32(Mi, H), zs=f32(Mi, 2, self.r)) for i in range(self.vd)],
@@ -187,12 +187,15 @@ class AlbefDatEngine:
                         hsel=f32(self.R, H), hsel16=b16(self.R, H), tu=f32(self.R, H), tg=f32(self.R, H), tst=f32(self.R, 2),
                         ty16=b16(self.R, H), logits=f32(self.R, self.Vp), loss=f32(4 + 2 * self.R))
         self.acts = {"gating": act_set(), "adapter_1": act_set()}
-        # backward scratch (one set, reused by both passes)
+        # backward scratch: one set per pass (their text-side backward passes run on two streams)
         Mmax = max(self.Mi, self.Mq, self.Ma, N * Lq, self.R)
-        self.g = dict(dlogits=b16(self.R, self.Vp), d1=f32(Mmax, H), d2=f32(Mmax, H), d3=f32(Mmax, H), d4=f32(Mmax, H),
+
+        def scratch():
+            return dict(dlogits=b16(self.R, self.Vp), d1=f32(Mmax, H), d2=f32(Mmax, H), d3=f32(Mmax, H), d4=f32(Mmax, H),
                       b1=b16(Mmax, H), b2=b16(Mmax, H), bI=b16(Mmax, I), b3=b16(Mmax, 3 * H), bkv=b16(Mmax, 2 * H),
                       z=f32(Mmax, self.r), dz=f32(Mmax, self.r), dsum=f32(max(B, N), self.heads, max(self.Ni, Lq, La)),
                       d_img=f32(self.Mi, H), d_qs=f32(self.Mq, H), d_rep=f32(N * Lq, H), d_dec=f32(self.Ma, H))
+        self.gs = {"gating": scratch(), "adapter_1": scratch()}
 
     # ------------------------------------------------------------------------------------------ adapters
     def _pack(self, a: int, m: int):
@@ -225,10 +228,10 @@ class AlbefDatEngine:
         key = ("wg", m, a, x.data_ptr(), dy.data_ptr(), rows)
         if key not in self._segs_cache:
             n = self.ad_numel
-            self._segs_cache[key] = L.make_wgrad_segs([dict(x=x, dy=dy, z=self.g["z"], dz=self.g["dz"],
+            self._segs_cache[key] = L.make_wgrad_segs([dict(x=x, dy=dy, z=self.gs[mode]["z"], dz=self.gs[mode]["dz"],
                                                             grad=self.ad[a].g[m * n:(m + 1) * n], rows=rows,
                                                             scale=0.5 if mode == "gating" else 1.0)])
-        L.adapter_wgrad(self._segs_cache[key], self.wpart)
+        L.adapter_wgrad(self._segs_cache[key], self.wpart[mode])
 
     def copy_global_to_teacher(self):
         self.ad[2].p.copy_(self.ad[1].p)
@@ -274,10 +277,10 @@ class AlbefDatEngine:
     def _vit_fwd(self, S, mode: str):
         B, H, Ni, vt = self.B, self.H, self.Ni, self.vit
         V = S["vit"]
-        L.im2col_patches(self.inp["image"], self.patches, B, 3, self.img, self.img, self.P)
-        L.gemm_bf16_nt(self.patches, vt["wp"], L.EPI_F32, bias=vt["bp"], out_f32=self.proj)
+        L.im2col_patches(self.inp["image"], V["patches"], B, 3, self.img, self.img, self.P)
+        L.gemm_bf16_nt(V["patches"], vt["wp"], L.EPI_F32, bias=vt["bp"], out_f32=V["proj"])
         # x = cat(cls, patches) + pos_embed  (vit.py:179-184): row 0 = cls + pos[0], rows 1.. = proj + pos[1..]
-        L.image_embed_assemble(self.proj, vt["cls"], vt["pos"][0], vt["pos"][1:], self.zero_h, V["h0"], B, 0, Ni - 1, Ni, H)
+        L.image_embed_assemble(V["proj"], vt["cls"], vt["pos"][0], vt["pos"][1:], self.zero_h, V["h0"], B, 0, Ni - 1, Ni, H)
         h = V["h0"]
         b0 = vt["blocks"][0]
         L.layernorm_fwd(h, b0["n1g"], b0["n1b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=V["blocks"][0]["st1"])
@@ -341,9 +344,13 @@ class AlbefDatEngine:
 
     def _forward(self, mode: str):
         """ALBEF.forward(train=True) up to logits[:, :-1] (albef_model.py:69-145), activations kept in self.acts[mode]."""
+        self._vit_fwd(self.acts[mode], mode)
+        return self._forward_text(mode)
+
+    def _forward_text(self, mode: str):
+        """Everything behind the image encoder: text encoder with cross-attention, answer decoder, LM head."""
         S = self.acts[mode]
         B, N, Lq, La, H = self.B, self.N, self.Lq, self.La, self.H
-        self._vit_fwd(S, mode)
         E, D = S["enc"], S["dec"]
         self._embed(self.enc, self.inp["question_ids"], self.zero_tt_q, B, Lq, E["h"], E["h16"])
         qs, _ = self._bert_fwd(self.enc, E, self.vd, mode, self.Mq, B, Lq, self.qmask8, False, S["vit"]["emb16"], self.Ni,
@@ -367,7 +374,7 @@ class AlbefDatEngine:
                   d_enc):
         """d_out: fp32 [M,768] gradient of the tower's output (consumed); d_enc: fp32 accumulator for the encoder-side
         states (zeroed by the caller); returns the gradient wrt the tower's embedding output (unused: embeddings frozen)."""
-        H, g = self.H, self.g
+        H, g = self.H, self.gs[mode]
         for i in range(len(T["layers"]) - 1, -1, -1):
             W, A = T["layers"][i], S["layers"][i]
             ds2, dxf, dx, ds1 = g["d1"][:M], g["d2"][:M], g["d3"][:M], g["d4"][:M]
@@ -406,7 +413,7 @@ class AlbefDatEngine:
 
     def _vit_bwd(self, S, mode: str, d_img):
         """d_img: fp32 [Mi,768] gradient wrt image_embeds (the final norm's output)."""
-        H, g, vt, Mi = self.H, self.g, self.vit, self.Mi
+        H, g, vt, Mi = self.H, self.gs[mode], self.vit, self.Mi
         V = S["vit"]
         cur, oth = g["d1"][:Mi], g["d2"][:Mi]
         L.layernorm_bwd_dx(V["out"], V["stf"], vt["ng"], Mi, H, dy_f32=d_img, out_f32=cur)
@@ -434,7 +441,12 @@ class AlbefDatEngine:
 
     def _backward(self, mode: str, teacher_logits):
         """L = (loss + kl) / 2 of the pass `mode` (task_trainer.py:300-302 / 320-323) -> gradients of its trainable adapter."""
-        S, g, hd, H = self.acts[mode], self.g, self.head, self.H
+        self._backward_text(mode, teacher_logits)
+        self._vit_bwd(self.acts[mode], mode, self.gs[mode]["d_img"])
+
+    def _backward_text(self, mode: str, teacher_logits):
+        """Loss, LM head, decoder and text encoder backward of the pass `mode`; leaves d(image_embeds) in its scratch set."""
+        S, g, hd, H = self.acts[mode], self.gs[mode], self.head, self.H
         L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
                           S["loss"])
         R = self.R
@@ -453,7 +465,6 @@ class AlbefDatEngine:
         g["d_img"].zero_()
         self._bert_bwd(self.enc, S["enc"], self.vd, mode, self.Mq, self.B, self.Lq, self.qmask8, False, S["vit"]["emb16"],
                        self.Ni, self.Ni, None, g["d_qs"], g["d_img"])
-        self._vit_bwd(S, mode, g["d_img"])
 
     # ------------------------------------------------------------------------------------------ train step
     def begin_local_update(self, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,
@@ -478,10 +489,25 @@ class AlbefDatEngine:
                      self.sched["total"], 0.9, 0.98, self.eps)
 
     def _step_kernels(self):
-        logits_g = self._forward("gating")                   # P0 == P2 forward (task_trainer.py:283-287,311-315)
+        # The two passes are independent up to the loss and from the loss down to their adapters, so they run side by
+        # side on two streams (separate activation, scratch and weight-gradient workspaces per pass; inside a captured
+        # step the fork / join become graph edges): the text towers' launches are small (25-token questions, 4-token
+        # answers: 24-156 workgroups) and overlap each other, and the other pass's kernels fill the CUs that the last,
+        # partial round of an image-encoder GEMM leaves idle (388 tiles on 256 CUs at N = 768).
+        cur = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.dev)
+        side = self.side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            logits_g = self._forward("gating")               # P0 == P2 forward (task_trainer.py:283-287,311-315)
         logits_1 = self._forward("adapter_1")                # P1 (task_trainer.py:290-295)
+        cur.wait_stream(side)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._backward("gating", logits_1)               # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
         self._backward("adapter_1", logits_g)                # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
-        self._backward("gating", logits_1)                   # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
+        cur.wait_stream(side)
         if 1 in self.opt_adapters:
             self._adamw(self.ad[1])
             self.repack_adapter(1)
