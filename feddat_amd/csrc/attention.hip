@@ -409,7 +409,9 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
                         ds[t][e] = pe * (dp[e] - d4[e]);          // the 1/8 of dS is applied to dK / dQ at the end
                     }
                     // dS^T panel of query tile 2 qs + t: row = key, 4 consecutive queries 4g .. 4g+3 (8 bytes)
-                    *reinterpret_cast<bf16x4*>(Pn + ((2 * qs + t) * S_pad + key) * 32 + g * 8) = cvt4(ds[t]);
+                    // (the 8-byte block index is XOR-ed with bits 2-3 of the key: the 16 lanes of a store then cover all 32
+                    // banks instead of 8 -- the plain layout was a 4-way conflict on every panel store)
+                    *reinterpret_cast<bf16x4*>(Pn + ((2 * qs + t) * S_pad + key) * 32 + ((g ^ ((key >> 2) & 3)) << 3)) = cvt4(ds[t]);
                 }
                 const bf16x8 pb = cvt8(p[0], p[1]);
                 const bf16x8 dsb = cvt8(ds[0], ds[1]);
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
             // transposed read of the 4 x 16 blocks of the panel (32-byte rows, 16 queries wide)
             const int i = lane & 15;
             auto tr = [&](int r0) {
-                const char* pp = panel + (r0 + (i >> 2)) * 32 + ((i & 3) << 3);
+                const int r = r0 + (i >> 2);
+                const char* pp = panel + r * 32 + (((i & 3) ^ ((r >> 2) & 3)) << 3);
                 return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pp);
             };
             const bf16x4 a4 = tr(ks * 32 + 4 * g), b4 = tr(ks * 32 + 16 + 4 * g);
