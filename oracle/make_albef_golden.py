@@ -292,9 +292,37 @@ def golden_full(out):
     print("G10 full losses", rec["losses"])
 
 
+def golden_round(out, steps=40):
+    """G11: a local round at realistic length on the reference -- `steps` train_steps of the small configuration (every
+    code path: ragged questions / answers, k = [2, 1, 3], weights != 1), one epoch, schedule past its warm-up.  Losses and,
+    per adapter_0 / adapter_1 tensor, norm / mean / max / 512 samples of the update."""
+    d = small_dims()
+    model = build_reference_model(d)
+    for n, p in model.named_parameters():
+        if "adapter" in n:
+            p.requires_grad = True
+    batches = [A.synthetic_batch(3, d, 700 + s, q_len=12, a_len=5, k=[2, 1, 3], ragged=True) for s in range(steps)]
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rec = {"losses": np.array(ref_local_update(model, batches, lr=1e-4, num_epochs=1), np.float32),
+           "steps": np.array(steps, np.int64)}
+    for k, v in model.state_dict().items():
+        if "adapter_0" in k or "adapter_1" in k:
+            dw = (v.detach() - init[k]).flatten()
+            idx = torch.linspace(0, dw.numel() - 1, min(512, dw.numel())).long()
+            rec["dnorm::" + k], rec["dmean::" + k] = np_(dw.norm()), np_(dw.abs().mean())
+            rec["dmax::" + k], rec["dsamp::" + k] = np_(dw.abs().max()), np_(dw[idx])
+    np.savez_compressed(os.path.join(out, "g11_albef_round40.npz"), **rec)
+    print("G11 losses first/last", rec["losses"][:3], rec["losses"][-3:],
+          "mean |dW|", float(np.mean([rec[k] for k in rec if k.startswith("dmean::")])))
+
+
 if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden")
     torch.manual_seed(0)
+    if "--only-g11" in sys.argv:
+        golden_round(out)
+        sys.exit(0)
     golden_small(out)
+    golden_round(out)
     if "--small-only" not in sys.argv:
         golden_full(out)

@@ -89,6 +89,43 @@ def test_small_train_steps_vs_reference_and_oracle(eng_mod, golden_dir):
     print(f"ALBEF small, 4 steps: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f}")
 
 
+def test_round_of_40_steps_vs_reference_golden(eng_mod, golden_dir):
+    """north-star at round length for the ALBEF path: 40 train_steps (hipGraph replay; schedule past its warm-up) of the
+    small configuration against the reference's own run (G11): loss trajectory, and per adapter_0 / adapter_1 tensor of the
+    three towers |ddW|.max < 1e-3, |ddW|.mean <= 0.1 |dW_ref|.mean, update norm within 5 %."""
+    g = load(golden_dir, "g11_albef_round40.npz")
+    steps = int(g["steps"])
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    P0 = {k: v.clone() for k, v in P.items()}
+    eng = _small_engine(eng_mod, P, 3, 6, 12, 5)
+    eng.begin_local_update(steps_per_epoch=steps, num_epochs=1)
+    worst_loss = 0.0
+    for s in range(steps):
+        b = A.synthetic_batch(3, d, 700 + s, q_len=12, a_len=5, k=[2, 1, 3], ragged=True)
+        out = eng.train_step(_dev(b), use_graph=True)
+        torch.cuda.synchronize()
+        ref = float(g["losses"][s])
+        worst_loss = max(worst_loss, abs(float(out[0]) - ref) / ref)
+    assert worst_loss < 1e-2, worst_loss
+    sd = eng.state_dict()
+    keys = [k.split("::", 1)[1] for k in g if k.startswith("dsamp::")]
+    worst_max, worst_ratio, worst_norm = 0.0, 0.0, 0.0
+    for k in keys:
+        dw = (sd[k].cpu() - P0[k]).flatten()
+        idx = torch.linspace(0, dw.numel() - 1, min(512, dw.numel())).long()
+        err = (dw[idx] - torch.from_numpy(g["dsamp::" + k])).abs()
+        move = float(g["dmean::" + k])
+        assert float(err.max()) < 1e-3, (k, float(err.max()))
+        assert float(err.mean()) <= 0.1 * move, (k, float(err.mean()), move)
+        nerr = abs(float(dw.norm()) - float(g["dnorm::" + k])) / float(g["dnorm::" + k])
+        assert nerr < 0.05, (k, nerr)
+        worst_max, worst_ratio = max(worst_max, float(err.max())), max(worst_ratio, float(err.mean()) / move)
+        worst_norm = max(worst_norm, nerr)
+    print(f"ALBEF small, {steps} steps vs reference: worst max |ddW| {worst_max:.2e}, mean ratio {worst_ratio:.3f}, "
+          f"norm error {worst_norm:.3f}, loss trajectory within {worst_loss:.2e}")
+
+
 def test_rank_answer_eval_vs_reference_golden(eng_mod, golden_dir):
     """ALBEF.rank_answer (albef_model.py:171-228): shortlist by first-token probability, re-rank by sequence likelihood."""
     g = load(golden_dir, "g10_albef_small.npz")

@@ -52,3 +52,23 @@ def test_g10_small_local_update_vs_reference(golden_dir):
         idx = torch.linspace(0, dw.numel() - 1, min(512, dw.numel())).long()
         err = (dw[idx] - T(g["dsamp::" + k])).abs()
         assert float(err.max()) < 3e-5 and float(err.mean()) <= 0.02 * float(g["dmean::" + k]) + 1e-9, k
+
+
+def test_g11_round_of_40_steps_vs_reference(golden_dir):
+    """A round at realistic length (40 train_steps, schedule past its warm-up) against the reference's own run (G11)."""
+    g = load(golden_dir, "g11_albef_round40.npz")
+    steps = int(g["steps"])
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    init = {k: v.clone() for k, v in P.items()}
+    c = A.AlbefDatClient(P, d, lr=1e-4, steps_per_epoch=steps, num_epochs=1)
+    losses = [float(c.train_step(A.synthetic_batch(3, d, 700 + s, q_len=12, a_len=5, k=[2, 1, 3], ragged=True)))
+              for s in range(steps)]
+    assert np.abs(np.array(losses) - g["losses"]).max() < 5e-4 * np.abs(g["losses"]).max()
+    keys = [k.split("::", 1)[1] for k in g if k.startswith("dsamp::")]
+    for k in keys:
+        dw = (P[k] - init[k]).flatten()
+        idx = torch.linspace(0, dw.numel() - 1, min(512, dw.numel())).long()
+        err = (dw[idx] - T(g["dsamp::" + k])).abs()
+        assert float(err.max()) < 1e-4 and float(err.mean()) <= 0.02 * float(g["dmean::" + k]) + 1e-9, (k, float(err.max()))
+        assert abs(float(dw.norm()) - float(g["dnorm::" + k])) <= 0.02 * float(g["dnorm::" + k]), k
