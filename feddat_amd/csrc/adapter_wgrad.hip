@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
     // product is h h' + h l' + l h' on the bf16 pipe: 9 bf16 MFMAs (16 clk each) replace 24 fp32 MFMAs (32 clk each)
     // per (r-tile, column tile, 32 tokens); the fp32 form made this kernel MFMA-bound at 1/16 of the bf16 rate.
     // Accumulation stays fp32; the bias gradients (column sums) are exact fp32 adds.
-    // the loads of round j + 1 are issued before the products of round j (addresses clamped into the wave's range, values
+    // the loads of round j + 1 are issued before the products of round j (addresses of masked tokens fall back to row 0, values
     // masked: the loop stays branch-free and the compiler's vmcnt counts exact)
     f32x4 braw[8];
     float sraw[8][NRT];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int t = t0 + 8 * g + e;
-            const int tc = t < t_end ? t : t_begin;
+            const int tc = t < t_end ? t : 0;          // masked tokens re-read row 0 (always inside the segment)
             bq[e] = *reinterpret_cast<const f32x4*>(big + (size_t)tc * H + c0 + 4 * i16);
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) sq[e][rt] = sm[(size_t)tc * R + rt * 16 + i16];
