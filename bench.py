@@ -231,6 +231,25 @@ def bench_albef(args, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
+def roofline_block(L, eng, batches, gemms):
+    """achieved = FLOPs of all K1 launches of a step / their summed in-step durations (HIP events around the engine's own
+    launches); the isolated figure (10 back-to-back launches per shape, operands MALL/L2-warm) is reported beside it and is
+    NOT what `frac` is."""
+    ach, tsum, rows, alg_bytes, launches, in_step_info = measure_gemms_in_step(L, eng, batches)
+    ach_iso, tsum_iso, rows_iso = measure_gemms(L, gemms)
+    tr = profiled_traffic()
+    return {"kernel": "gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one train_step, FLOP-weighted, "
+                      "durations measured in-step)",
+            "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16, 4), "frac_in_step": round(ach / PEAK_BF16, 4),
+            "frac_isolated": round(ach_iso / PEAK_BF16, 4),
+            "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": round(alg_bytes),
+            "traffic_ratio": round(tr["bytes_per_launch"] / alg_bytes, 3) if tr else None,
+            "traffic_source": (tr["source"] + ": " + tr["note"]) if tr else None, "launches_per_step": launches,
+            "gemm_ms_per_step": round(tsum * 1e3, 3), "gemm_ms_per_step_isolated": round(tsum_iso * 1e3, 3),
+            "shapes": rows, "shapes_isolated": rows_iso, "in_step": in_step_info}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,27 +389,16 @@ def main():
         }
         out.update(extra_host)
         if not args.no_roofline:
-            # achieved = FLOPs of all K1 launches of a step / their summed in-step durations (HIP events around the
-            # engine's own launches); the isolated figure (10 back-to-back launches per shape, operands MALL/L2-warm) is
-            # reported beside it and is NOT what `frac` is.
-            ach, tsum, rows, alg_bytes, launches, in_step_info = measure_gemms_in_step(L, eng, batches)
-            ach_iso, tsum_iso, rows_iso = measure_gemms(L, gemms)
-            tr = profiled_traffic()
-            out["roofline"] = {"kernel": "gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one "
-                                         "train_step, FLOP-weighted, durations measured in-step)",
-                               "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16, 4),
-                               "frac_in_step": round(ach / PEAK_BF16, 4), "frac_isolated": round(ach_iso / PEAK_BF16, 4),
-                               "traffic": tr["bytes_per_launch"] if tr else None,
-                               "algorithmic_bytes_per_launch": round(alg_bytes),
-                               "traffic_ratio": round(tr["bytes_per_launch"] / alg_bytes, 3) if tr else None,
-                               "traffic_source": (tr["source"] + ": " + tr["note"]) if tr else None,
-                               "launches_per_step": launches,
-                               "gemm_ms_per_step": round(tsum * 1e3, 3), "gemm_ms_per_step_isolated": round(tsum_iso * 1e3, 3),
-                               "shapes": rows, "shapes_isolated": rows_iso, "in_step": in_step_info}
+            try:
+                out["roofline"] = roofline_block(L, eng, batches, gemms)
+            except Exception as e:      # the throughput line must survive a failure of the auxiliary measurement
+                out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline({k: v.float().cpu() for k, v in params.items()},
-                                               [{k: v.cpu() for k, v in b.items()} for b in batches], B, res, task)
+            try:
+                out["cpu_baseline"] = cpu_baseline({k: v.float().cpu() for k, v in params.items()},
+                                                   [{k: v.cpu() for k, v in b.items()} for b in batches], B, res, task)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
