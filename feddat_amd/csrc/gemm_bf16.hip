@@ -748,6 +748,176 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// v3 (experimental, debug flag 1): ONE wave per SIMD.  192 x 192 x 64 tile, 4 waves (2 x 2, 96 x 96 per wave = 6 x 6
+// MFMA tiles: 72 MFMAs per 24 fragment reads), persistent blocks and the continuous k-tile stream of v2.  The
+// accumulators are pinned to AGPRs by issuing the MFMA as inline asm ("+a"): with the builtin hipcc parked part of the
+// 144 accumulator registers in other registers and moved them around every MFMA.  Every MFMA is followed by exactly one
+// other instruction (fragment read of the next k-half, staging write, staging load), which issues while the MFMA runs.
+//   half 0 of k-tile j (stage s):  MFMA(j, 0) | read frags(j, 1) from s | ds_write k-tile j+1 -> s^1 | global loads of j+2
+//   lgkmcnt(0), barrier
+//   half 1:                        MFMA(j, 1) | read frags(j+1, 0) from s^1
+constexpr int V3_STAGE = 2 * V2_TILE_B;       // A 192 x 128 B + B 192 x 128 B
+constexpr int V3_LDS = 2 * V3_STAGE;
+
+__device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// first product of a tile: C = 0 as an inline constant, the accumulator needs no zeroing
+__device__ __forceinline__ void mfma_agpr_first(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+
+// (A variant that DEFERRED a tile's epilogue into the next tile's k-loop was built on this kernel -- accumulators copied
+// aside at the boundary, one twelfth of the stores per k-tile between the MFMAs -- and was bit-exact, but slower: on this ISA
+// loads and stores share vmcnt and complete out of order with respect to each other, so with one store in flight every
+// wait for a staging load becomes vmcnt(0).  The epilogue therefore stays at the tile boundary, as in v2.)
+constexpr int V3_EPI_OFF = V3_LDS;                  // per-wave epilogue staging behind the two stages
+constexpr int V3_LDS_TOTAL = V3_LDS + 4 * V2_EPI_WAVE;
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmArgs& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int total = a.tiles_m * (g.N / V2_BN);
+    const int grid = gridDim.x, bid = blockIdx.x;
+    const int my_tiles = (total - bid + grid - 1) / grid;
+    const int nk = g.K / BK;
+    const int total_it = my_tiles * nk;
+
+    f32x4 acc[6][6];
+    int m0, n0, m_last;
+    v2_tile_coords(a, bid, total, m0, n0, m_last);
+    unsigned pp[12];                     // byte offsets of this lane's staging pieces from A / B (operands < 4 GiB: checked)
+    auto piece_ptrs = [&](int tm0, int tml, int tn0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int r = (wave * 6 + i) * 8 + (lane >> 3);
+            pp[i] = ((unsigned)min(tm0 + r, tml) * (unsigned)g.lda + (lane & 7) * 8) * 2u;
+            pp[6 + i] = ((unsigned)min(tn0 + r, g.N - 1) * (unsigned)g.ldb + (lane & 7) * 8) * 2u;
+        }
+    };
+    piece_ptrs(m0, m_last, n0);
+    int l_tile = 0, l_kt = 0, issued = 0;
+    const int lds_lane = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 3)) & 7) << 4);
+    u32x4 rs[12];
+    auto gload_piece = [&](int p) {
+        const char* base = reinterpret_cast<const char*>(p < 6 ? g.A : g.B);
+        rs[p] = *reinterpret_cast<const u32x4*>(base + (pp[p] + (unsigned)(l_kt * BK * 2)));
+    };
+    auto stream_advance = [&]() {
+        if (issued + 1 < total_it) {
+            if (++l_kt == nk) {
+                l_kt = 0;
+                ++l_tile;
+                int lm0, ln0, lml;
+                v2_tile_coords(a, bid + l_tile * grid, total, lm0, ln0, lml);
+                piece_ptrs(lm0, lml, ln0);
+            }
+        }
+        ++issued;
+    };
+    auto lwrite_piece = [&](int p, int stage) {
+        char* sb = smem + stage * V3_STAGE + lds_lane + (p < 6 ? (wave * 6 + p) * 1024 : V2_TILE_B + (wave * 6 + p - 6) * 1024);
+        *reinterpret_cast<u32x4*>(sb) = rs[p];
+    };
+
+    const int frow = lane & 15, fg = lane >> 4;
+    const int frag_off[2] = {frow * 128 + (((0 + fg) ^ (frow & 7)) << 4), frow * 128 + (((4 + fg) ^ (frow & 7)) << 4)};
+    bf16x8 fa[2][6], fb[2][6];
+    auto read_a = [&](int stage, int ks, int i) {
+        fa[ks][i] = *reinterpret_cast<const bf16x8*>(smem + stage * V3_STAGE + frag_off[ks] + (wm * 96 + i * 16) * 128);
+    };
+    auto read_b = [&](int stage, int ks, int j) {
+        fb[ks][j] = *reinterpret_cast<const bf16x8*>(smem + stage * V3_STAGE + V2_TILE_B + frag_off[ks] + (wn * 96 + j * 16) * 128);
+    };
+
+#pragma unroll
+    for (int p = 0; p < 12; ++p) gload_piece(p);
+    stream_advance();
+#pragma unroll
+    for (int p = 0; p < 12; ++p) lwrite_piece(p, 0);
+#pragma unroll
+    for (int p = 0; p < 12; ++p) gload_piece(p);
+    stream_advance();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        read_b(0, 0, i);
+        read_a(0, 0, i);
+    }
+
+    // one k-tile; FIRST: the tile's first k-tile, whose half 0 starts the accumulators from the constant 0
+    auto k_tile = [&](auto first_tag, const int st) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // ---- half 0: MFMA (i, j) then filler #(6 i + j): 12 fragment reads, 12 staging writes, 12 staging loads
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (FIRST) mfma_agpr_first(acc[i][j], fb[0][j], fa[0][i]);
+                else mfma_agpr(acc[i][j], fb[0][j], fa[0][i]);
+                const int f = 6 * i + j;
+                __builtin_amdgcn_sched_barrier(0);
+                if (f < 12) {                              // fragments of k-half 1
+                    if (f < 6) read_b(st, 1, f);
+                    else read_a(st, 1, f - 6);
+                } else {                                   // k-tile j+1 -> the other stage, piece by piece, each register
+                    const int q = f - 12;                  // refilled with k-tile j+2 right behind its write (12 writes in a
+                    if ((q & 1) == 0) lwrite_piece(q >> 1, st ^ 1);   // row, then the loads, with the barrier pulled forward
+                    else gload_piece(q >> 1);              // to slot 29: 10 % slower -- the four waves' writes collide)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        stream_advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- half 1: the fragments of the next k-tile's half 0 behind the first two MFMA rows
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                mfma_agpr(acc[i][j], fb[1][j], fa[1][i]);
+                const int f = 6 * i + j;
+                __builtin_amdgcn_sched_barrier(0);
+                if (f >= 12 && f < 24) {
+                    const int q = f - 12;
+                    if (q < 6) read_b(st ^ 1, 0, q);
+                    else read_a(st ^ 1, 0, q - 6);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    char* stg = smem + V3_EPI_OFF + wave * V2_EPI_WAVE;
+    int it = 0;
+    for (int tile = 0; tile < my_tiles; ++tile) {
+        k_tile(std::true_type{}, it & 1);
+        ++it;
+        for (int kt = 1; kt < nk; ++kt, ++it) k_tile(std::false_type{}, it & 1);
+        // The compiler cannot see that the asm blocks are MFMAs: it would read their results right behind them.  The wait
+        // states are attached to the accumulators themselves (in / out operands), row by row.
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            asm volatile("s_nop 15\n\ts_nop 15"
+                         : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
+        if (!(a.dbg & 8)) {
+            const int mb = m0 + wm * 96, nb = n0 + wn * 96, me = m_last + 1;
+            if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU)
+                v2_epilogue_bf16<EPI, 6>(g, acc, stg, mb, nb, me, lane);
+            else
+                v2_epilogue<EPI, 6>(g, acc, stg, mb, nb, me, lane);
+        }
+        if (tile + 1 < my_tiles) v2_tile_coords(a, bid + (tile + 1) * grid, total, m0, n0, m_last);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Skinny GEMM (M <= 64): the top ViLT layer runs everything behind its attention on the 2B token-0 rows only
 // (engine._top_layer_fwd / _bwd).  With so few rows the product is a stream over the weight matrix, so it is split over
 // (N / 64) x ksplit blocks -- enough blocks to pull B through every CU -- into fp32 partials [ksplit][M][N]; a second
@@ -892,7 +1062,16 @@ static const V2Kernel (*v2_kernel_table())[5] {
     return kernels;
 }
 
+static const V2Kernel* v3_kernel_table() {
+    static const V2Kernel kernels[5] = {gemm_nt_v3_kernel<FEDDAT_EPI_BF16>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32>,
+                                        gemm_nt_v3_kernel<FEDDAT_EPI_GELU>, gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU>,
+                                        gemm_nt_v3_kernel<FEDDAT_EPI_F32>};
+    return kernels;
+}
+
 int fd_prepare_gemm_kernels() {
+    for (int e = 0; e < 5; ++e)
+        if (fd_set_max_lds((const void*)v3_kernel_table()[e], V3_LDS_TOTAL) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     for (int w = 0; w < 2; ++w)
         for (int e = 0; e < 5; ++e)
             if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
@@ -1014,6 +1193,20 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         if (dbg & 32) wm4 = false;
         if (dbg & 64) wm4 = true;
         a2 = wm4 ? a4 : a3;
+        // v3 (one wave per SIMD) has the faster k-loop (1.09-1.23 PF/s against 0.96-1.15) but only four waves to run an
+        // epilogue: it takes every launch except the two heavy epilogues (GELU with two outputs, . gelu'(aux) with its cold
+        // aux operand: in the step 89.8 us on v3 against 82.0) and the smallest plain product (measured per shape in the
+        // step, tools/step_breakdown.py --detail); debug flag 1 keeps everything on v2, flag 2 forces v3
+        const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU &&
+                             !(epi == FEDDAT_EPI_BF16 && K <= 768 && N <= 768);
+        if (((dbg & 2) || v3_pick) && !(dbg & 1)) {
+            const V2Kernel k3 = v3_kernel_table()[epi];
+            a2 = a3;
+            if (fd_set_max_lds((const void*)k3, V3_LDS_TOTAL) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+            const int total3 = a2.tiles_m * (N / V2_BN);
+            hipLaunchKernelGGL(k3, dim3(total3 < n_cu ? total3 : n_cu), dim3(256), V3_LDS_TOTAL, stream, a2);
+            FD_LAUNCH_RET();
+        }
         const V2Kernel kern = v2_kernel_table()[wm4 ? 1 : 0][epi];
         const int lds_bytes = wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS;
         if (fd_set_max_lds((const void*)kern, lds_bytes) != FEDDAT_OK) return FEDDAT_ELAUNCH;

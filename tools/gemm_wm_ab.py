@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 from feddat_amd import lib as L
 dev = "cuda:0"
 M = 11840
-for (N, K, epi) in [(3072, 768, 3), (3072, 768, 2), (3072, 768, 0), (2304, 768, 0), (768, 3072, 1), (768, 768, 1)]:
+for (N, K, epi) in [(3072, 768, 3), (3072, 768, 2), (3072, 768, 0), (2304, 768, 0), (768, 3072, 1), (768, 768, 1), (768, 3072, 0), (768, 2304, 0), (768, 768, 0)]:
     A = torch.randn(M, K, device=dev).bfloat16(); B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     o = torch.empty(M, N, dtype=torch.bfloat16, device=dev); o2 = torch.empty_like(o)
     aux = torch.randn(M, N, device=dev).bfloat16(); resid = torch.randn(M, N, device=dev); o32 = torch.empty(M, N, device=dev)
@@ -14,7 +14,7 @@ for (N, K, epi) in [(3072, 768, 3), (3072, 768, 2), (3072, 768, 0), (2304, 768, 
         elif epi == 2: L.gemm_bf16_nt(A, B, 2, bias=bias, out_bf16=o, out2_bf16=o2)
         elif epi == 3: L.gemm_bf16_nt(A, B, 3, aux=aux, out_bf16=o)
     res = []
-    for flag in (32, 64, 32 | 8):
+    for flag in (32, 64, 32 | 8, 1, 1 | 8):
         L.set_debug_flags(flag)
         call(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -25,4 +25,4 @@ for (N, K, epi) in [(3072, 768, 3), (3072, 768, 2), (3072, 768, 0), (2304, 768, 
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 20 * 1e3)
     L.set_debug_flags(0)
-    print(f"N={N} K={K} epi={epi}: WM3 {res[0]:.1f} us  WM4 {res[1]:.1f} us  | WM3 without epilogue {res[2]:.1f} us ({2*M*N*K/res[2]/1e6:.0f} TF/s)")
+    print(f"N={N} K={K} epi={epi}: WM3 {res[0]:.1f} us  WM4 {res[1]:.1f} us  | WM3 without epilogue {res[2]:.1f} us ({2*M*N*K/res[2]/1e6:.0f} TF/s) | v3 {res[3]:.1f} us, without epilogue {res[4]:.1f} us ({2*M*N*K/res[4]/1e6:.0f} TF/s)")
