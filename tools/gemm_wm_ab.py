@@ -14,7 +14,7 @@ for (N, K, epi) in [(3072, 768, 3), (3072, 768, 2), (3072, 768, 0), (2304, 768, 
         elif epi == 2: L.gemm_bf16_nt(A, B, 2, bias=bias, out_bf16=o, out2_bf16=o2)
         elif epi == 3: L.gemm_bf16_nt(A, B, 3, aux=aux, out_bf16=o)
     res = []
-    for flag in (32, 64, 32 | 8, 1, 1 | 8):
+    for flag in (1 | 32, 1 | 64, 1 | 32 | 8, 2, 2 | 8):      # 1: v2 only, 2: force v3
         L.set_debug_flags(flag)
         call(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
