@@ -378,7 +378,10 @@ __device__ __forceinline__ void v2_piece_ptrs(const GemmArgs& g, int m0, int m_l
 // instead of 6 x dwordx2 (the 8-byte form was store-issue-bound at ~9 B/clk/CU: 9.5 us of every 27 us FFN1 tile).
 // The aux operand of MUL_DGELU takes the opposite way: 16-byte row-contiguous loads -> LDS -> accumulator layout.
 constexpr int V2_EPI_LD16 = 208;              // bytes per staged bf16 row (96 x 2 + 16 pad)
-template <int EPI, int WM>
+// SINK (v3: one wave per SIMD, nothing else to hide a stall): stores of rows outside the tile go to a dummy line
+// instead of being predicated, so the whole epilogue is one basic block the scheduler can interleave.
+__device__ uint4 fd_epi_sink[64];
+template <int EPI, int WM, bool SINK = false>
 __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)[WM][6], char* stg, int mbase, int nbase,
                                                  int m_end, int lane) {
     asm volatile("" : "+v"(lane));
@@ -403,9 +406,10 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
             ux[i][p] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(g.aux) + off);
         }
     };
-    if (EPI == FEDDAT_EPI_MUL_DGELU) {         // the whole wave tile's aux up front: 3 WM loads per lane in flight
+    constexpr int AUX_AHEAD = WM < 4 ? WM : 4; // row groups of aux in flight: 12 loads per lane (all of them for WM <= 4)
+    if (EPI == FEDDAT_EPI_MUL_DGELU) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) aux_load(i);
+        for (int i = 0; i < AUX_AHEAD; ++i) aux_load(i);
     }
     char* wr = stg + frow * V2_EPI_LD16 + fg * 8;          // accumulator-layout position: row frow, cols 16 j + 4 fg
     auto put = [&](bf16* dst, int ld, int i, const f32x4 (&val)[6]) {
@@ -417,7 +421,12 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int m = mbase + i * 16 + srow[p];
-            if (m < m_end && !(g.nostore & 1)) *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
+            if (SINK) {
+                bf16* o = m < m_end ? dst + (size_t)m * ld + nbase + sc8[p] * 8 : reinterpret_cast<bf16*>(fd_epi_sink) + lane * 8;
+                *reinterpret_cast<bf16x8*>(o) = v[p];
+            } else if (m < m_end && !(g.nostore & 1)) {
+                *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
+            }
         }
     };
     f32x4 sw4[6];
@@ -445,6 +454,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
                 if (!(g.nostore & 2)) val[j] = val[j] * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
                 else val[j] = val[j] * f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
             }
+            if (i + AUX_AHEAD < WM) aux_load(i + AUX_AHEAD);
         }
         if (EPI == FEDDAT_EPI_GELU) {
             if (g.out2_bf16) put(g.out2_bf16, g.ldo2, i, val);
@@ -756,8 +766,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 //   half 0 of k-tile j (stage s):  MFMA(j, 0) | read frags(j, 1) from s | ds_write k-tile j+1 -> s^1 | global loads of j+2
 //   lgkmcnt(0), barrier
 //   half 1:                        MFMA(j, 1) | read frags(j+1, 0) from s^1
-constexpr int V3_STAGE = 2 * V2_TILE_B;       // A 192 x 128 B + B 192 x 128 B
-constexpr int V3_LDS = 2 * V3_STAGE;
+
+
 
 __device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
@@ -771,11 +781,22 @@ __device__ __forceinline__ void mfma_agpr_first(f32x4& c, const bf16x8& a, const
 // aside at the boundary, one twelfth of the stores per k-tile between the MFMAs -- and was bit-exact, but slower: on this ISA
 // loads and stores share vmcnt and complete out of order with respect to each other, so with one store in flight every
 // wait for a staging load becomes vmcnt(0).  The epilogue therefore stays at the tile boundary, as in v2.)
-constexpr int V3_EPI_OFF = V3_LDS;                  // per-wave epilogue staging behind the two stages
-constexpr int V3_LDS_TOTAL = V3_LDS + 4 * V2_EPI_WAVE;
+// RT = 16-row MFMA tiles per wave along M: 6 -> 192 x 192 block tile (96 x 96 per wave), 8 -> 256 x 192 (128 x 96 per
+// wave) for launches whose tile count then still fills whole rounds (N = 3072 at M = 11 840: 3 rounds instead of 4).
+template <int RT> struct V3Cfg {
+    static constexpr int BM = 32 * RT;
+    static constexpr int TILE_A = BM * BK * 2;
+    static constexpr int STAGE = TILE_A + V2_TILE_B;
+    static constexpr int EPI_OFF = 2 * STAGE;
+    static constexpr int LDS = EPI_OFF + 4 * V2_EPI_WAVE;      // 116 / 132 KiB
+    static constexpr int NP = RT + 6;                         // staging pieces per wave and k-tile (A: RT, B: 6)
+};
 
-template <int EPI>
+template <int EPI, int RT>
 __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
+    using Cfg = V3Cfg<RT>;
+    constexpr int NP = Cfg::NP, NM = 6 * RT;                  // MFMAs per k-half
+    static_assert(3 * NP <= NM, "one filler per MFMA");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmArgs& g = a.g;
     const int tid = threadIdx.x;
@@ -788,24 +809,28 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     const int nk = g.K / BK;
     const int total_it = my_tiles * nk;
 
-    f32x4 acc[6][6];
+    f32x4 acc[RT][6];
     int m0, n0, m_last;
     v2_tile_coords(a, bid, total, m0, n0, m_last);
-    unsigned pp[12];                     // byte offsets of this lane's staging pieces from A / B (operands < 4 GiB: checked)
+    unsigned pp[NP];                     // byte offsets of this lane's staging pieces from A / B (operands < 4 GiB: checked)
     auto piece_ptrs = [&](int tm0, int tml, int tn0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int r = (wave * RT + i) * 8 + (lane >> 3);
+            pp[i] = ((unsigned)min(tm0 + r, tml) * (unsigned)g.lda + (lane & 7) * 8) * 2u;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int r = (wave * 6 + i) * 8 + (lane >> 3);
-            pp[i] = ((unsigned)min(tm0 + r, tml) * (unsigned)g.lda + (lane & 7) * 8) * 2u;
-            pp[6 + i] = ((unsigned)min(tn0 + r, g.N - 1) * (unsigned)g.ldb + (lane & 7) * 8) * 2u;
+            pp[RT + i] = ((unsigned)min(tn0 + r, g.N - 1) * (unsigned)g.ldb + (lane & 7) * 8) * 2u;
         }
     };
     piece_ptrs(m0, m_last, n0);
     int l_tile = 0, l_kt = 0, issued = 0;
     const int lds_lane = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 3)) & 7) << 4);
-    u32x4 rs[12];
+    u32x4 rs[NP];
     auto gload_piece = [&](int p) {
-        const char* base = reinterpret_cast<const char*>(p < 6 ? g.A : g.B);
+        const char* base = reinterpret_cast<const char*>(p < RT ? g.A : g.B);
         rs[p] = *reinterpret_cast<const u32x4*>(base + (pp[p] + (unsigned)(l_kt * BK * 2)));
     };
     auto stream_advance = [&]() {
@@ -821,55 +846,56 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
         ++issued;
     };
     auto lwrite_piece = [&](int p, int stage) {
-        char* sb = smem + stage * V3_STAGE + lds_lane + (p < 6 ? (wave * 6 + p) * 1024 : V2_TILE_B + (wave * 6 + p - 6) * 1024);
+        char* sb = smem + stage * Cfg::STAGE + lds_lane +
+                   (p < RT ? (wave * RT + p) * 1024 : Cfg::TILE_A + (wave * 6 + p - RT) * 1024);
         *reinterpret_cast<u32x4*>(sb) = rs[p];
     };
 
     const int frow = lane & 15, fg = lane >> 4;
     const int frag_off[2] = {frow * 128 + (((0 + fg) ^ (frow & 7)) << 4), frow * 128 + (((4 + fg) ^ (frow & 7)) << 4)};
-    bf16x8 fa[2][6], fb[2][6];
+    bf16x8 fa[2][RT], fb[2][6];
     auto read_a = [&](int stage, int ks, int i) {
-        fa[ks][i] = *reinterpret_cast<const bf16x8*>(smem + stage * V3_STAGE + frag_off[ks] + (wm * 96 + i * 16) * 128);
+        fa[ks][i] = *reinterpret_cast<const bf16x8*>(smem + stage * Cfg::STAGE + frag_off[ks] + (wm * (16 * RT) + i * 16) * 128);
     };
     auto read_b = [&](int stage, int ks, int j) {
-        fb[ks][j] = *reinterpret_cast<const bf16x8*>(smem + stage * V3_STAGE + V2_TILE_B + frag_off[ks] + (wn * 96 + j * 16) * 128);
+        fb[ks][j] = *reinterpret_cast<const bf16x8*>(smem + stage * Cfg::STAGE + Cfg::TILE_A + frag_off[ks] + (wn * 96 + j * 16) * 128);
+    };
+    auto read_frag = [&](int stage, int ks, int q) {           // q < 6: B fragment q (every MFMA row needs them), then A
+        if (q < 6) read_b(stage, ks, q);
+        else read_a(stage, ks, q - 6);
     };
 
 #pragma unroll
-    for (int p = 0; p < 12; ++p) gload_piece(p);
+    for (int p = 0; p < NP; ++p) gload_piece(p);
     stream_advance();
 #pragma unroll
-    for (int p = 0; p < 12; ++p) lwrite_piece(p, 0);
+    for (int p = 0; p < NP; ++p) lwrite_piece(p, 0);
 #pragma unroll
-    for (int p = 0; p < 12; ++p) gload_piece(p);
+    for (int p = 0; p < NP; ++p) gload_piece(p);
     stream_advance();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        read_b(0, 0, i);
-        read_a(0, 0, i);
-    }
+    for (int q = 0; q < NP; ++q) read_frag(0, 0, q);
 
     // one k-tile; FIRST: the tile's first k-tile, whose half 0 starts the accumulators from the constant 0
     auto k_tile = [&](auto first_tag, const int st) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        // ---- half 0: MFMA (i, j) then filler #(6 i + j): 12 fragment reads, 12 staging writes, 12 staging loads
+        // ---- half 0: MFMA (i, j) then filler #(6 i + j): NP fragment reads, then per piece its write and its reload
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 if (FIRST) mfma_agpr_first(acc[i][j], fb[0][j], fa[0][i]);
                 else mfma_agpr(acc[i][j], fb[0][j], fa[0][i]);
                 const int f = 6 * i + j;
                 __builtin_amdgcn_sched_barrier(0);
-                if (f < 12) {                              // fragments of k-half 1
-                    if (f < 6) read_b(st, 1, f);
-                    else read_a(st, 1, f - 6);
-                } else {                                   // k-tile j+1 -> the other stage, piece by piece, each register
-                    const int q = f - 12;                  // refilled with k-tile j+2 right behind its write (12 writes in a
-                    if ((q & 1) == 0) lwrite_piece(q >> 1, st ^ 1);   // row, then the loads, with the barrier pulled forward
-                    else gload_piece(q >> 1);              // to slot 29: 10 % slower -- the four waves' writes collide)
+                if (f < NP) {                              // fragments of k-half 1
+                    read_frag(st, 1, f);
+                } else if (f < 3 * NP) {                   // k-tile j+1 -> the other stage, piece by piece, each register
+                    const int q = f - NP;                  // refilled with k-tile j+2 right behind its write (all writes in a
+                    if ((q & 1) == 0) lwrite_piece(q >> 1, st ^ 1);   // row, then the loads, with the barrier pulled forward:
+                    else gload_piece(q >> 1);              // 10 % slower -- the four waves' writes collide)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -878,22 +904,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
         __builtin_amdgcn_s_barrier();
         // ---- half 1: the fragments of the next k-tile's half 0 behind the first two MFMA rows
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 mfma_agpr(acc[i][j], fb[1][j], fa[1][i]);
                 const int f = 6 * i + j;
                 __builtin_amdgcn_sched_barrier(0);
-                if (f >= 12 && f < 24) {
-                    const int q = f - 12;
-                    if (q < 6) read_b(st ^ 1, 0, q);
-                    else read_a(st ^ 1, 0, q - 6);
-                }
+                if (f >= 12 && f < 12 + NP) read_frag(st ^ 1, 0, f - 12);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
 
-    char* stg = smem + V3_EPI_OFF + wave * V2_EPI_WAVE;
+    char* stg = smem + Cfg::EPI_OFF + wave * V2_EPI_WAVE;
     int it = 0;
     for (int tile = 0; tile < my_tiles; ++tile) {
         k_tile(std::true_type{}, it & 1);
@@ -902,15 +924,15 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
         // The compiler cannot see that the asm blocks are MFMAs: it would read their results right behind them.  The wait
         // states are attached to the accumulators themselves (in / out operands), row by row.
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < RT; ++i)
             asm volatile("s_nop 15\n\ts_nop 15"
                          : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
         if (!(a.dbg & 8)) {
-            const int mb = m0 + wm * 96, nb = n0 + wn * 96, me = m_last + 1;
+            const int mb = m0 + wm * (16 * RT), nb = n0 + wn * 96, me = m_last + 1;
             if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU)
-                v2_epilogue_bf16<EPI, 6>(g, acc, stg, mb, nb, me, lane);
+                v2_epilogue_bf16<EPI, RT, true>(g, acc, stg, mb, nb, me, lane);
             else
-                v2_epilogue<EPI, 6>(g, acc, stg, mb, nb, me, lane);
+                v2_epilogue<EPI, RT>(g, acc, stg, mb, nb, me, lane);
         }
         if (tile + 1 < my_tiles) v2_tile_coords(a, bid + (tile + 1) * grid, total, m0, n0, m_last);
     }
@@ -1062,16 +1084,20 @@ static const V2Kernel (*v2_kernel_table())[5] {
     return kernels;
 }
 
-static const V2Kernel* v3_kernel_table() {
-    static const V2Kernel kernels[5] = {gemm_nt_v3_kernel<FEDDAT_EPI_BF16>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32>,
-                                        gemm_nt_v3_kernel<FEDDAT_EPI_GELU>, gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU>,
-                                        gemm_nt_v3_kernel<FEDDAT_EPI_F32>};
+static const V2Kernel (*v3_kernel_table())[5] {
+    static const V2Kernel kernels[2][5] = {
+        {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 6>,
+         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 6>},
+        {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 8>,
+         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 8>}};
     return kernels;
 }
 
 int fd_prepare_gemm_kernels() {
-    for (int e = 0; e < 5; ++e)
-        if (fd_set_max_lds((const void*)v3_kernel_table()[e], V3_LDS_TOTAL) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+    for (int w = 0; w < 2; ++w)
+        for (int e = 0; e < 5; ++e)
+            if (fd_set_max_lds((const void*)v3_kernel_table()[w][e], w ? V3Cfg<8>::LDS : V3Cfg<6>::LDS) != FEDDAT_OK)
+                return FEDDAT_ELAUNCH;
     for (int w = 0; w < 2; ++w)
         for (int e = 0; e < 5; ++e)
             if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
@@ -1193,18 +1219,20 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         if (dbg & 32) wm4 = false;
         if (dbg & 64) wm4 = true;
         a2 = wm4 ? a4 : a3;
-        // v3 (one wave per SIMD) has the faster k-loop (1.09-1.23 PF/s against 0.96-1.15) but only four waves to run an
-        // epilogue: it takes every launch except the two heavy epilogues (GELU with two outputs, . gelu'(aux) with its cold
-        // aux operand: in the step 89.8 us on v3 against 82.0) and the smallest plain product (measured per shape in the
-        // step, tools/step_breakdown.py --detail); debug flag 1 keeps everything on v2, flag 2 forces v3
-        const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU &&
-                             !(epi == FEDDAT_EPI_BF16 && K <= 768 && N <= 768);
+        // v3 (one wave per SIMD) has the faster k-loop (1.1-1.28 PF/s against 0.96-1.15) but only four waves to run an
+        // epilogue: it takes every launch except the two heavy epilogues (GELU with two outputs; . gelu'(aux) with its cold
+        // aux operand) -- in isolation v3 is level or ahead on those too (84 against 98 us for . gelu'), in the step, with
+        // nothing cache-warm, it is behind (86 / 89 us against 82 / 81: tools/step_breakdown.py --detail); debug flag 1
+        // keeps everything on v2, flag 2 forces v3
+        const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU;
         if (((dbg & 2) || v3_pick) && !(dbg & 1)) {
-            const V2Kernel k3 = v3_kernel_table()[epi];
-            a2 = a3;
-            if (fd_set_max_lds((const void*)k3, V3_LDS_TOTAL) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+            const bool rt8 = (dbg & 64) ? true : (dbg & 32) ? false : wm4;
+            const V2Kernel k3 = v3_kernel_table()[rt8 ? 1 : 0][epi];
+            a2 = rt8 ? a4 : a3;
+            const int lds3 = rt8 ? V3Cfg<8>::LDS : V3Cfg<6>::LDS;
+            if (fd_set_max_lds((const void*)k3, lds3) != FEDDAT_OK) return FEDDAT_ELAUNCH;
             const int total3 = a2.tiles_m * (N / V2_BN);
-            hipLaunchKernelGGL(k3, dim3(total3 < n_cu ? total3 : n_cu), dim3(256), V3_LDS_TOTAL, stream, a2);
+            hipLaunchKernelGGL(k3, dim3(total3 < n_cu ? total3 : n_cu), dim3(256), lds3, stream, a2);
             FD_LAUNCH_RET();
         }
         const V2Kernel kern = v2_kernel_table()[wm4 ? 1 : 0][epi];

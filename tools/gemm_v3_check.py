@@ -7,7 +7,7 @@ for (M, N, K) in [(11840, 768, 768), (11849, 3072, 768), (5920, 2304, 768), (120
     A = torch.randn(M, K, device=dev).bfloat16(); B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     bias = torch.randn(N, device=dev); resid = torch.randn(M, N, device=dev); aux = torch.randn(M, N, device=dev).bfloat16()
     outs = {}
-    for flag in (0, int(sys.argv[1]) if len(sys.argv) > 1 else 1):
+    for flag in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 2):     # 1 = v2 only
         L.set_debug_flags(flag)
         o = torch.zeros(M, N, dtype=torch.bfloat16, device=dev); o2 = torch.zeros_like(o); o3 = torch.zeros_like(o)
         o32 = torch.zeros(M, N, device=dev); o4 = torch.zeros_like(o); o5 = torch.zeros(M, N, device=dev)
@@ -20,6 +20,6 @@ for (M, N, K) in [(11840, 768, 768), (11849, 3072, 768), (5920, 2304, 768), (120
         torch.cuda.synchronize()
         outs[flag] = [o, o32, o2, o3, o4, o5]
     L.set_debug_flags(0)
-    k1 = [k for k in outs if k != 0][0]
-    d = [float((x.float() - y.float()).abs().max()) for x, y in zip(outs[0], outs[k1])]
+    k1 = [k for k in outs if k != 1][0]
+    d = [float((x.float() - y.float()).abs().max()) for x, y in zip(outs[1], outs[k1])]
     print(M, N, K, "max abs diff v2 vs v3 per epilogue:", ["%.3g" % v for v in d])

@@ -14,7 +14,7 @@ for (N, K, epi) in [(3072, 768, 3), (3072, 768, 2), (3072, 768, 0), (2304, 768, 
         elif epi == 2: L.gemm_bf16_nt(A, B, 2, bias=bias, out_bf16=o, out2_bf16=o2)
         elif epi == 3: L.gemm_bf16_nt(A, B, 3, aux=aux, out_bf16=o)
     res = []
-    for flag in (1 | 32, 1 | 64, 1 | 32 | 8, 2, 2 | 8):      # 1: v2 only, 2: force v3
+    for flag in (1 | 32, 1 | 64, 2 | 32, 2 | 64, 2 | 32 | 8, 2 | 64 | 8):      # 1: v2 only, 2: force v3; 32 / 64: 192- / 256-row tiles
         L.set_debug_flags(flag)
         call(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -25,4 +25,4 @@ for (N, K, epi) in [(3072, 768, 3), (3072, 768, 2), (3072, 768, 0), (2304, 768, 
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 20 * 1e3)
     L.set_debug_flags(0)
-    print(f"N={N} K={K} epi={epi}: WM3 {res[0]:.1f} us  WM4 {res[1]:.1f} us  | WM3 without epilogue {res[2]:.1f} us ({2*M*N*K/res[2]/1e6:.0f} TF/s) | v3 {res[3]:.1f} us, without epilogue {res[4]:.1f} us ({2*M*N*K/res[4]/1e6:.0f} TF/s)")
+    print(f"N={N} K={K} epi={epi}: v2 192 {res[0]:.1f} / 256 {res[1]:.1f} us | v3 192 {res[2]:.1f} / 256 {res[3]:.1f} us | v3 k-loop only 192 {res[4]:.1f} ({2*M*N*K/res[4]/1e6:.0f} TF/s) / 256 {res[5]:.1f} ({2*M*N*K/res[5]/1e6:.0f} TF/s)")
