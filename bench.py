@@ -123,7 +123,7 @@ def measure_gemms_in_step(L, eng, batches, steps=3):
                                                            empty_bracket_us=round(empty_us, 2), other_ops_ms_per_step=other)
 
 
-def profiled_traffic(kernel_substr="gemm_nt_v2_kernel"):
+def profiled_traffic(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel")):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_per_kernel.csv,
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
     FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled."""
@@ -134,7 +134,7 @@ def profiled_traffic(kernel_substr="gemm_nt_v2_kernel"):
         return None
     tot, n = 0.0, 0        # the kernel is templated on its epilogue: dispatch-weighted mean over all instantiations
     for r in csv.DictReader(open(files[-1])):
-        if kernel_substr in r["kernel"] and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
+        if any(k in r["kernel"] for k in kernel_substrs) and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
             k = int(r["dispatches"])
             tot += k * (2 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024
             n += k
@@ -238,8 +238,8 @@ def roofline_block(L, eng, batches, gemms):
     ach, tsum, rows, alg_bytes, launches, in_step_info = measure_gemms_in_step(L, eng, batches)
     ach_iso, tsum_iso, rows_iso = measure_gemms(L, gemms)
     tr = profiled_traffic()
-    return {"kernel": "gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one train_step, FLOP-weighted, "
-                      "durations measured in-step)",
+    return {"kernel": "gemm_nt_v3_kernel / gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one train_step, "
+                      "FLOP-weighted, durations measured in-step)",
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16, 4), "frac_in_step": round(ach / PEAK_BF16, 4),
             "frac_isolated": round(ach_iso / PEAK_BF16, 4),
