@@ -830,8 +830,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     const int lds_lane = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 3)) & 7) << 4);
     u32x4 rs[NP];
     auto gload_piece = [&](int p) {
-        const char* base = reinterpret_cast<const char*>(p < RT ? g.A : g.B);
-        rs[p] = *reinterpret_cast<const u32x4*>(base + (pp[p] + (unsigned)(l_kt * BK * 2)));
+        // scalar base (operand + k offset of the stream position) + this lane's 32-bit piece offset: no vector address math
+        const char* base = reinterpret_cast<const char*>(p < RT ? g.A : g.B) + (size_t)l_kt * (BK * 2);
+        rs[p] = *reinterpret_cast<const u32x4*>(base + pp[p]);
     };
     auto stream_advance = [&]() {
         if (issued + 1 < total_it) {
