@@ -94,6 +94,40 @@ def test_gemm_epilogues(L, M, N, K):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,N,K", [(11849, 3072, 768), (5920, 2304, 768), (11840, 768, 3072), (1030, 192, 64)])
+def test_gemm_kernel_variants_bit_identical(L, M, N, K):
+    """The two persistent kernels (v2: two wave groups per SIMD; v3: one wave per SIMD, inline-asm MFMAs with AGPR
+    accumulators) and both tile heights of each accumulate in the same order and share the epilogues: every epilogue's
+    output must be bit-identical across them (the production dispatch mixes them per launch)."""
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    B = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    aux = bf(torch.randn(M, N, generator=g)).to(DEV)
+
+    def run(flags):
+        L.set_debug_flags(flags)
+        try:
+            o0 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            o2, u2, o3 = torch.zeros_like(o0), torch.zeros_like(o0), torch.zeros_like(o0)
+            o1, o4 = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+            L.gemm_bf16_nt(A, B, L.EPI_BF16, bias=bias, out_bf16=o0)
+            L.gemm_bf16_nt(A, B, L.EPI_RESID_F32, bias=bias, resid=resid, out_f32=o1)
+            L.gemm_bf16_nt(A, B, L.EPI_GELU, bias=bias, out_bf16=o2, out2_bf16=u2)
+            L.gemm_bf16_nt(A, B, L.EPI_MUL_DGELU, aux=aux, out_bf16=o3)
+            L.gemm_bf16_nt(A, B, L.EPI_F32, bias=bias, out_f32=o4)
+            torch.cuda.synchronize()
+        finally:
+            L.set_debug_flags(0)
+        return [o0, o1, o2, u2, o3, o4]
+    ref = run(1 | 32)                      # v2, 192-row tiles
+    assert rel_err(ref[0], A.float() @ B.float().t() + bias) < 1.5e-2
+    for flags in (1 | 64, 2 | 32, 2 | 64, 0):      # v2 256-row, v3 192 / 256-row, production dispatch
+        for a_, b_ in zip(ref, run(flags)):
+            assert torch.equal(a_, b_), flags
+
+
 def test_gemm_rejects_bad_shapes(L):
     A = torch.zeros(8, 60, dtype=torch.bfloat16, device=DEV)
     B = torch.zeros(100, 60, dtype=torch.bfloat16, device=DEV)
