@@ -2,11 +2,11 @@
 //     dW_down[r][c] = sum_t dz[t][r] * x[t][c]          db_down[r] = sum_t dz[t][r]
 //     dW_up  [c][r] = s * sum_t dy[t][c] * z[t][r]      db_up  [c] = s * sum_t dy[t][c]
 // Both are "small^T x big" products contracted over the tokens: small = [T,48], big = [T,768], fp32.
-// bf16 MFMA 16x16x32 on split operands (every fp32 value = bf16 head + bf16 remainder, three products per pair: fp32
+// bf16 MFMA 16x16x32 on split operands (every fp32 value = bf16 head + bf16 remainder, all four products per pair: fp32
 // accuracy to ~2^-16 relative per product, fp32 accumulation; details at the loop): lane (index, token group) =
 // (lane & 15, lane >> 4) holds 8 consecutive tokens of its index, so the token-major activations are consumed as they
 // lie in HBM, no transposes.  A wave owns 64 columns x all 48 bottleneck units for a range of tokens: 8 float4 loads of
-// `big` feed 4 interleaved column tiles, 24 dword loads of `small` feed the 3 r-tiles -> 36 MFMAs per 32 tokens.  The 4
+// `big` feed 4 interleaved column tiles, 24 dword loads of `small` feed the 3 r-tiles -> 48 MFMAs per 32 tokens.  The 4
 // waves of a block own 4 consecutive token ranges and are summed through LDS; the NBLK blocks per column chunk leave NBLK
 // partials that the (deterministic) reduce kernel folds straight into the flat gradient buffer [wd | bd | wu | bu].
 // HBM-bound in bytes (x and dy are each read once: 2 x T x 768 x 4 B).
@@ -19,8 +19,8 @@ constexpr int NCH = H / CW;                                 // 12 column chunks
 constexpr int NBLK = 10;                                    // token-split blocks per column chunk: 12 x 10 x 4 problems = 480 blocks
 constexpr int PSTRIDE = R * H + R + H;                      // one partial: [out r x c | colsum_small | colsum_big]
 
-// x[0..7] (fp32) -> head = bf16(x) (round to nearest even: the remainder is zero-mean and <= 2^-9 |x|, so the dropped
-// remainder x remainder product is ~2^-18 relative; truncated heads left a one-signed 2^-14 bias), rest = bf16(x - head)
+// x[0..7] (fp32) -> head = bf16(x) (round to nearest even: the remainder is zero-mean and <= 2^-9 |x|; truncated heads
+// left a one-signed 2^-14 bias in the remainder x remainder product), rest = bf16(x - head)
 __device__ __forceinline__ void split_bf16x2(const float (&x)[8], bf16x8& head, bf16x8& rest) {
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     head = cvt8(f32x4{x[0], x[1], x[2], x[3]}, f32x4{x[4], x[5], x[6], x[7]});
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
     // 32 tokens per round.  Lane (i16, g) holds tokens t0 + 8 g .. + 7 of its 4 columns (one float4 per token) and of
     // its bottleneck unit per r-tile: exactly the K = 32 operand layout of the bf16 MFMA, no transposes.  Every fp32
     // value is split into its bf16 rounding and the bf16-rounded remainder (x = h + l to 2^-17 relative) and the
-    // product is h h' + h l' + l h' on the bf16 pipe: 9 bf16 MFMAs (16 clk each) replace 24 fp32 MFMAs (32 clk each)
+    // product is l l' + l h' + h l' + h h' on the bf16 pipe: 12 bf16 MFMAs (16 clk each) replace 24 fp32 MFMAs (32 clk each)
     // per (r-tile, column tile, 32 tokens); the fp32 form made this kernel MFMA-bound at 1/16 of the bf16 rate.
     // Accumulation stays fp32; the bias gradients (column sums) are exact fp32 adds.
     // the loads of round j + 1 are issued before the products of round j (addresses of masked tokens fall back to row 0, values
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
             split_bf16x2(x, bh, bl);
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
+                acc[rt][v] = mfma16x32(sl[rt], bl, acc[rt][v]);        // smallest terms first
                 acc[rt][v] = mfma16x32(sl[rt], bh, acc[rt][v]);
                 acc[rt][v] = mfma16x32(sh[rt], bl, acc[rt][v]);
                 acc[rt][v] = mfma16x32(sh[rt], bh, acc[rt][v]);
