@@ -14,7 +14,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # MFMA results that feed VALU code right away (softmax, ReLU masks): keep them in VGPRs instead of AGPRs, which saves
 # one v_accvgpr_read per accumulator element (attention backward: 240 of its 1160 VALU instructions)
 _VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-PER_FILE_FLAGS = {"attention.hip": _VGPR_MFMA}
+# adapter.hip: the weight-stationary kernels keep 288 dwords of MFMA A operands in AGPRs; their results feed VALU code
+PER_FILE_FLAGS = {"attention.hip": _VGPR_MFMA, "adapter.hip": _VGPR_MFMA}
 
 
 def _stale(target, deps):

@@ -133,174 +133,6 @@ struct LnFuse {            // optional LayerNorm of the adapter output (the next
     float eps;
 };
 
-template <int NA>
-__device__ __forceinline__ void fwd_body(const float* __restrict__ x, float* __restrict__ out,
-                                         const feddat_adapter_seg& sg, int row0, float* stg_all, const LnFuse& ln,
-                                         float* lnred, float* __restrict__ z_save) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, i16 = lane & 15;
-    const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
-    float* stg = stg_all + wave * STG_WAVE;
-
-    // 1. this wave's [16 x 192] slice of x: HBM -> registers (row-contiguous) -> LDS -> MFMA fragments
-    f32x4 xk[KS / 4][2];
-    {
-        f32x4 v[NLD];
-        slice_load(x + (size_t)(row0 + sg.x_row_delta) * H + wave * WCOLS, nvalid, lane, v);
-        FD_COMPILER_FENCE();
-        slice_to_lds(stg, lane, v);
-    }
-    frags_from_lds(stg, lane, xk);
-
-    // 2. down-projection of this wave's feature quarter, K-split reduce
-    const bf16* wd[2] = {(const bf16*)sg.wd[0], (const bf16*)sg.wd[NA - 1]};
-    f32x4 z[2][NT];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    down_proj<NA>(wd, lane, wave * (KS / 4), z, xk);
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) ksplit_store<NA * NT>(stg_all, wave, lane, a * NT + nt, z[a][nt]);
-    __syncthreads();
-    bf16x8 zb01[NA], zb2[NA];
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 t = ksplit_sum<NA * NT>(stg_all, lane, a * NT + nt);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sg.bd[a] + nt * 16 + 4 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(t[e] + b4[e], 0.f);
-            // relu(Wd x + bd), fp32 [T][2][48], saved for the backward (which then neither re-reads x nor repeats the
-            // down-projection).  Wave nt stores r-tile nt right here: the one early store of the kernel costs the later
-            // weight waits one L2 write acknowledgement, keeping 6 tiles alive to the end cost spills
-            if (z_save && nt == wave && i16 < nvalid)
-                *reinterpret_cast<f32x4*>(z_save + (size_t)(row0 + i16) * (2 * R) + a * R + nt * 16 + 4 * g) = z[a][nt];
-        }
-        zb01[a] = cvt8(z[a][0], z[a][1]);
-        zb2[a] = pad8(z[a][2]);
-    }
-
-    // 3. up-projection of this wave's 12 column tiles; the results replace the kept x fragments
-#pragma unroll
-    for (int k = 0; k < CT / 4; ++k) {
-        const int ct = wave * (CT / 4) + k;
-        const int c = ct * 16 + 4 * g;
-        f32x4 o = xk[k >> 1][k & 1];           // x[row][c .. c+3]
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            bf16x8 w01, w2;
-            load_w48((const bf16*)sg.wu[a], ct, lane, w01, w2);
-            f32x4 y = mfma16x32(w01, zb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
-            y = mfma16x32(w2, zb2[a], y);
-            const f32x4 bu4 = *reinterpret_cast<const f32x4*>(sg.bu[a] + c);
-            const float sc = sg.scale[a];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += sc * (y[e] + bu4[e]);
-        }
-        xk[k >> 1][k & 1] = o;
-    }
-
-    // 4. LayerNorm statistics over the 768 outputs of each token: 48 per lane -> 4 lane groups (shuffles) -> 4 waves
-    // (LDS, fixed order); two passes (mean, then centred second moment) like the stand-alone LN kernel
-    float mean = 0.f, rstd = 0.f;
-    f32x4 gam[3], bet[3];                      // read-back path: lane l handles chunks (l + 16 j) % 48, j = 0..2
-    if (ln.gamma) {                            // uniform over the launch
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c = (lane + 16 * j) % WCH;
-            gam[j] = *reinterpret_cast<const f32x4*>(ln.gamma + wave * WCOLS + c * 4);
-            bet[j] = *reinterpret_cast<const f32x4*>(ln.beta + wave * WCOLS + c * 4);
-        }
-        float s1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < CT / 4; ++k) {
-            const f32x4 o = xk[k >> 1][k & 1];
-            s1 += (o[0] + o[1]) + (o[2] + o[3]);
-        }
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        if (g == 0) lnred[wave * 16 + i16] = s1;
-        __syncthreads();
-        mean = ((lnred[i16] + lnred[16 + i16]) + (lnred[32 + i16] + lnred[48 + i16])) * (1.0f / H);
-        float s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < CT / 4; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = xk[k >> 1][k & 1][e] - mean;
-                s2 += d * d;
-            }
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (g == 0) lnred[64 + wave * 16 + i16] = s2;
-        __syncthreads();
-        const float var = ((lnred[64 + i16] + lnred[80 + i16]) + (lnred[96 + i16] + lnred[112 + i16])) * (1.0f / H);
-        rstd = rsqrtf(var + ln.eps);
-        // per-wave copy of the row statistics for the read-back path (rows are indexed by f / 48 there, not by lane & 15)
-        if (g == 0) {
-            lnred[128 + wave * 32 + 2 * i16] = mean;
-            lnred[128 + wave * 32 + 2 * i16 + 1] = rstd;
-        }
-    } else {
-        __syncthreads();                       // every wave is done with the partials parked in the staging regions
-    }
-
-    // 5. outputs: fragment layout -> LDS -> row-contiguous stores (fp32 out; bf16 LN(out) computed on the way)
-    frags_to_lds(stg, lane, xk);
-    float* orow = out + (size_t)row0 * H + wave * WCOLS;
-    if (!ln.gamma) {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * ROWF + c * 4);
-            if (r < nvalid) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v;
-        }
-        return;
-    }
-    bf16* yrow = ln.y16 + (size_t)row0 * H + wave * WCOLS;
-    f32x4 v[NLD];
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
-        v[j] = *reinterpret_cast<const f32x4*>(stg + r * ROWF + c * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
-        if (r < nvalid) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int f = j * 64 + lane, r = f / WCH, c = f - r * WCH;
-        const float m = lnred[128 + wave * 32 + 2 * r], rs = lnred[128 + wave * 32 + 2 * r + 1];
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - m) * rs * gam[j % 3][e] + bet[j % 3][e];
-        if (r < nvalid) *reinterpret_cast<bf16x4*>(yrow + (size_t)r * H + c * 4) = cvt4(y);
-    }
-    if (wave == 0 && g == 0 && i16 < nvalid && ln.stats) {
-        ln.stats[2 * (size_t)(row0 + i16)] = mean;
-        ln.stats[2 * (size_t)(row0 + i16) + 1] = rstd;
-    }
-}
-
-__global__ __launch_bounds__(256, 3) void adapter_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                             AdapterLaunch L, LnFuse ln, float* __restrict__ z_save) {
-    __shared__ __attribute__((aligned(16))) float stg[4 * STG_WAVE];
-    __shared__ float lnred[128 + 4 * 32];
-    const int tile = blockIdx.x;
-    const int s = tile < L.tiles0 ? 0 : 1;
-    const int t = s ? tile - L.tiles0 : tile;
-    const feddat_adapter_seg& sg = L.seg[s];
-    const int row0 = sg.row_begin + t * 16;
-    if (sg.n_adapters == 2) fwd_body<2>(x, out, sg, row0, stg, ln, lnred, z_save);
-    else fwd_body<1>(x, out, sg, row0, stg, ln, lnred, z_save);
-}
-
 // ZS: the forward saved z = relu(Wd x + bd) for every adapter of the segment (feddat_adapter_fwd*'s z_save): the backward
 // then reads dy and 192-384 B of z per token instead of dy and x, and runs one K=768 product per adapter instead of two.
 template <int NA, bool ZS>
@@ -444,7 +276,7 @@ __device__ __forceinline__ void bwd_body(const float* __restrict__ x, const floa
 }
 
 template <bool ZS>
-__global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 2) void adapter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dx, bf16* __restrict__ dx16,
                                                           float* __restrict__ z_out, float* __restrict__ dz_out,
                                                           AdapterLaunch L, const float* __restrict__ z_saved) {
@@ -457,6 +289,517 @@ __global__ __launch_bounds__(256, 3) void adapter_bwd_kernel(const float* __rest
     if (sg.n_adapters == 2) bwd_body<2, ZS>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
     else bwd_body<1, ZS>(x, dy, dx, dx16, z_out, dz_out, sg, row0, stg, z_saved);
 }
+
+// =====================================================================================================================
+// Weight-stationary persistent forms (the ones the entry points launch for every shape).
+//
+// What bounded the one-tile-per-block kernels above (r02, PMC): 740 blocks in a single generation, each a serial chain
+// load -> ~1 us of compute fed by 216-288 KB of weight fragments through L1/L2 -> store, with HBM idle during the compute
+// of all of them: 2.7 TB/s.  Here ONE block of 4 waves (one per SIMD, 512 registers each) stays on every CU:
+//   * wave w keeps its quarter of every weight matrix of its segment IN REGISTERS for the whole launch: the K-quarter
+//     of the down-type matrix (6 k-steps x 3 r-tiles x 4 dwords = 72 per adapter) and the 12 column tiles of the up-type
+//     matrix (12 x 6 = 72 per adapter): 288 dwords per lane for the gated segment; after the prologue the compute phase
+//     touches no memory but LDS;
+//   * 16-token tiles stream through two LDS buffers filled by LDS-DMA (global_load_lds, 1 KiB row pieces, no VGPR round
+//     trip): tile t+1 is in flight while tile t is computed and stored;
+//   * rows keep the 8-float padding (776-float rows) that makes the lane & 15 = token fragment reads conflict-free, and
+//     every HBM access stays row-contiguous.
+// Loads and stores share vmcnt and retire out of order with respect to each other, so the wait for tile t+1's DMA at the
+// top of an iteration is vmcnt(0) and also covers the stores of tile t; with 128 KB of traffic per tile and CU (6.5 us at
+// the CU's share of HBM) against ~1.2 us of compute that wait is where an HBM-bound kernel should be waiting.
+// =====================================================================================================================
+constexpr int ROWT = H + 8;                   // floats per LDS tile row
+constexpr int TILE_F = 16 * ROWT;             // one 16-token tile: 49 664 B
+constexpr int KSPL_F = 4 * 6 * 64 * 4;        // K-split partials: 4 waves x 6 slots x 64 lanes x f32x4 = 24 KiB
+constexpr int ZT_F = 16 * 2 * R;              // saved-z tile of the backward: 6 KiB
+
+struct WsLaunch {
+    AdapterLaunch a;
+    int g0;        // blocks [0, g0) walk segment 0, blocks [g0, gridDim.x) segment 1
+    int dbg;       // tools/ ablations (feddat_set_debug_flags bits 24..26; 0 in production): 1 no global stores, 2 no compute,
+                   // 4 no DMA beyond the first tile -- timing only, results are wrong
+};
+
+#define FD_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// LDS-DMA piece: the 64 lanes' 16-byte loads land at LDS bytes [m0, m0 + 1024).  Issued as inline asm ON PURPOSE: for the
+// builtin, hipcc's waitcnt pass assumes every later ds_read may alias the DMA's destination and puts vmcnt(0) in front of
+// each of them -- the prefetch of the NEXT tile would be waited for by the first fragment read of THIS one.  The kernels
+// wait by hand (FD_WAIT_VM0 + barrier before a tile buffer is read).  s_nop: SALU write of M0 -> LDS-DMA needs 1 wait state.
+__device__ __forceinline__ void ws_dma16(const float* g, const float* lds_dst) {
+    const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(a) : "memory");
+}
+// one 16-token tile, HBM -> LDS by DMA: 48 row pieces of 1 KiB, 12 per wave (wave w: rows 4w .. 4w+3)
+__device__ __forceinline__ void ws_tile_dma(const float* __restrict__ src, int nvalid, float* buf, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int r = wave * 4 + j / 3, part = j % 3;
+        const int rr = r < nvalid ? r : nvalid - 1;       // rows past the segment end re-read its last row
+        ws_dma16(src + (size_t)rr * H + part * 256 + lane * 4, buf + r * ROWT + part * 256);
+    }
+}
+__device__ __forceinline__ void ws_frags_from_lds(const float* buf, int wave, int lane, f32x4 (&keep)[KS / 4][2]) {
+    const float* p = buf + (lane & 15) * ROWT + wave * WCOLS + 4 * (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < KS / 4; ++k) {
+        keep[k][0] = *reinterpret_cast<const f32x4*>(p + k * 32);
+        keep[k][1] = *reinterpret_cast<const f32x4*>(p + k * 32 + 16);
+    }
+}
+__device__ __forceinline__ void ws_frags_to_lds(float* buf, int wave, int lane, const f32x4 (&keep)[KS / 4][2]) {
+    float* p = buf + (lane & 15) * ROWT + wave * WCOLS + 4 * (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < KS / 4; ++k) {
+        *reinterpret_cast<f32x4*>(p + k * 32) = keep[k][0];
+        *reinterpret_cast<f32x4*>(p + k * 32 + 16) = keep[k][1];
+    }
+}
+
+// register-resident weights of one wave: NA adapters x (K-quarter of the down-type matrix, 12 column tiles of the up-type one)
+template <int NA>
+struct WsWeights {
+    bf16x8 dn[NA][NT][KS / 4];
+    bf16x8 up01[NA][CT / 4];
+    bf16x8 up2[NA][CT / 8];      // r = 32..47 of column tiles 2p (slots 0-3) and 2p+1 (slots 4-7)
+};
+template <int NA>
+__device__ __forceinline__ void ws_load_weights(WsWeights<NA>& W, const void* const* dn, const void* const* up, int wave,
+                                                int lane) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const bf16* d = (const bf16*)dn[a];
+        const bf16* u = (const bf16*)up[a];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < KS / 4; ++k)
+                W.dn[a][nt][k] = *reinterpret_cast<const bf16x8*>(d + ((nt * KS + wave * (KS / 4) + k) * 64 + lane) * 8);
+#pragma unroll
+        for (int k = 0; k < CT / 4; ++k) {
+            const int ct = wave * (CT / 4) + k;
+            W.up01[a][k] = *reinterpret_cast<const bf16x8*>(u + (ct * 64 + lane) * 8);
+        }
+#pragma unroll
+        for (int p = 0; p < CT / 8; ++p) {
+            const int ct = wave * (CT / 4) + 2 * p;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(u + CT * 64 * 8 + (ct * 64 + lane) * 4);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(u + CT * 64 * 8 + ((ct + 1) * 64 + lane) * 4);
+            W.up2[a][p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    }
+}
+// the r = 32..47 remainder of the bottleneck as the B operand of a K = 32 MFMA whose A operand carries the remainders of
+// TWO column tiles: [z | 0] selects the even tile's weights (slots 0-3), [0 | z] the odd tile's (slots 4-7)
+__device__ __forceinline__ bf16x8 pad8hi(const f32x4 a) {
+    return bf16x8{0, 0, 0, 0, (bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3]};
+}
+
+// block -> (segment, first tile, tile stride)
+__device__ __forceinline__ void ws_walk(const WsLaunch& L, int& s, int& t0, int& tstep, int& ntiles) {
+    const int b = blockIdx.x;
+    s = b < L.g0 ? 0 : 1;
+    t0 = s ? b - L.g0 : b;
+    tstep = s ? (int)gridDim.x - L.g0 : L.g0;
+    const feddat_adapter_seg& sg = L.a.seg[s];
+    ntiles = (sg.row_end - sg.row_begin + 15) / 16;
+}
+
+template <int NA>
+__device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* __restrict__ out,
+                                            const feddat_adapter_seg& sg, int t0, int tstep, int ntiles, float* smem,
+                                            const LnFuse& ln, float* __restrict__ z_save, const int dbg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    float* kspl = smem + 2 * TILE_F;
+    float* lnred = kspl + KSPL_F;              // 256 floats
+    float* sbu = lnred + 256;                  // [2][H]  up-projection biases
+    float* sbd = sbu + 2 * H;                  // [2][64] down-projection biases
+    float* sgam = sbd + 128;                   // [H] gamma, [H] beta of the fused LayerNorm
+    float* sbet = sgam + H;
+    if (t0 >= ntiles) return;
+
+    // ---- prologue: the first two tiles in flight, weights -> registers, small tables -> LDS
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = t0 + p * tstep;
+        if (t < ntiles && !(p && (dbg & 4))) {
+            const int row0 = sg.row_begin + t * 16;
+            const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
+            ws_tile_dma(x + (size_t)(row0 + sg.x_row_delta) * H, nvalid, smem + p * TILE_F, wave, lane);
+        }
+    }
+    WsWeights<NA> W;
+    ws_load_weights<NA>(W, sg.wd, sg.wu, wave, lane);
+    for (int i = threadIdx.x; i < NA * H; i += 256) sbu[i] = sg.bu[i / H][i % H];
+    if (threadIdx.x < NA * R) sbd[(threadIdx.x / R) * 64 + threadIdx.x % R] = sg.bd[threadIdx.x / R][threadIdx.x % R];
+    if (ln.gamma)
+        for (int i = threadIdx.x; i < H; i += 256) {
+            sgam[i] = ln.gamma[i];
+            sbet[i] = ln.beta[i];
+        }
+    float sc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) sc[a] = sg.scale[a];
+    FD_WAIT_VM0();
+    __syncthreads();
+
+    // Steady state, iteration t (its tile is in LDS): compute -> vmcnt(0) [tile t+1 landed; the stores of tile t-1, issued
+    // a whole compute phase ago, are out] -> stores of tile t -> barrier -> DMA of tile t+2 into the buffer just freed.
+    // The stores of tile t and the DMA of tile t+2 are in flight during the compute phase of tile t+1.
+    int cur = 0;
+    for (int t = t0; t < ntiles; t += tstep, cur ^= 1) {
+        const int row0 = sg.row_begin + t * 16;
+        const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
+        float* buf = smem + cur * TILE_F;      // (one base pointer + offset: keeps the accesses typed as LDS, not flat)
+
+        f32x4 z_keep[NA];
+        float mean = 0.f, rstd = 0.f;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) z_keep[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 2)) {
+        // 1. + 2. down-projection of this wave's feature quarter (fragments straight from the tile buffer; the kept copy
+        // of x for the residual is re-read from LDS in step 3 instead of living in 48 registers), K-split reduce
+        const float* frag = buf + i16 * ROWT + wave * WCOLS + 4 * g;
+        f32x4 z[NA][NT];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) z[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS / 4; ++k) {
+            const bf16x8 xf = cvt8(*reinterpret_cast<const f32x4*>(frag + k * 32),
+                                   *reinterpret_cast<const f32x4*>(frag + k * 32 + 16));
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) z[a][nt] = mfma16x32(W.dn[a][nt][k], xf, z[a][nt]);
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                reinterpret_cast<f32x4*>(kspl)[(wave * 6 + a * NT + nt) * 64 + lane] = z[a][nt];
+        __syncthreads();
+        bf16x8 zb01[NA], zb2[NA][2];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 tsum = reinterpret_cast<const f32x4*>(kspl)[(a * NT + nt) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) tsum = tsum + reinterpret_cast<const f32x4*>(kspl)[(w * 6 + a * NT + nt) * 64 + lane];
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbd + a * 64 + nt * 16 + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[a][nt][e] = fmaxf(tsum[e] + b4[e], 0.f);
+                if (nt == wave) z_keep[a] = z[a][nt];      // wave nt stores r-tile nt (with the other stores, below)
+            }
+            zb01[a] = cvt8(z[a][0], z[a][1]);
+            zb2[a][0] = pad8(z[a][2]);
+            zb2[a][1] = pad8hi(z[a][2]);
+        }
+
+        // 3. up-projection of this wave's 12 column tiles on top of the residual x (fragment k of the tile buffer)
+        f32x4 xk[KS / 4][2];
+#pragma unroll
+        for (int k = 0; k < CT / 4; ++k) {
+            const int c = (wave * (CT / 4) + k) * 16 + 4 * g;
+            f32x4 o = *reinterpret_cast<const f32x4*>(frag + k * 16);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                f32x4 y = mfma16x32(W.up01[a][k], zb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
+                y = mfma16x32(W.up2[a][k >> 1], zb2[a][k & 1], y);
+                const f32x4 bu4 = *reinterpret_cast<const f32x4*>(sbu + a * H + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += sc[a] * (y[e] + bu4[e]);
+            }
+            xk[k >> 1][k & 1] = o;
+        }
+
+        // 4. LayerNorm statistics (two passes, fixed summation order)
+        if (ln.gamma) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < CT / 4; ++k) {
+                const f32x4 o = xk[k >> 1][k & 1];
+                s1 += (o[0] + o[1]) + (o[2] + o[3]);
+            }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            if (g == 0) lnred[wave * 16 + i16] = s1;
+            __syncthreads();
+            mean = ((lnred[i16] + lnred[16 + i16]) + (lnred[32 + i16] + lnred[48 + i16])) * (1.0f / H);
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < CT / 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = xk[k >> 1][k & 1][e] - mean;
+                    s2 += d * d;
+                }
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (g == 0) lnred[64 + wave * 16 + i16] = s2;
+            __syncthreads();
+            const float var = ((lnred[64 + i16] + lnred[80 + i16]) + (lnred[96 + i16] + lnred[112 + i16])) * (1.0f / H);
+            rstd = rsqrtf(var + ln.eps);
+            if (g == 0) {
+                lnred[128 + wave * 32 + 2 * i16] = mean;
+                lnred[128 + wave * 32 + 2 * i16 + 1] = rstd;
+            }
+        }
+
+        // 5. outputs: fragment layout -> LDS (this wave's own columns of the tile buffer) -> row-contiguous stores
+        ws_frags_to_lds(buf, wave, lane, xk);
+        }
+        float* orow = out + (size_t)row0 * H + wave * WCOLS;
+        const float* srow = buf + wave * WCOLS;
+        f32x4 v[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+            v[j] = *reinterpret_cast<const f32x4*>(srow + r * ROWT + c * 4);
+        }
+        FD_WAIT_VM0();                         // next tile's DMA has landed; no store is issued before this point
+        const bool st_on = !(dbg & 1);
+        if (z_save && wave < NT && i16 < nvalid && st_on) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                *reinterpret_cast<f32x4*>(z_save + (size_t)(row0 + i16) * (2 * R) + a * R + wave * 16 + 4 * g) = z_keep[a];
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+            if (r < nvalid && st_on) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
+        }
+        if (ln.gamma) {
+            bf16* yrow = ln.y16 + (size_t)row0 * H + wave * WCOLS;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+                const float m = lnred[128 + wave * 32 + 2 * r], rs = lnred[128 + wave * 32 + 2 * r + 1];
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(sgam + wave * WCOLS + c * 4);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(sbet + wave * WCOLS + c * 4);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - m) * rs * gm[e] + bt[e];
+                if (r < nvalid && st_on) *reinterpret_cast<bf16x4*>(yrow + (size_t)r * H + c * 4) = cvt4(y);
+            }
+            if (wave == 0 && g == 0 && i16 < nvalid && ln.stats && st_on) {
+                ln.stats[2 * (size_t)(row0 + i16)] = mean;
+                ln.stats[2 * (size_t)(row0 + i16) + 1] = rstd;
+            }
+        }
+        __syncthreads();                       // every wave: next tile visible, this buffer consumed
+        if (t + 2 * tstep < ntiles && !(dbg & 4)) {
+            const int rn = sg.row_begin + (t + 2 * tstep) * 16;
+            const int nv = (sg.row_end - rn) < 16 ? (sg.row_end - rn) : 16;
+            ws_tile_dma(x + (size_t)(rn + sg.x_row_delta) * H, nv, buf, wave, lane);
+        }
+    }
+}
+
+constexpr int WS_FWD_LDS = (2 * TILE_F + KSPL_F + 256 + 2 * H + 128 + 2 * H) * 4;
+
+__global__ __launch_bounds__(256, 1) void adapter_fwd_ws_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                WsLaunch L, LnFuse ln, float* __restrict__ z_save) {
+    extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+    int s, t0, tstep, ntiles;
+    ws_walk(L, s, t0, tstep, ntiles);
+    const feddat_adapter_seg& sg = L.a.seg[s];
+    if (sg.n_adapters == 2) ws_fwd_body<2>(x, out, sg, t0, tstep, ntiles, ws_smem, ln, z_save, L.dbg);
+    else ws_fwd_body<1>(x, out, sg, t0, tstep, ntiles, ws_smem, ln, z_save, L.dbg);
+}
+
+
+// saved-z tile of the backward: 16 tokens x [2][48] fp32 = 6 KiB, contiguous in HBM -> 6 DMA pieces
+__device__ __forceinline__ void ws_ztile_dma(const float* __restrict__ zs, int nvalid, float* dst, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wave + 4 * j;
+        if (piece < 6) {
+            const int fo = piece * 256 + lane * 4, r = fo / (2 * R), c = fo - r * (2 * R);
+            const int rr = r < nvalid ? r : nvalid - 1;
+            ws_dma16(zs + (size_t)rr * (2 * R) + c, dst + piece * 256);
+        }
+    }
+}
+
+// Backward, z saved by the forward.  Register-resident: WuT (down-type: g = Wu^T dy) and WdT (up-type: dx = dy + Wd^T dz).
+template <int NA>
+__device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float* __restrict__ dx, bf16* __restrict__ dx16,
+                                            float* __restrict__ z_out, float* __restrict__ dz_out,
+                                            const feddat_adapter_seg& sg, int t0, int tstep, int ntiles, float* smem,
+                                            const float* __restrict__ z_saved, const int dbg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    float* kspl = smem + 2 * TILE_F;
+    float* ztile = kspl + KSPL_F;              // [2][ZT_F]
+    if (t0 >= ntiles) return;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = t0 + p * tstep;
+        if (t < ntiles && !(p && (dbg & 4))) {
+            const int row0 = sg.row_begin + t * 16;
+            const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
+            ws_tile_dma(dy + (size_t)row0 * H, nvalid, smem + p * TILE_F, wave, lane);
+            ws_ztile_dma(z_saved + (size_t)row0 * (2 * R), nvalid, ztile + p * ZT_F, wave, lane);
+        }
+    }
+    WsWeights<NA> W;
+    ws_load_weights<NA>(W, sg.wuT, sg.wdT, wave, lane);
+    float sc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) sc[a] = sg.scale[a];
+    const int train_slot = sg.train_slot;
+    const bool exp_z = train_slot >= 0 && wave < NT && z_out;
+    FD_WAIT_VM0();
+    __syncthreads();
+
+    int cur = 0;      // pipeline order as in ws_fwd_body
+    for (int t = t0; t < ntiles; t += tstep, cur ^= 1) {
+        const int row0 = sg.row_begin + t * 16;
+        const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
+        float* buf = smem + cur * TILE_F;
+        float* zt = ztile + cur * ZT_F;
+
+        f32x4 z_keep = f32x4{0.f, 0.f, 0.f, 0.f}, dz_keep = z_keep;
+        if (!(dbg & 2)) {
+        // g = Wu^T dy over this wave's feature quarter, K-split reduce
+        const float* frag = buf + i16 * ROWT + wave * WCOLS + 4 * g;
+        f32x4 gr[NA][NT];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) gr[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS / 4; ++k) {
+            const bf16x8 df = cvt8(*reinterpret_cast<const f32x4*>(frag + k * 32),
+                                   *reinterpret_cast<const f32x4*>(frag + k * 32 + 16));
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) gr[a][nt] = mfma16x32(W.dn[a][nt][k], df, gr[a][nt]);
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                reinterpret_cast<f32x4*>(kspl)[(wave * 6 + a * NT + nt) * 64 + lane] = gr[a][nt];
+        __syncthreads();
+
+        // dz = scale * g * (z > 0); z and dz of the trainable slot go out for the weight gradients
+        bf16x8 dzb01[NA], dzb2[NA][2];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 gs = reinterpret_cast<const f32x4*>(kspl)[(a * NT + nt) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) gs = gs + reinterpret_cast<const f32x4*>(kspl)[(w * 6 + a * NT + nt) * 64 + lane];
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(zt + i16 * (2 * R) + a * R + nt * 16 + 4 * g);
+                f32x4 dz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = zz[e] > 0.f ? sc[a] * gs[e] : 0.f;
+                gr[a][nt] = dz;
+                if (a == train_slot && nt == wave) {
+                    z_keep = zz;
+                    dz_keep = dz;
+                }
+            }
+            dzb01[a] = cvt8(gr[a][0], gr[a][1]);
+            dzb2[a][0] = pad8(gr[a][2]);
+            dzb2[a][1] = pad8hi(gr[a][2]);
+        }
+        if (dx) {
+            // dx = dy + sum_a Wd[a]^T dz[a] on this wave's 12 column tiles, written back over the dy fragments
+#pragma unroll
+            for (int k = 0; k < CT / 4; ++k) {
+                f32x4 o = *reinterpret_cast<const f32x4*>(frag + k * 16);
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    f32x4 y = mfma16x32(W.up01[a][k], dzb01[a], f32x4{0.f, 0.f, 0.f, 0.f});
+                    y = mfma16x32(W.up2[a][k >> 1], dzb2[a][k & 1], y);
+                    o = o + y;
+                }
+                *reinterpret_cast<f32x4*>(buf + i16 * ROWT + wave * WCOLS + 4 * g + k * 16) = o;
+            }
+        }
+        }
+        f32x4 v[NLD];
+        if (dx) {
+            const float* srow = buf + wave * WCOLS;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+                v[j] = *reinterpret_cast<const f32x4*>(srow + r * ROWT + c * 4);
+            }
+        }
+        FD_WAIT_VM0();                         // next tile's DMA has landed; no store is issued before this point
+        const bool st_on = !(dbg & 1);
+        if (exp_z && i16 < nvalid && st_on) {
+            *reinterpret_cast<f32x4*>(z_out + (size_t)(row0 + i16) * R + wave * 16 + 4 * g) = z_keep;
+            *reinterpret_cast<f32x4*>(dz_out + (size_t)(row0 + i16) * R + wave * 16 + 4 * g) = dz_keep;
+        }
+        if (dx) {
+            float* orow = dx + (size_t)row0 * H + wave * WCOLS;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+                if (r < nvalid && st_on) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
+            }
+            if (dx16) {
+                bf16* brow = dx16 + (size_t)row0 * H + wave * WCOLS;
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+                    if (r < nvalid && st_on) *reinterpret_cast<bf16x4*>(brow + (size_t)r * H + c * 4) = cvt4(v[j]);
+                }
+            }
+        }
+        __syncthreads();                       // every wave: next tile visible, this buffer consumed
+        if (t + 2 * tstep < ntiles && !(dbg & 4)) {
+            const int rn = sg.row_begin + (t + 2 * tstep) * 16;
+            const int nv = (sg.row_end - rn) < 16 ? (sg.row_end - rn) : 16;
+            ws_tile_dma(dy + (size_t)rn * H, nv, buf, wave, lane);
+            ws_ztile_dma(z_saved + (size_t)rn * (2 * R), nv, zt, wave, lane);
+        }
+    }
+}
+
+constexpr int WS_BWD_LDS = (2 * TILE_F + KSPL_F + 2 * ZT_F) * 4;
+
+__global__ __launch_bounds__(256, 1) void adapter_bwd_ws_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                bf16* __restrict__ dx16, float* __restrict__ z_out,
+                                                                float* __restrict__ dz_out, WsLaunch L,
+                                                                const float* __restrict__ z_saved) {
+    extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+    int s, t0, tstep, ntiles;
+    ws_walk(L, s, t0, tstep, ntiles);
+    const feddat_adapter_seg& sg = L.a.seg[s];
+    if (sg.n_adapters == 2) ws_bwd_body<2>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg);
+    else ws_bwd_body<1>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg);
+}
+
+// host: blocks per segment, proportional to the tiles (at least one block per non-empty segment, one block per CU in all)
+int ws_plan(const AdapterLaunch& A, int tiles, WsLaunch& L, int& grid) {
+    int n_cu = 0;
+    const int rc = fd_device_cus(&n_cu);
+    if (rc) return rc;
+    L.a = A;
+    L.dbg = (fd_debug_flags() >> 24) & 7;
+    const int t0 = A.tiles0, t1 = tiles - A.tiles0;
+    grid = tiles < n_cu ? tiles : n_cu;
+    if (t1 == 0) L.g0 = grid;
+    else if (t0 == 0) L.g0 = 0;
+    else {
+        int g0 = (int)(((long)grid * t0 + tiles / 2) / tiles);
+        g0 = g0 < 1 ? 1 : (g0 > grid - 1 ? grid - 1 : g0);
+        L.g0 = g0;
+    }
+    return FEDDAT_OK;
+}
+
 
 __global__ __launch_bounds__(256) void adapter_pack_kernel(const float* __restrict__ wd, const float* __restrict__ wu,
                                                            bf16* __restrict__ wd16, bf16* __restrict__ wdT16,
@@ -526,6 +869,18 @@ int prep_launch(const feddat_adapter_seg* segs, int nseg, int T, AdapterLaunch& 
 // tools/ ablation: bits 16..23 of the debug flags = extra dynamic LDS in KiB (caps the resident blocks per CU)
 int dbg_extra_lds() { return ((fd_debug_flags() >> 16) & 0xff) * 1024; }
 
+int ws_launch_fwd(const float* x, float* out, const AdapterLaunch& A, int tiles, const LnFuse& ln, float* z_save,
+                  hipStream_t stream) {
+    WsLaunch W;
+    int grid;
+    int rc = ws_plan(A, tiles, W, grid);
+    if (rc) return rc;
+    rc = fd_set_max_lds((const void*)adapter_fwd_ws_kernel, WS_FWD_LDS);
+    if (rc) return rc;
+    hipLaunchKernelGGL(adapter_fwd_ws_kernel, dim3(grid), dim3(256), WS_FWD_LDS, stream, x, out, W, ln, z_save);
+    FD_LAUNCH_RET();
+}
+
 }  // namespace
 
 extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int r, const feddat_adapter_seg* segs,
@@ -536,9 +891,7 @@ extern "C" int feddat_adapter_fwd(const float* x, float* out, int T, int Hd, int
     const int rc = prep_launch(segs, nseg, T, L, tiles, false);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, out, L,
-                       LnFuse{nullptr, nullptr, nullptr, nullptr, 0.f}, z_save);
-    FD_LAUNCH_RET();
+    return ws_launch_fwd(x, out, L, tiles, LnFuse{nullptr, nullptr, nullptr, nullptr, 0.f}, z_save, stream);
 }
 
 extern "C" int feddat_adapter_fwd_ln(const float* x, float* out, int T, int Hd, int r, const feddat_adapter_seg* segs,
@@ -550,9 +903,7 @@ extern "C" int feddat_adapter_fwd_ln(const float* x, float* out, int T, int Hd, 
     const int rc = prep_launch(segs, nseg, T, L, tiles, false);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    hipLaunchKernelGGL(adapter_fwd_kernel, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, out, L,
-                       LnFuse{ln_gamma, ln_beta, (bf16*)y_bf16, stats, eps}, z_save);
-    FD_LAUNCH_RET();
+    return ws_launch_fwd(x, out, L, tiles, LnFuse{ln_gamma, ln_beta, (bf16*)y_bf16, stats, eps}, z_save, stream);
 }
 
 extern "C" int feddat_adapter_bwd(const float* x, const float* z_saved, const float* dy, float* dx, void* dx_bf16,
@@ -565,12 +916,19 @@ extern "C" int feddat_adapter_bwd(const float* x, const float* z_saved, const fl
     const int rc = prep_launch(segs, nseg, T, L, tiles, true);
     if (rc) return rc;
     if (tiles == 0) return FEDDAT_OK;
-    if (z_saved)
-        hipLaunchKernelGGL(adapter_bwd_kernel<true>, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx,
-                           (bf16*)dx_bf16, z_out, dz_out, L, z_saved);
-    else
+    if (z_saved) {
+        WsLaunch W;
+        int grid;
+        const int rc2 = ws_plan(L, tiles, W, grid);
+        if (rc2) return rc2;
+        const int rc3 = fd_set_max_lds((const void*)adapter_bwd_ws_kernel, WS_BWD_LDS);
+        if (rc3) return rc3;
+        hipLaunchKernelGGL(adapter_bwd_ws_kernel, dim3(grid), dim3(256), WS_BWD_LDS, stream, dy, dx, (bf16*)dx_bf16,
+                           z_out, dz_out, W, z_saved);
+    } else {
         hipLaunchKernelGGL(adapter_bwd_kernel<false>, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx,
                            (bf16*)dx_bf16, z_out, dz_out, L, z_saved);
+    }
     FD_LAUNCH_RET();
 }
 
