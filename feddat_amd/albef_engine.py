@@ -480,7 +480,12 @@ class AlbefDatEngine:
             grp.g.zero_()
         self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))       # adapter_1 is stepped at tick 2b
         self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))       # adapter_0 at tick 2b + 1
-        self.graph = None
+        # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
+        # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
+        sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps)
+        if getattr(self, "_graph_sig", None) != sig:
+            self.graph = None
+            self._graph_sig = sig
 
     def _adamw(self, grp: FlatGroup):
         if not hasattr(grp, "_wdv"):
@@ -505,7 +510,11 @@ class AlbefDatEngine:
         cur.wait_stream(side)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._backward("gating", logits_1)               # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
+            if 0 in self.opt_adapters:
+                self._backward("gating", logits_1)           # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
+            else:        # adapter_0 left the optimizer (server flags after the first eval): only the loss values are needed
+                L.lm_loss_fwd_bwd(logits_g, logits_1, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, None,
+                                  self.acts["gating"]["loss"])
         self._backward("adapter_1", logits_g)                # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
         cur.wait_stream(side)
         if 1 in self.opt_adapters:

@@ -15,6 +15,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define FD_WAVE 64
 
+// One target only.  Besides the K = 32 bf16 MFMA forms and the 160 KiB LDS plans, the fp8 quantisers assume OCP e4m3
+// (finite max 448): on an fnuz-e4m3 part (gfx942, max 240) amax / 448 scaling would overflow to NaN.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libfeddat_hip.so is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 #define FD_CHECK_ARG(cond)                 \
     do {                                   \
         if (!(cond)) return FEDDAT_EINVAL; \

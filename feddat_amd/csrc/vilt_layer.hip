@@ -11,14 +11,29 @@
 
 struct feddat_ctx;
 
+// The composites launch on the calling thread's CURRENT device with buffers the caller allocated there: a context that was
+// created for another device is a caller bug (its per-device kernel attributes were prepared elsewhere), reported, not
+// silently launched.  Shapes are the ViLT-B ones the kernels underneath are built for (H = 768, r = 48, I = 4 H).
+static int check_ctx_and_shape(const feddat_ctx* ctx, int heads) {
+    int cdev = -1, cur = -2;
+    if (feddat_ctx_device(ctx, &cdev, nullptr) != FEDDAT_OK) return FEDDAT_EINVAL;
+    if (hipGetDevice(&cur) != hipSuccess) return FEDDAT_ELAUNCH;
+    if (cdev != cur) return FEDDAT_EINVAL;
+    return heads * 64 == 768 ? FEDDAT_OK : FEDDAT_EINVAL;
+}
+
 extern "C" int feddat_vilt_layer_fwd(feddat_ctx* ctx, const feddat_vilt_layer_weights* W, const feddat_vilt_layer_acts* A,
                                      int nb, int S, int heads, const uint8_t* key_mask, int ln1_done,
                                      const feddat_adapter_seg* segs, int nseg, const float* next_ln_g,
                                      const float* next_ln_b, hipStream_t stream) {
     FD_CHECK_ARG(ctx && W && A && nb > 0 && S > 0 && heads > 0 && segs);
+    int rc = check_ctx_and_shape(ctx, heads);
+    if (rc != FEDDAT_OK) return rc;
     const int rows = nb * S, H = heads * 64, I = 4 * H;
     FD_CHECK_ARG(A->h_in && A->qkv && A->ctx && A->lse && A->h2 && A->st2 && A->u && A->h3 && A->h_out && A->x16 && A->f16);
-    int rc;
+    FD_CHECK_ARG(W->wqkv && W->wo && W->w1 && W->w2 && W->bqkv && W->bo && W->b1 && W->b2 && W->ln2_g && W->ln2_b);
+    FD_CHECK_ARG(ln1_done || (A->st1 && W->ln1_g && W->ln1_b));       // LN1 runs here: its weights and statistics buffer
+    FD_CHECK_ARG(!next_ln_g || (next_ln_b && A->st1_next));           // fused next-layer LN: beta and its statistics buffer
 #define FD_TRY(call) do { rc = (call); if (rc != FEDDAT_OK) return rc; } while (0)
     if (!ln1_done)
         FD_TRY(feddat_layernorm_fwd(A->h_in, H, W->ln1_g, W->ln1_b, W->ln_eps, rows, H, A->x16, nullptr, A->st1, stream));
@@ -46,8 +61,11 @@ extern "C" int feddat_vilt_layer_bwd(feddat_ctx* ctx, const feddat_vilt_layer_we
                                      float* wgrad_partials, long wgrad_partials_elems, hipStream_t stream) {
     FD_CHECK_ARG(ctx && W && A && G && nb > 0 && S > 0 && heads > 0 && segs);
     FD_CHECK_ARG(G->dh_out && G->dh_in && G->dh3 && G->dh16 && G->dU && G->dx16 && G->dctx && G->dqkv && G->z && G->dz);
+    int rc = check_ctx_and_shape(ctx, heads);
+    if (rc != FEDDAT_OK) return rc;
+    FD_CHECK_ARG(A->h_in && A->st1 && A->qkv && A->ctx && A->lse && A->h2 && A->st2 && A->u && (A->z_save || A->h3));
+    FD_CHECK_ARG(W->w2T && W->w1T && W->woT && W->wqkvT && W->ln1_g && W->ln2_g);
     const int rows = nb * S, H = heads * 64, I = 4 * H;
-    int rc;
     // adapter: d h3 (fp32 + bf16 copy), z / dz for the weight gradients of the trainable adapter(s)
     FD_TRY(feddat_adapter_bwd(A->z_save ? nullptr : A->h3, A->z_save, G->dh_out, G->dh3, G->dh16, G->z, G->dz, rows, H, 48,
                               segs, nseg, stream));

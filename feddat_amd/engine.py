@@ -659,7 +659,12 @@ class ViltDatEngine:
         self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))
         self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))
         self.head[task].state.copy_(torch.tensor([0, 0], dtype=torch.int32))
-        self.graph = None
+        # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
+        # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
+        sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps)
+        if getattr(self, "_graph_sig", None) != sig:
+            self.graph = None
+            self._graph_sig = sig
 
     def _step_kernels(self):
         B, task = self.B, self.task

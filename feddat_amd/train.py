@@ -170,7 +170,7 @@ class AlbefTaskTrainer(TaskTrainer):
         return 0.0, model
 
     def train_step(self, model, step, batch, optimizer=None, scheduler=None, hooks=None, epoch=None):
-        out = model.engine.train_step(batch)
+        out = model.engine.train_step(batch, use_graph=self.use_graph)
         model.activate_gating()
         model.set_active_adapter("adapter_0")
         return out[0]
@@ -339,7 +339,7 @@ def main(argv=None):
                 dist.barrier()          # every rank's personal files are on disk before round.json appears
             if rank == 0:
                 flags_after = dict(server_flags)
-                if (comm_round % 5 == 0 or comm_round == args.comm_rounds - 1) and not albef:
+                if comm_round % 5 == 0 or comm_round == args.comm_rounds - 1:
                     flags_after.update({0: False, 1: True})         # the eval below leaves the server in this state
                 checkpoint.save_federation(args.output_dir, {n: sd[n] for n in comm_names}, {}, comm_round,
                                            server_flags=flags_after)
@@ -352,6 +352,12 @@ def main(argv=None):
                 scores = TaskTrainer(args, task_key, data[task_key], data[task_key][:2], log).eval(model)
                 server_flags = dict(model.adapter_requires_grad)
                 log.info("round %d %s test score server = %s", comm_round, task_key, scores)
+        elif comm_round % 5 == 0 or comm_round == args.comm_rounds - 1:
+            # ALBEF: the synthetic stand-in has no answer list to rank, so the periodic evaluation is skipped -- but its
+            # side effect on the SERVER model is not: TaskTrainer.eval ends in set_active_adapter('adapter_1')
+            # (task_trainer.py:236-244 -> adapter.py:79-85), so every client optimizer built from the next round on
+            # (create_optimizer filters on requires_grad, task_trainer.py:477-504) no longer holds adapter_0.
+            server_flags.update({0: False, 1: True})
     eng.comm_flat().copy_(server_flat)
     eng.repack_adapter(1)
     if world > 1:

@@ -33,8 +33,18 @@ ALL_SITES = FWD_SITES + BWD_SITES
 ON = set()
 
 
+MANT = int(os.environ.get("ROUND_MANT_BITS", "7"))   # explicit mantissa bits kept: 7 = bf16, 10 = fp16 / tf32, 15 = bf16 hi+lo
+
+
 def bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    """Round to nearest even at MANT explicit mantissa bits (MANT = 7 is exactly the fp32 -> bf16 -> fp32 round trip)."""
+    if MANT == 7:
+        return t.to(torch.bfloat16).to(torch.float32)
+    drop = 23 - MANT
+    xi = t.contiguous().view(torch.int32)
+    xi = xi + ((1 << (drop - 1)) - 1) + ((xi >> drop) & 1)
+    xi = xi & ~((1 << drop) - 1)
+    return xi.view(torch.float32)
 
 
 class _RF(torch.autograd.Function):        # round the VALUE, pass the gradient through
