@@ -146,6 +146,19 @@ __device__ __forceinline__ f32x4 mfma16x64_fp8(bf16x8 a, bf16x8 b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[0], b2[0], c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[1], b2[1], c, 0, 0, 0);
 }
+// CDNA4 block-scaled form, v_mfma_scale_f32_16x16x128_f8f6f4 with both formats e4m3 and unit (E8M0 = 127) block scales:
+// 32 contraction slots per lane and operand = two 16-byte fragment reads, at TWICE the bf16 MFMA rate (the K = 32 fp8
+// instruction above issues at the bf16 rate).  The per-row / per-channel fp32 scales of the quantisers stay on the
+// accumulators.  Slot pairing: A and B take the same (fragment, byte) -> slot map, which is all the contraction needs.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16x128_fp8_mx(bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi, f32x4 c) {
+    const i32x4 a0 = __builtin_bit_cast(i32x4, a_lo), a1 = __builtin_bit_cast(i32x4, a_hi);
+    const i32x4 b0 = __builtin_bit_cast(i32x4, b_lo), b1 = __builtin_bit_cast(i32x4, b_hi);
+    const i32x8 A = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const i32x8 B = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
 __device__ __forceinline__ f32x4 mfma16x4_f32(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -560,7 +560,7 @@ struct V2State {
     int l_tile, l_kt;     // tile index / k-tile of the next staging load
 };
 
-template <int EPI, int WM, bool FP8 = false>
+template <int EPI, int WM, bool FP8 = false, bool FP8_K32 = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     using Cfg = V2Cfg<WM>;
     constexpr int NP = Cfg::NP;
@@ -723,6 +723,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
         // 2 WM groups of 6 MFMAs; after group p (< NP): ds_write of staging piece p, then its global reload
         const int wstage = written & 1;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (FP8 && !FP8_K32) {
+            // CDNA4 form: ONE block-scaled K = 128 instruction per output tile and k-tile (both k-halves' fragments = the 32
+            // bytes per lane it takes) at twice the bf16 rate: WM groups of 6 MFMAs, two staging pieces behind each
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16x128_fp8_mx(fb[0][j], fb[1][j], fa[0][i], fa[1][i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 2 * i; p < 2 * i + 2; ++p)
+                    if (p < NP) {
+                        lwrite_piece(p, wstage);
+                        gload_piece(p);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -737,6 +754,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         __builtin_amdgcn_s_setprio(0);
         ++written;
         stream_advance();
@@ -1108,8 +1126,9 @@ int fd_prepare_gemm_kernels() {
 }
 
 // fp8 (e4m3) operands on the same persistent kernel: byte for byte the data movement of a bf16 product with K / 2
-// "elements" (128 fp8 per 128-byte LDS row); only the MFMA (two K = 32 fp8 instructions per 16-byte fragment) and the
-// dequantising epilogue differ.
+// "elements" (128 fp8 per 128-byte LDS row); only the MFMA -- ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per output
+// tile and k-tile, unit block scales, twice the bf16 rate (debug flag 256: the K = 32 fp8 instruction it replaced, which
+// issues at the bf16 rate) -- and the dequantising epilogue differ.
 extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb,
                                   const float* b_scale, int M, int N, int K, int epi, const float* bias, void* out_bf16,
                                   int ldo16, void* out2_bf16, int ldo2, hipStream_t stream) {
@@ -1123,7 +1142,7 @@ extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale,
     g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.bias = bias; g.sa = a_scale; g.sw = b_scale;
     g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
-    a2.dbg = 0;
+    a2.dbg = fd_debug_flags() & 8;       // tools/ ablation: 8 = skip the epilogue (k-loop timing)
     int n_cu = 0;
     if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     const int tiles_n = N / V2_BN;
@@ -1147,7 +1166,10 @@ extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale,
     a2 = wm4 ? a4 : a3;
     using KernelFn = void (*)(GemmArgsV2);
     KernelFn kern;
-    if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true>;
+    if (fd_debug_flags() & 256) {      // tools/ A/B only: the CDNA3-style K = 32 fp8 instruction (bf16 issue rate)
+        if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, true>;
+        else kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true, true>;
+    } else if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true>;
     else kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true>;
     const int lds_bytes = wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS;
     if (fd_set_max_lds((const void*)kern, lds_bytes) != FEDDAT_OK) return FEDDAT_ELAUNCH;
