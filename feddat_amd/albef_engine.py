@@ -12,6 +12,16 @@ Step algebra: only adapter tensors are trainable (main.py:138-159: the LM head `
 no-grad gated pass P0 and the gated pass P2 of one train_step are the same computation (P1 updates adapter_1 only, the
 gated passes read adapter_0 / adapter_2) -> the gated forward runs ONCE; its logits serve as the teacher of P1 and as the
 student of P2.  Nothing trainable lies below the first ViT block's adapter, so the backward stops there.
+
+Dropout.  The reference trains under model.train() (task_trainer.py:75) with hidden_dropout_prob =
+attention_probs_dropout_prob = 0.1 (src/configs/model_configs.py:44-46) in the two BERT towers -- after the embedding
+LayerNorm (xbert.py:216), on the attention probabilities (:333), on BertSelfOutput's dense output (:360) and on BertOutput's
+dense output ahead of the adapter (:440); the ViT has none (vit.py:120).  `dropout=p` reproduces that with counter-based
+masks (seed, train step, pass, site, element -> bit; include/feddat_hip.h) that the backward regenerates.  With p > 0 the P0
+and P2 forwards draw DIFFERENT masks (three independent forwards in the reference), so the "gated forward once" identity
+only holds for the image encoder: the text towers then run three times (P0 no-grad, P1, P2).  dropout=0 (the default) is
+the deterministic configuration every parity fixture except g12 is captured in; feddat_amd.train.main passes the
+reference's 0.1 (--albef_dropout).
 """
 from __future__ import annotations
 
@@ -31,8 +41,11 @@ class AlbefDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], device, batch: int, n_answers: int, q_len: int = 25, a_len: int = 4,
                  vit_depth: int = 12, enc_layers: int = 12, fusion_layer: int = 6, dec_layers: int = 6, image: int = 384,
                  vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0,
-                 max_pos: int = 512):
+                 max_pos: int = 512, dropout: float = 0.0, seed: int = 0):
         L.load()
+        if not 0.0 <= dropout < 1.0:
+            raise L.FeddatHipError("dropout must be in [0, 1)")
+        self.dropout, self.seed = float(dropout), int(seed)
         self.dev = dev = torch.device(device)
         self.B, self.N, self.Lq, self.La = batch, n_answers, q_len, a_len
         self.vd, self.el, self.fl, self.dl = vit_depth, enc_layers, fusion_layer, dec_layers
@@ -133,7 +146,10 @@ class AlbefDatEngine:
         self._segs_cache: Dict = {}
         self.wpart = {m: torch.empty(L.adapter_wgrad_workspace_elems(1), device=dev) for m in ("gating", "adapter_1")}
         self.side = None           # second stream of train_step (created lazily on the engine's device)
+        self.drop_ctr = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] = train_steps since begin_local_update
         self._alloc()
+        if self.dropout > 0:       # teacher logits of P0: the gated text pass is re-run (other masks) for P2
+            self.logits_all = torch.empty(self.R, self.Vp, device=dev)
 
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self):
@@ -179,7 +195,8 @@ class AlbefDatEngine:
                     d.update(qc=b16(M, H), kvc=b16(kv_rows, 2 * H), ctx2=b16(M, H), lse2=f32(nb, self.heads, Sq),
                              t2=f32(M, H), st_c=f32(M, 2), c=f32(M, H), c16=b16(M, H))
                 return d
-            return dict(h=f32(M, H), h16=b16(M, H), f16=b16(M, I), tA=f32(M, H), layers=[layer(i) for i in range(layers)])
+            return dict(h=f32(M, H), h16=b16(M, H), f16=b16(M, I), tA=f32(M, H), td=f32(M, H),
+                        layers=[layer(i) for i in range(layers)])
 
         def act_set():
             return dict(vit=vit_set(), enc=bert_set(self.Mq, B, Lq, self.el, self.fl, self.Mi),
@@ -236,6 +253,20 @@ class AlbefDatEngine:
     def copy_global_to_teacher(self):
         self.ad[2].p.copy_(self.ad[1].p)
         self.repack_adapter(2)
+
+    _KINDS = {"emb": 0, "self_probs": 1, "self_out": 2, "cross_probs": 3, "cross_out": 4, "out": 5}
+
+    def _drop(self, pass_id, tower: int, layer: int, kind: str):
+        """(p, key0, key1, step counter) of one dropout site of pass `pass_id` (0 / 1 / 2 = P0 / P1 / P2), or None when the
+        pass runs without dropout (pass_id None: eval / plain forwards, or dropout = 0).  Site numbering as the oracle's
+        (tower 0 = text encoder, 1 = decoder)."""
+        if pass_id is None or self.dropout <= 0:
+            return None
+        key = (pass_id, tower, layer, kind)
+        if key not in self._segs_cache:
+            k0, k1 = L.dropout_keys(self.seed, pass_id, (tower * 64 + layer) * 8 + self._KINDS[kind])
+            self._segs_cache[key] = (self.dropout, k0, k1, self.drop_ctr)
+        return self._segs_cache[key]
 
     # ------------------------------------------------------------------------------------------ inputs
     def set_batch(self, batch: Dict):
@@ -303,38 +334,52 @@ class AlbefDatEngine:
                              z_save=A["zs"])
             h = nxt
 
-    def _embed(self, T, ids, tts, nb, Lt, out_f32, out_b16):
+    def _embed(self, T, ids, tts, nb, Lt, out_f32, out_b16, drop=None):
         L.text_embed(ids, tts, T["word"], T["pos"], T["typ"], T["lng"], T["lnb"], 1e-12, self.zero_h, out_f32, nb, Lt, Lt,
                      self.H)
-        L.cvt_f32_bf16(out_f32, out_b16)
+        if drop is not None:                 # embeddings = self.dropout(LayerNorm(...))   xbert.py:216
+            L.dropout(out_f32, drop, out_f32=out_f32, out_bf16=out_b16)
+        else:
+            L.cvt_f32_bf16(out_f32, out_b16)
 
-    def _attn_out(self, W, ctx, resid, M, t_out, st, y, y16):
-        """BertSelfOutput: LN(dense(ctx) + input) (xbert.py BertSelfOutput)."""
-        L.gemm_bf16_nt(ctx, W["o"]["w"], L.EPI_RESID_F32, bias=W["o"]["b"], resid=resid, out_f32=t_out)
+    def _dense_resid(self, x16, lin, resid, out, tmp, drop):
+        """out = dropout(x W^T + b) + resid: one GEMM with the residual epilogue, or -- with dropout between the dense
+        layer and the residual add (xbert.py:360,440) -- the plain product followed by the fused mask + add."""
+        if drop is None:
+            L.gemm_bf16_nt(x16, lin["w"], L.EPI_RESID_F32, bias=lin["b"], resid=resid, out_f32=out)
+        else:
+            L.gemm_bf16_nt(x16, lin["w"], L.EPI_F32, bias=lin["b"], out_f32=tmp)
+            L.dropout(tmp, drop, resid=resid, out_f32=out)
+
+    def _attn_out(self, W, ctx, resid, M, t_out, st, y, y16, tmp=None, drop=None):
+        """BertSelfOutput: LN(dropout(dense(ctx)) + input) (xbert.py:356-362)."""
+        self._dense_resid(ctx, W["o"], resid, t_out, tmp, drop)
         L.layernorm_fwd(t_out, W["lng"], W["lnb"], 1e-12, M, self.H, y_bf16=y16, y_f32=y, stats=st)
 
-    def _bert_fwd(self, T, S, m0: int, mode: str, M, nb, Sq, self_mask, causal, enc16, enc_rows, Skv, enc_mask):
+    def _bert_fwd(self, T, S, m0: int, mode: str, M, nb, Sq, self_mask, causal, enc16, enc_rows, Skv, enc_mask,
+                  pass_id=None, tower: int = 0):
         H = self.H
         h, h16 = S["h"], S["h16"]
         for i, W in enumerate(T["layers"]):
             A = S["layers"][i]
+            dk = lambda kind: self._drop(pass_id, tower, i, kind)      # noqa: E731
             L.gemm_bf16_nt(h16, W["att"]["qkv"]["w"], L.EPI_BF16, bias=W["att"]["qkv"]["b"], out_bf16=A["qkv"])
             L.attn2_fwd(A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:], A["ctx"], A["lse"], nb, Sq, Sq,
-                        self.heads, key_mask=self_mask, causal=causal)
-            self._attn_out(W["att"], A["ctx"], h, M, A["t1"], A["st_a"], A["a"], A["a16"])
+                        self.heads, key_mask=self_mask, causal=causal, drop=dk("self_probs"))
+            self._attn_out(W["att"], A["ctx"], h, M, A["t1"], A["st_a"], A["a"], A["a16"], S["td"], dk("self_out"))
             c, c16 = A["a"], A["a16"]
             if W["cross"] is not None:
                 Wc = W["cross"]
                 L.gemm_bf16_nt(A["a16"], Wc["q"]["w"], L.EPI_BF16, bias=Wc["q"]["b"], out_bf16=A["qc"])
                 L.gemm_bf16_nt(enc16, Wc["kv"]["w"], L.EPI_BF16, bias=Wc["kv"]["b"], out_bf16=A["kvc"])
                 L.attn2_fwd(A["qc"], A["kvc"][:, :H], A["kvc"][:, H:], A["ctx2"], A["lse2"], nb, Sq, Skv, self.heads,
-                            key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows)
-                self._attn_out(Wc, A["ctx2"], A["a"], M, A["t2"], A["st_c"], A["c"], A["c16"])
+                            key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows, drop=dk("cross_probs"))
+                self._attn_out(Wc, A["ctx2"], A["a"], M, A["t2"], A["st_c"], A["c"], A["c16"], S["td"], dk("cross_out"))
                 c, c16 = A["c"], A["c16"]
             L.gemm_bf16_nt(c16, W["fc1"]["w"], L.EPI_GELU, bias=W["fc1"]["b"], out_bf16=S["f16"], out2_bf16=A["u"])
-            # BertOutput with the adapter (xbert.py:438-445 -> adapter.py:97-116): s1 = dense + inp; x = LN(s1);
+            # BertOutput with the adapter (xbert.py:438-445 -> adapter.py:97-116): s1 = dropout(dense) + inp; x = LN(s1);
             # y + inp = s1 + (x + A(x)) - x; out = LN(y + inp), same LayerNorm twice
-            L.gemm_bf16_nt(S["f16"], W["fc2"]["w"], L.EPI_RESID_F32, bias=W["fc2"]["b"], resid=c, out_f32=A["s1"])
+            self._dense_resid(S["f16"], W["fc2"], c, A["s1"], S["td"], dk("out"))
             L.layernorm_fwd(A["s1"], W["lng"], W["lnb"], 1e-12, M, H, y_f32=A["x"], stats=A["st_x"])
             L.adapter_fwd(A["x"], S["tA"], self._segs(m0 + i, mode, M, False), M, z_save=A["zs"])
             L.axpby3(A["s1"], 1.0, S["tA"], 1.0, A["x"], -1.0, out_f32=A["s2"])
@@ -342,24 +387,27 @@ class AlbefDatEngine:
             h, h16 = A["out"], A["out16"]
         return h, h16
 
-    def _forward(self, mode: str):
-        """ALBEF.forward(train=True) up to logits[:, :-1] (albef_model.py:69-145), activations kept in self.acts[mode]."""
+    def _forward(self, mode: str, pass_id=None):
+        """ALBEF.forward(train=True) up to logits[:, :-1] (albef_model.py:69-145), activations kept in self.acts[mode].
+        pass_id (0 / 1 / 2): the train_step pass whose dropout masks apply; None = no dropout."""
         self._vit_fwd(self.acts[mode], mode)
-        return self._forward_text(mode)
+        return self._forward_text(mode, pass_id)
 
-    def _forward_text(self, mode: str):
+    def _forward_text(self, mode: str, pass_id=None):
         """Everything behind the image encoder: text encoder with cross-attention, answer decoder, LM head."""
         S = self.acts[mode]
         B, N, Lq, La, H = self.B, self.N, self.Lq, self.La, self.H
         E, D = S["enc"], S["dec"]
-        self._embed(self.enc, self.inp["question_ids"], self.zero_tt_q, B, Lq, E["h"], E["h16"])
+        self._embed(self.enc, self.inp["question_ids"], self.zero_tt_q, B, Lq, E["h"], E["h16"],
+                    self._drop(pass_id, 0, 0, "emb"))
         qs, _ = self._bert_fwd(self.enc, E, self.vd, mode, self.Mq, B, Lq, self.qmask8, False, S["vit"]["emb16"], self.Ni,
-                               self.Ni, None)
+                               self.Ni, None, pass_id, 0)
         # one question's states for each of its k answers (albef_model.py:93-98)
         L.gather_rows(qs, self.rep_idx, dst_bf16=S["enc_rep16"])
-        self._embed(self.dec, self.inp["answer_ids"], self.zero_tt_a, N, La, D["h"], D["h16"])
+        self._embed(self.dec, self.inp["answer_ids"], self.zero_tt_a, N, La, D["h"], D["h16"],
+                    self._drop(pass_id, 1, 0, "emb"))
         out, _ = self._bert_fwd(self.dec, D, self.vd + self.el, mode, self.Ma, N, La, self.amask8, True, S["enc_rep16"], Lq,
-                                Lq, self.qmask8_rep)
+                                Lq, self.qmask8_rep, pass_id, 1)
         # BertOnlyMLMHead on the positions that predict a next token (logits[:, :-1])
         hd = self.head
         L.gather_rows(out, self.sel_idx, dst_f32=S["hsel"], dst_bf16=S["hsel16"])
@@ -371,43 +419,55 @@ class AlbefDatEngine:
 
     # ------------------------------------------------------------------------------------------ backward
     def _bert_bwd(self, T, S, m0: int, mode: str, M, nb, Sq, self_mask, causal, enc16, enc_rows, Skv, enc_mask, d_out,
-                  d_enc):
+                  d_enc, pass_id=None, tower: int = 0):
         """d_out: fp32 [M,768] gradient of the tower's output (consumed); d_enc: fp32 accumulator for the encoder-side
         states (zeroed by the caller); returns the gradient wrt the tower's embedding output (unused: embeddings frozen)."""
         H, g = self.H, self.gs[mode]
         for i in range(len(T["layers"]) - 1, -1, -1):
             W, A = T["layers"][i], S["layers"][i]
+            dk = lambda kind: self._drop(pass_id, tower, i, kind)      # noqa: E731
+
+            def ln_bwd_to_operand(x, st, gam, dy, dres, out, kind):
+                """LayerNorm backward whose fp32 result also becomes the bf16 dY operand of the dense layer ahead of it --
+                through that layer's dropout mask when the pass has one (d dense = mask / (1 - p) . d out)."""
+                d = dk(kind)
+                if d is None:
+                    L.layernorm_bwd_dx(x, st, gam, M, H, dy_f32=dy, dres=dres, out_f32=out, out_bf16=g["b1"][:M])
+                else:
+                    L.layernorm_bwd_dx(x, st, gam, M, H, dy_f32=dy, dres=dres, out_f32=out)
+                    L.dropout(out, d, out_bf16=g["b1"][:M])
             ds2, dxf, dx, ds1 = g["d1"][:M], g["d2"][:M], g["d3"][:M], g["d4"][:M]
             L.layernorm_bwd_dx(A["s2"], A["st_o"], W["lng"], M, H, dy_f32=d_out, out_f32=ds2)
             L.adapter_bwd(None, ds2, dxf, self._segs(m0 + i, mode, M, True), M, z_out=g["z"], dz_out=g["dz"],
                           z_saved=A["zs"])
             self._wgrad(m0 + i, mode, A["x"], ds2, M)
             L.axpby3(dxf, 1.0, ds2, -1.0, out_f32=dx)                      # d x = Wd^T dz (the adapter's residual is r, not x)
-            L.layernorm_bwd_dx(A["s1"], A["st_x"], W["lng"], M, H, dy_f32=dx, dres=ds2, out_f32=ds1, out_bf16=g["b1"][:M])
+            ln_bwd_to_operand(A["s1"], A["st_x"], W["lng"], dx, ds2, ds1, "out")
             L.gemm_bf16_nt(g["b1"][:M], W["fc2"]["wT"], L.EPI_MUL_DGELU, aux=A["u"], out_bf16=g["bI"][:M])
             dc = d_out                                                      # reuse: d_out is dead
             L.gemm_bf16_nt(g["bI"][:M], W["fc1"]["wT"], L.EPI_RESID_F32, resid=ds1, out_f32=dc)
             if W["cross"] is not None:
                 Wc = W["cross"]
                 dt2 = ds2
-                L.layernorm_bwd_dx(A["t2"], A["st_c"], Wc["lng"], M, H, dy_f32=dc, out_f32=dt2, out_bf16=g["b1"][:M])
+                ln_bwd_to_operand(A["t2"], A["st_c"], Wc["lng"], dc, None, dt2, "cross_out")
                 L.gemm_bf16_nt(g["b1"][:M], Wc["o"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:M])
                 kv_rows = A["kvc"].shape[0]
                 dq, dkv = g["b1"][:M], g["bkv"][:kv_rows]
                 L.attn2_bwd(A["qc"], A["kvc"][:, :H], A["kvc"][:, H:], A["ctx2"], A["lse2"], g["b2"][:M], g["dsum"], dq,
-                            dkv[:, :H], dkv[:, H:], nb, Sq, Skv, self.heads, key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows)
+                            dkv[:, :H], dkv[:, H:], nb, Sq, Skv, self.heads, key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows,
+                            drop=dk("cross_probs"))
                 da = dc
                 L.gemm_bf16_nt(dq, Wc["q"]["wT"], L.EPI_RESID_F32, resid=dt2, out_f32=da)
                 L.gemm_bf16_nt(dkv, Wc["kv"]["wT"], L.EPI_RESID_F32, resid=d_enc, out_f32=d_enc)
             else:
                 da = dc
             dt1 = ds2
-            L.layernorm_bwd_dx(A["t1"], A["st_a"], W["att"]["lng"], M, H, dy_f32=da, out_f32=dt1, out_bf16=g["b1"][:M])
+            ln_bwd_to_operand(A["t1"], A["st_a"], W["att"]["lng"], da, None, dt1, "self_out")
             L.gemm_bf16_nt(g["b1"][:M], W["att"]["o"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:M])
             dqkv = g["b3"][:M]
             L.attn2_bwd(A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:], A["ctx"], A["lse"], g["b2"][:M],
                         g["dsum"], dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], nb, Sq, Sq, self.heads, key_mask=self_mask,
-                        causal=causal)
+                        causal=causal, drop=dk("self_probs"))
             L.gemm_bf16_nt(dqkv, W["att"]["qkv"]["wT"], L.EPI_RESID_F32, resid=dt1, out_f32=d_out)
         return d_out
 
@@ -439,12 +499,12 @@ class AlbefDatEngine:
             L.layernorm_bwd_dx(A["h_in"], A["st1"], W["n1g"], Mi, H, dy_bf16=g["b2"][:Mi], dres=cur, out_f32=oth)
             cur, oth = oth, cur
 
-    def _backward(self, mode: str, teacher_logits):
+    def _backward(self, mode: str, teacher_logits, pass_id=None):
         """L = (loss + kl) / 2 of the pass `mode` (task_trainer.py:300-302 / 320-323) -> gradients of its trainable adapter."""
-        self._backward_text(mode, teacher_logits)
+        self._backward_text(mode, teacher_logits, pass_id)
         self._vit_bwd(self.acts[mode], mode, self.gs[mode]["d_img"])
 
-    def _backward_text(self, mode: str, teacher_logits):
+    def _backward_text(self, mode: str, teacher_logits, pass_id=None):
         """Loss, LM head, decoder and text encoder backward of the pass `mode`; leaves d(image_embeds) in its scratch set."""
         S, g, hd, H = self.acts[mode], self.gs[mode], self.head, self.H
         L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
@@ -459,12 +519,12 @@ class AlbefDatEngine:
         L.gather_rows(g["d1"][:R], self.unsel_idx, dst_f32=g["d_dec"])          # zero rows at the last position of each answer
         g["d_rep"].zero_()
         self._bert_bwd(self.dec, S["dec"], self.vd + self.el, mode, self.Ma, self.N, self.La, self.amask8, True,
-                       S["enc_rep16"], self.Lq, self.Lq, self.qmask8_rep, g["d_dec"], g["d_rep"])
+                       S["enc_rep16"], self.Lq, self.Lq, self.qmask8_rep, g["d_dec"], g["d_rep"], pass_id, 1)
         # question states were repeated per answer: sum the answers of each question back (rows = [N, Lq * H])
         L.segment_sum_rows(g["d_rep"].view(self.N, self.Lq * H), self.seg_off, g["d_qs"].view(self.B, self.Lq * H))
         g["d_img"].zero_()
         self._bert_bwd(self.enc, S["enc"], self.vd, mode, self.Mq, self.B, self.Lq, self.qmask8, False, S["vit"]["emb16"],
-                       self.Ni, self.Ni, None, g["d_qs"], g["d_img"])
+                       self.Ni, self.Ni, None, g["d_qs"], g["d_img"], pass_id, 0)
 
     # ------------------------------------------------------------------------------------------ train step
     def begin_local_update(self, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,
@@ -480,6 +540,7 @@ class AlbefDatEngine:
             grp.g.zero_()
         self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))       # adapter_1 is stepped at tick 2b
         self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))       # adapter_0 at tick 2b + 1
+        self.drop_ctr.zero_()
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps)
@@ -503,19 +564,28 @@ class AlbefDatEngine:
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.dev)
         side = self.side
+        drop = self.dropout > 0
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            logits_g = self._forward("gating")               # P0 == P2 forward (task_trainer.py:283-287,311-315)
-        logits_1 = self._forward("adapter_1")                # P1 (task_trainer.py:290-295)
+            if drop:
+                # P0 (task_trainer.py:283-287): no-grad gated forward under its own masks.  The image encoder has no dropout,
+                # so its gated forward is shared with P2; the text towers run again for P2 below (other masks).
+                self._vit_fwd(self.acts["gating"], "gating")
+                self.logits_all.copy_(self._forward_text("gating", 0))
+                logits_teacher = self.logits_all
+            else:
+                logits_teacher = self._forward("gating")     # P0 == P2 forward (task_trainer.py:283-287,311-315)
+        logits_1 = self._forward("adapter_1", 1 if drop else None)       # P1 (task_trainer.py:290-295)
         cur.wait_stream(side)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            logits_g = self._forward_text("gating", 2) if drop else logits_teacher
             if 0 in self.opt_adapters:
-                self._backward("gating", logits_1)           # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
+                self._backward("gating", logits_1, 2 if drop else None)   # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
             else:        # adapter_0 left the optimizer (server flags after the first eval): only the loss values are needed
                 L.lm_loss_fwd_bwd(logits_g, logits_1, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, None,
                                   self.acts["gating"]["loss"])
-        self._backward("adapter_1", logits_g)                # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
+        self._backward("adapter_1", logits_teacher, 1 if drop else None)  # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
         cur.wait_stream(side)
         if 1 in self.opt_adapters:
             self._adamw(self.ad[1])
@@ -525,6 +595,8 @@ class AlbefDatEngine:
             self._adamw(self.ad[0])
             self.repack_adapter(0)
         L.step_tick(self.ad[0].state, 2, 1)
+        if drop:
+            L.step_tick(self.drop_ctr, 1, 0)                 # the next train_step draws fresh masks (also under graph replay)
 
     def train_step(self, batch: Optional[Dict] = None, use_graph: bool = False):
         """One DAT + MKD step; returns the device buffer {loss_0, kl_0, L_0} of the P2 pass (the reference returns loss_0).
@@ -545,6 +617,7 @@ class AlbefDatEngine:
         optimizer state is saved / restored around the warm-up + capture run so that capturing does not advance training."""
         groups = [self.ad[0], self.ad[1]]
         saved = [(g.p.clone(), g.m.clone(), g.v.clone(), g.state.clone()) for g in groups]
+        saved_ctr = self.drop_ctr.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -560,6 +633,7 @@ class AlbefDatEngine:
             g.m.copy_(m)
             g.v.copy_(v)
             g.state.copy_(st)
+        self.drop_ctr.copy_(saved_ctr)
         for a in (0, 1):
             self.repack_adapter(a)
         torch.cuda.synchronize()

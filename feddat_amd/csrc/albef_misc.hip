@@ -16,6 +16,29 @@ __global__ __launch_bounds__(256) void axpby3_kernel(const float* __restrict__ a
     if (out16) reinterpret_cast<bf16x4*>(out16)[i] = cvt4(v);
 }
 
+// out = keep(idx) ? x * 1/(1-p) : 0  (+ resid): nn.Dropout in train mode on a [rows, cols] tensor (BertEmbeddings
+// xbert.py:216, BertSelfOutput :360, BertOutput :440 -- there followed by the residual add of the fused forms), and the same
+// mask applied to a gradient in the backward.  Input fp32 or bf16, outputs fp32 and / or bf16.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x32, const bf16* __restrict__ x16,
+                                                      const float* __restrict__ resid, float* __restrict__ out,
+                                                      bf16* __restrict__ out16, long n4, float p, uint32_t key0,
+                                                      uint32_t key1, const int* __restrict__ step) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const FdDrop d = fd_drop_make(p, key0, key1, step);
+    f32x4 v;
+    if (x32) v = reinterpret_cast<const f32x4*>(x32)[i];
+    else {
+        const bf16x4 h = reinterpret_cast<const bf16x4*>(x16)[i];
+        v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fd_drop_keep(d, (uint32_t)(4 * i + e)) ? v[e] * d.scale : 0.f;
+    if (resid) v = v + reinterpret_cast<const f32x4*>(resid)[i];
+    if (out) reinterpret_cast<f32x4*>(out)[i] = v;
+    if (out16) reinterpret_cast<bf16x4*>(out16)[i] = cvt4(v);
+}
+
 // dst[r] = src[idx[r]] (fp32 rows of `width` floats, width % 4 == 0; idx < 0 -> a zero row), optional bf16 copy
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
                                                           float* __restrict__ dst, bf16* __restrict__ dst16, int width) {
@@ -144,6 +167,15 @@ extern "C" int feddat_axpby3(const float* a, float alpha, const float* b, float 
     const long n4 = n / 4;
     hipLaunchKernelGGL(axpby3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a, alpha, b, beta, c,
                        gamma, out_f32, (bf16*)out_bf16, n4);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_dropout(const float* x_f32, const void* x_bf16, const float* resid, float* out_f32, void* out_bf16,
+                              long n, float p, unsigned key0, unsigned key1, const int* step_ctr, hipStream_t stream) {
+    FD_CHECK_ARG((x_f32 != nullptr) != (x_bf16 != nullptr) && (out_f32 || out_bf16) && n > 0 && n % 4 == 0);
+    FD_CHECK_ARG(p >= 0.f && p < 1.f && n < (1L << 32));
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, x_f32,
+                       (const bf16*)x_bf16, resid, out_f32, (bf16*)out_bf16, n / 4, p, key0, key1, step_ctr);
     FD_LAUNCH_RET();
 }
 

@@ -99,13 +99,16 @@ struct Attn2Args {
     const bf16* dout;  long lddo;
     float* dsum;                 // [B, heads, Sq]: rowsum(dO * O), written by the dQ kernel, read by the dK/dV kernel
     bf16 *dq, *dk, *dv;  long lddq, lddk, lddv;
+    // dropout on the attention probabilities (BertSelfAttention, xbert.py:333): element ((b * heads + h) * Sq + q) * Skv + key
+    // of the [B, heads, Sq, Skv] probability tensor is kept iff fd_drop_keep says so; p = 0: off (the DROP = false kernels)
+    float drop_p;  uint32_t dkey0, dkey1;  const int* dstep;
 };
 
 // All three kernels are templated on QT = 16-row tiles per wave on the block's own side (block = 64 QT rows): every
 // fragment of the streamed side read from LDS feeds QT MFMAs.  With QT = 1 a chunk costs the CU's one LDS pipe ~2x the
 // cycles its four MFMA pipes need (4 waves x (8 ds_read_b128 + 16 ds_read_b64_tr) against 16 MFMAs per wave); QT = 2 is
 // used for long sequences (577 image tokens), QT = 1 for the <= 64-row text streams.
-template <int QT, bool CAUSAL>
+template <int QT, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
     constexpr int QB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
     const int kend = CAUSAL ? min(a.Skv, q0 + QB) : a.Skv;
+    const FdDrop drop = DROP ? fd_drop_make(a.drop_p, a.dkey0, a.dkey1, a.dstep) : FdDrop{};
     bf16x8 kpre[2], vpre[2];
     chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
     chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
@@ -204,6 +208,14 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
             csum += __shfl_xor(csum, 16, 64);
             csum += __shfl_xor(csum, 32, 64);
             l[t] += csum;
+            if (DROP) {      // softmax normalises over ALL keys (l above); the dropped, rescaled probabilities meet V
+                const uint32_t base = (uint32_t)(((size_t)(b * a.heads + h) * a.Sq + qi[t]) * a.Skv + k0 + 4 * g);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        s[t][kt][e] = fd_drop_keep(drop, base + kt * 16 + e) ? s[t][kt][e] * drop.scale : 0.f;
+            }
             pb[t][0] = cvt8(s[t][0], s[t][1]);
             pb[t][1] = cvt8(s[t][2], s[t][3]);
         }
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
 }
 
 // dQ (and D = rowsum(dO * O)) of one 64 QT-query block: K / V stream through LDS.
-template <int QT, bool CAUSAL>
+template <int QT, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
     constexpr int QB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Gs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
     const bf16* O = a.o + (size_t)b * a.sq_b * a.ldo + h * D;
     const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
     const int kend = CAUSAL ? min(a.Skv, q0 + QB) : a.Skv;
+    const FdDrop drop = DROP ? fd_drop_make(a.drop_p, a.dkey0, a.dkey1, a.dstep) : FdDrop{};
     bf16x8 kpre[2], vpre[2];
     chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
     chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
@@ -319,7 +332,11 @@ __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
                     for (int e = 0; e < 4; ++e) {
                         float pe = kv4[e] * __builtin_amdgcn_exp2f(sc[e] * SC - lq[t]);
                         if (CAUSAL && k0 + krow + 4 * g + e > qi[t]) pe = 0.f;
-                        ds[t][tt][e] = pe * (dp[e] - dq_[t]);              // the 1/8 of dS is applied at the end
+                        float dpe = dp[e];
+                        if (DROP)      // dP = mask / (1 - p) . (dO V^T); D = rowsum(dO . O) already holds the dropped O
+                            dpe = fd_drop_keep(drop, (uint32_t)(((size_t)(b * a.heads + h) * a.Sq + qi[t]) * a.Skv + k0 + krow +
+                                                                4 * g + e)) ? dpe * drop.scale : 0.f;
+                        ds[t][tt][e] = pe * (dpe - dq_[t]);                // the 1/8 of dS is applied at the end
                     }
                 }
             }
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
 }
 
 // dK, dV of one 64 QT-key block: Q / dO (and their LSE / D) stream through LDS.
-template <int QT, bool CAUSAL>
+template <int QT, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
     constexpr int KB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Ks[KB * ROWB], Vs[KB * ROWB], Qs[BLK * ROWB], Gs[BLK * ROWB];
@@ -357,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
     const bf16* V = a.v + (size_t)b * a.skv_b * a.ldv + h * D;
     const bf16* G = a.dout + (size_t)b * a.sq_b * a.lddo + h * D;
     const int qstart = CAUSAL ? k0 : 0;                    // queries before the block's first key see none of it
+    const FdDrop drop = DROP ? fd_drop_make(a.drop_p, a.dkey0, a.dkey1, a.dstep) : FdDrop{};
     bf16x8 qpre[2], gpre[2];
     chunk_fetch(Q, a.ldq, qstart, a.Sq, tid, qpre);
     chunk_fetch(G, a.lddo, qstart, a.Sq, tid, gpre);
@@ -418,8 +436,12 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
                     for (int e = 0; e < 4; ++e) {
                         float pe = kv[t] * __builtin_amdgcn_exp2f(sc[e] * SC - l4[e]);
                         if (CAUSAL && key[t] > q0 + qrow + 4 * g + e) pe = 0.f;
-                        p[t][tt][e] = pe;
-                        ds[t][tt][e] = pe * (dp[e] - d4[e]);
+                        float mk = 1.0f;
+                        if (DROP)
+                            mk = fd_drop_keep(drop, (uint32_t)(((size_t)(b * a.heads + h) * a.Sq + q0 + qrow + 4 * g + e) * a.Skv +
+                                                               key[t])) ? drop.scale : 0.f;
+                        p[t][tt][e] = pe * mk;                           // dV = (P . mask / (1 - p))^T dO
+                        ds[t][tt][e] = pe * (dp[e] * mk - d4[e]);
                     }
                 }
             }
@@ -462,25 +484,76 @@ int check(const Attn2Args& a, int B) {
 
 }  // namespace
 
-extern "C" int feddat_attn2_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                                const uint8_t* key_mask, int causal, void* ctx, long ldo, float* lse, int B, int Sq,
-                                int Skv, long q_rows_per_sample, long kv_rows_per_sample, int heads, hipStream_t stream) {
+#define FD_ATTN2_LAUNCH(KERN, QT_, GRID)                                                                              \
+    do {                                                                                                           \
+        if (a.drop_p > 0.f) {                                                                                      \
+            if (a.causal) hipLaunchKernelGGL((KERN<QT_, true, true>), GRID, dim3(256), 0, stream, a);              \
+            else hipLaunchKernelGGL((KERN<QT_, false, true>), GRID, dim3(256), 0, stream, a);                      \
+        } else {                                                                                                   \
+            if (a.causal) hipLaunchKernelGGL((KERN<QT_, true, false>), GRID, dim3(256), 0, stream, a);             \
+            else hipLaunchKernelGGL((KERN<QT_, false, false>), GRID, dim3(256), 0, stream, a);                     \
+        }                                                                                                          \
+    } while (0)
+
+static int attn2_fwd_launch(Attn2Args& a, int B, hipStream_t stream) {
+    const int rc = check(a, B);
+    if (rc) return rc;
+    FD_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (size_t)B * a.heads * a.Sq * a.Skv < (1ull << 32));
+    const dim3 grid2((a.Sq + 2 * BLK - 1) / (2 * BLK), a.heads, B), grid1((a.Sq + BLK - 1) / BLK, a.heads, B);
+    if (a.Sq > BLK) FD_ATTN2_LAUNCH(attn2_fwd_kernel, 2, grid2);
+    else FD_ATTN2_LAUNCH(attn2_fwd_kernel, 1, grid1);
+    FD_LAUNCH_RET();
+}
+
+static int attn2_bwd_launch(Attn2Args& a, int B, hipStream_t stream) {
+    const int rc = check(a, B);
+    if (rc) return rc;
+    FD_CHECK_ARG(a.lse && a.dout && a.dsum && a.dq && a.dk && a.dv && a.lddo % 8 == 0 && a.lddq % 8 == 0 && a.lddk % 8 == 0 &&
+                 a.lddv % 8 == 0);
+    FD_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (size_t)B * a.heads * a.Sq * a.Skv < (1ull << 32));
+    const int Sq = a.Sq, Skv = a.Skv, heads = a.heads;
+    const dim3 gq2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), gk2((Skv + 2 * BLK - 1) / (2 * BLK), heads, B),
+        g1((Sq + BLK - 1) / BLK, heads, B), g1k((Skv + BLK - 1) / BLK, heads, B);
+    if (Sq > BLK) FD_ATTN2_LAUNCH(attn2_bwd_dq_kernel, 2, gq2);
+    else FD_ATTN2_LAUNCH(attn2_bwd_dq_kernel, 1, g1);
+    if (Skv > BLK) FD_ATTN2_LAUNCH(attn2_bwd_dkv_kernel, 2, gk2);
+    else FD_ATTN2_LAUNCH(attn2_bwd_dkv_kernel, 1, g1k);
+    FD_LAUNCH_RET();
+}
+
+static Attn2Args attn2_args(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const uint8_t* key_mask,
+                            int causal, const void* ctx, long ldo, const float* lse, int Sq, int Skv, long q_rows_per_sample,
+                            long kv_rows_per_sample, int heads) {
     Attn2Args a{};
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq_b = q_rows_per_sample; a.skv_b = kv_rows_per_sample;
     a.kmask = key_mask; a.Sq = Sq; a.Skv = Skv; a.heads = heads; a.causal = causal;
-    a.o = (bf16*)ctx; a.ldo = ldo; a.lse = lse;
-    const int rc = check(a, B);
-    if (rc) return rc;
-    const dim3 grid2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), grid1((Sq + BLK - 1) / BLK, heads, B);
-    if (Sq > BLK) {
-        if (causal) hipLaunchKernelGGL((attn2_fwd_kernel<2, true>), grid2, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((attn2_fwd_kernel<2, false>), grid2, dim3(256), 0, stream, a);
-    } else {
-        if (causal) hipLaunchKernelGGL((attn2_fwd_kernel<1, true>), grid1, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((attn2_fwd_kernel<1, false>), grid1, dim3(256), 0, stream, a);
-    }
-    FD_LAUNCH_RET();
+    a.o = (bf16*)const_cast<void*>(ctx); a.ldo = ldo; a.lse = const_cast<float*>(lse);
+    return a;
+}
+
+extern "C" int feddat_attn2_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                const uint8_t* key_mask, int causal, void* ctx, long ldo, float* lse, int B, int Sq,
+                                int Skv, long q_rows_per_sample, long kv_rows_per_sample, int heads, hipStream_t stream) {
+    Attn2Args a = attn2_args(q, ldq, k, ldk, v, ldv, key_mask, causal, ctx, ldo, lse, Sq, Skv, q_rows_per_sample,
+                             kv_rows_per_sample, heads);
+    return attn2_fwd_launch(a, B, stream);
+}
+
+extern "C" int feddat_attn2_fwd_dropout(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                        const uint8_t* key_mask, int causal, void* ctx, long ldo, float* lse, int B, int Sq,
+                                        int Skv, long q_rows_per_sample, long kv_rows_per_sample, int heads, float p,
+                                        unsigned key0, unsigned key1, const int* step_ctr, hipStream_t stream) {
+    Attn2Args a = attn2_args(q, ldq, k, ldk, v, ldv, key_mask, causal, ctx, ldo, lse, Sq, Skv, q_rows_per_sample,
+                             kv_rows_per_sample, heads);
+    a.drop_p = p; a.dkey0 = key0; a.dkey1 = key1; a.dstep = step_ctr;
+    return attn2_fwd_launch(a, B, stream);
+}
+
+static void attn2_bwd_args(Attn2Args& a, const void* dctx, long lddo, float* dsum_ws, void* dq, long lddq, void* dk, long lddk,
+                           void* dv, long lddv) {
+    a.dout = (const bf16*)dctx; a.lddo = lddo; a.dsum = dsum_ws;
+    a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
 }
 
 extern "C" int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
@@ -488,31 +561,21 @@ extern "C" int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk
                                 const void* dctx, long lddo, float* dsum_ws, void* dq, long lddq, void* dk, long lddk,
                                 void* dv, long lddv, int B, int Sq, int Skv, long q_rows_per_sample,
                                 long kv_rows_per_sample, int heads, hipStream_t stream) {
-    Attn2Args a{};
-    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v;
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq_b = q_rows_per_sample; a.skv_b = kv_rows_per_sample;
-    a.kmask = key_mask; a.Sq = Sq; a.Skv = Skv; a.heads = heads; a.causal = causal;
-    a.o = (bf16*)ctx; a.ldo = ldo; a.lse = const_cast<float*>(lse);
-    a.dout = (const bf16*)dctx; a.lddo = lddo; a.dsum = dsum_ws;
-    a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-    const int rc = check(a, B);
-    if (rc) return rc;
-    FD_CHECK_ARG(lse && dctx && dsum_ws && dq && dk && dv && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0);
-    const dim3 gq2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), gk2((Skv + 2 * BLK - 1) / (2 * BLK), heads, B),
-        g1((Sq + BLK - 1) / BLK, heads, B), g1k((Skv + BLK - 1) / BLK, heads, B);
-    if (Sq > BLK) {
-        if (causal) hipLaunchKernelGGL((attn2_bwd_dq_kernel<2, true>), gq2, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((attn2_bwd_dq_kernel<2, false>), gq2, dim3(256), 0, stream, a);
-    } else {
-        if (causal) hipLaunchKernelGGL((attn2_bwd_dq_kernel<1, true>), g1, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((attn2_bwd_dq_kernel<1, false>), g1, dim3(256), 0, stream, a);
-    }
-    if (Skv > BLK) {
-        if (causal) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<2, true>), gk2, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<2, false>), gk2, dim3(256), 0, stream, a);
-    } else {
-        if (causal) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<1, true>), g1k, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<1, false>), g1k, dim3(256), 0, stream, a);
-    }
-    FD_LAUNCH_RET();
+    Attn2Args a = attn2_args(q, ldq, k, ldk, v, ldv, key_mask, causal, ctx, ldo, lse, Sq, Skv, q_rows_per_sample,
+                             kv_rows_per_sample, heads);
+    attn2_bwd_args(a, dctx, lddo, dsum_ws, dq, lddq, dk, lddk, dv, lddv);
+    return attn2_bwd_launch(a, B, stream);
+}
+
+extern "C" int feddat_attn2_bwd_dropout(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                        const uint8_t* key_mask, int causal, const void* ctx, long ldo, const float* lse,
+                                        const void* dctx, long lddo, float* dsum_ws, void* dq, long lddq, void* dk, long lddk,
+                                        void* dv, long lddv, int B, int Sq, int Skv, long q_rows_per_sample,
+                                        long kv_rows_per_sample, int heads, float p, unsigned key0, unsigned key1,
+                                        const int* step_ctr, hipStream_t stream) {
+    Attn2Args a = attn2_args(q, ldq, k, ldk, v, ldv, key_mask, causal, ctx, ldo, lse, Sq, Skv, q_rows_per_sample,
+                             kv_rows_per_sample, heads);
+    attn2_bwd_args(a, dctx, lddo, dsum_ws, dq, lddq, dk, lddk, dv, lddv);
+    a.drop_p = p; a.dkey0 = key0; a.dkey1 = key1; a.dstep = step_ctr;
+    return attn2_bwd_launch(a, B, stream);
 }

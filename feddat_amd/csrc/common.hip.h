@@ -54,6 +54,31 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Counter-based dropout mask (ALBEF BERT towers, xbert.py:216,333,360,440): element `idx` of the tensor a site drops is
+// KEPT iff hash(idx; key0, key1, step) >= p * 2^32 -- two murmur3 finalisers with the keys injected; (key0, key1) name
+// (seed, pass, site), `step` is the train-step counter read from device memory so that a captured hipGraph draws fresh masks
+// on every replay.  The backward REGENERATES the mask, nothing is stored.  The oracle restates this function
+// (oracle/albef_oracle.py dropout_keep) -- same bits on both sides.
+__device__ __forceinline__ uint32_t fd_fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+struct FdDrop {
+    uint32_t key0, key1s, thr;      // key1s = key1 + step * 0x632BE5AB (folded once per kernel)
+    float scale;                    // 1 / (1 - p)
+};
+__device__ __forceinline__ FdDrop fd_drop_make(float p, uint32_t key0, uint32_t key1, const int* step) {
+    FdDrop d;
+    d.key0 = key0;
+    d.key1s = key1 + (step ? (uint32_t)*step : 0u) * 0x632BE5ABu;
+    d.thr = (uint32_t)((double)p * 4294967296.0);
+    d.scale = 1.0f / (1.0f - p);
+    return d;
+}
+__device__ __forceinline__ bool fd_drop_keep(const FdDrop& d, uint32_t idx) {
+    return fd_fmix32(fd_fmix32(idx * 0x9E3779B1u + d.key0) + d.key1s) >= d.thr;
+}
+
 // erf-GELU and its derivative: HF ACT2FN["gelu"] / nn.GELU() (vilt.py:206).
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| < 1.5e-7, far below the bf16 output rounding of the GEMM epilogues it
 // is fused into, and 2.5x fewer VALU ops than erff -- the GELU epilogue was ~30 % of the FFN1 GEMM's time).

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_PKG, "libfeddat_hip.so")
 
 EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32 = 0, 1, 2, 3, 4
 
-vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 
 
 class AdapterSeg(C.Structure):
@@ -75,6 +75,11 @@ _SIGS = {
     "feddat_attn2_fwd": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, i32, i32, i32, i64, i64, i32, vp],
     "feddat_attn2_bwd": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32,
                          i32, i64, i64, i32, vp],
+    "feddat_attn2_fwd_dropout": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, i32, i32, i32, i64, i64, i32, f32, u32, u32,
+                                 vp, vp],
+    "feddat_attn2_bwd_dropout": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64,
+                                 i32, i32, i32, i64, i64, i32, f32, u32, u32, vp, vp],
+    "feddat_dropout": [vp, vp, vp, vp, vp, i64, f32, u32, u32, vp, vp],
     "feddat_layernorm_fwd": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp],
     "feddat_layernorm_bwd_dx": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp],
     "feddat_layernorm_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
@@ -293,17 +298,31 @@ def attn_bwd(qkv, ctx, lse, dctx, dqkv, B, S, heads, key_mask=None):
          "feddat_attn_bwd")
 
 
-def attn2_fwd(q, k, v, ctx, lse, B, Sq, Skv, heads, *, key_mask=None, causal=False, q_rows=None, kv_rows=None):
-    """General attention: q [B*q_rows, >=heads*64] / k, v [B*kv_rows, ...] bf16 2-D views (row strides from the tensors)."""
+def attn2_fwd(q, k, v, ctx, lse, B, Sq, Skv, heads, *, key_mask=None, causal=False, q_rows=None, kv_rows=None, drop=None):
+    """General attention: q [B*q_rows, >=heads*64] / k, v [B*kv_rows, ...] bf16 2-D views (row strides from the tensors).
+    drop = (p, key0, key1, step_counter) applies dropout to the attention probabilities (xbert.py:333)."""
     _dev(q, k, v, ctx)
+    if drop is not None and drop[0] > 0:
+        _chk(load().feddat_attn2_fwd_dropout(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(key_mask),
+                                             int(causal), _p(ctx), ctx.stride(0), _p(lse), B, Sq, Skv,
+                                             Sq if q_rows is None else q_rows, Skv if kv_rows is None else kv_rows, heads,
+                                             drop[0], drop[1], drop[2], _p(drop[3]), _stream()), "feddat_attn2_fwd_dropout")
+        return
     _chk(load().feddat_attn2_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(key_mask), int(causal),
                                  _p(ctx), ctx.stride(0), _p(lse), B, Sq, Skv, Sq if q_rows is None else q_rows,
                                  Skv if kv_rows is None else kv_rows, heads, _stream()), "feddat_attn2_fwd")
 
 
 def attn2_bwd(q, k, v, ctx, lse, dctx, dsum_ws, dq, dk, dv, B, Sq, Skv, heads, *, key_mask=None, causal=False,
-              q_rows=None, kv_rows=None):
+              q_rows=None, kv_rows=None, drop=None):
     _dev(q, k, v, ctx, dctx, dq, dk, dv)
+    if drop is not None and drop[0] > 0:
+        _chk(load().feddat_attn2_bwd_dropout(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(key_mask),
+                                             int(causal), _p(ctx), ctx.stride(0), _p(lse), _p(dctx), dctx.stride(0),
+                                             _p(dsum_ws), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), B, Sq,
+                                             Skv, Sq if q_rows is None else q_rows, Skv if kv_rows is None else kv_rows, heads,
+                                             drop[0], drop[1], drop[2], _p(drop[3]), _stream()), "feddat_attn2_bwd_dropout")
+        return
     _chk(load().feddat_attn2_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(key_mask), int(causal),
                                  _p(ctx), ctx.stride(0), _p(lse), _p(dctx), dctx.stride(0), _p(dsum_ws), _p(dq),
                                  dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), B, Sq, Skv,
@@ -447,6 +466,26 @@ def lm_loss_fwd_bwd(logits, teacher, labels, row_weight, V, temp, kl_scale, dlog
     _chk(load().feddat_lm_loss_fwd_bwd(_p(logits), _p(teacher), logits.stride(0), _p(labels), _p(row_weight), R, V, temp,
                                        kl_scale, _p(dlogits_bf16), 0 if dlogits_bf16 is None else dlogits_bf16.stride(0),
                                        _p(scalars), _stream()), "feddat_lm_loss_fwd_bwd")
+
+
+def dropout(x, drop, *, resid=None, out_f32=None, out_bf16=None):
+    """out = mask(idx) x / (1 - p) (+ resid); x fp32 or bf16; drop = (p, key0, key1, step_counter)."""
+    _dev(x, resid, out_f32, out_bf16)
+    x32, x16 = (x, None) if x.dtype == torch.float32 else (None, x)
+    _chk(load().feddat_dropout(_p(x32), _p(x16), _p(resid), _p(out_f32), _p(out_bf16), x.numel(), drop[0], drop[1], drop[2],
+                               _p(drop[3]), _stream()), "feddat_dropout")
+
+
+def dropout_keys(seed: int, pass_id: int, site: int):
+    """(key0, key1) of one dropout site: splitmix64 of (seed, pass, site) split in two 32-bit halves (include/feddat_hip.h)."""
+    M = (1 << 64) - 1
+    z = (seed * 0x9E3779B97F4A7C15 + pass_id * 0xBF58476D1CE4E5B9 + site * 0x94D049BB133111EB + 0x2545F4914F6CDD1D) & M
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & M
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return z & 0xFFFFFFFF, z >> 32
 
 
 def axpby3(a, alpha, b=None, beta=0.0, c=None, gamma=0.0, *, out_f32=None, out_bf16=None):

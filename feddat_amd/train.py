@@ -226,6 +226,9 @@ def build_parser() -> argparse.ArgumentParser:
                         "(heterogeneous len(loader), e.g. 40,50,60,70,80,45,55,65 for 8 clients)")
     p.add_argument("--image_size", type=int, default=384)
     p.add_argument("--num_layers", type=int, default=12)
+    p.add_argument("--albef_dropout", type=float, default=0.1,
+                   help="hidden / attention-probability dropout of the ALBEF BERT towers under train_step (the reference's "
+                        "model.train() with src/configs/model_configs.py:44-46); 0 = the deterministic parity configuration")
     p.add_argument("--albef_dims", type=str, default="",
                    help="ALBEF only: override depths for quick runs, e.g. vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2")
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
@@ -278,7 +281,8 @@ def main(argv=None):
         dims = {k: int(v) for k, v in (kv.split("=") for kv in args.albef_dims.split(",") if kv)}
         params = albef_spec.random_init(seed=args.seed, image=args.image_size, **dims)   # stand-in for ALBEF.pth
         model = create_albef_continual_learner_model(params, dev, args.batch_size, args.batch_size, lr=args.lr,
-                                                     image=args.image_size, **dims)
+                                                     image=args.image_size, dropout=args.albef_dropout,
+                                                     seed=args.seed + 7919 * rank, **dims)
         Trainer = AlbefTaskTrainer
     else:
         params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)    # stand-in for from_pretrained

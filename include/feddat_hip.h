@@ -114,6 +114,22 @@ int feddat_attn2_bwd(const void* q, long ldq, const void* k, long ldk, const voi
                      int causal, const void* ctx, long ldo, const float* lse, const void* dctx, long lddo, float* dsum_ws,
                      void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, int B, int Sq, int Skv,
                      long q_rows_per_sample, long kv_rows_per_sample, int heads, hipStream_t stream);
+/* The same with train-mode dropout on the attention probabilities (BertSelfAttention, src/modeling/models/xbert.py:333;
+ * attention_probs_dropout_prob = 0.1, src/configs/model_configs.py:44): ctx = (softmax(S) . M / (1 - p)) V, and in the
+ * backward dP = M / (1 - p) . (dO V^T).  The mask is COUNTER-BASED and never stored: element
+ * idx = ((b * heads + h) * S_q + q) * S_kv + key of the [B, heads, S_q, S_kv] probability tensor is kept iff
+ *     fmix32(fmix32(idx * 0x9E3779B1 + key0) + key1 + step * 0x632BE5AB) >= p * 2^32      (32-bit wrap-around; fmix32 =
+ * the murmur3 finaliser), step = *step_ctr (device int, may be NULL = 0) so that a captured hipGraph draws a fresh mask on
+ * every replay; the forward and the backward of one pass take the same (key0, key1, step).  B * heads * S_q * S_kv < 2^32. */
+int feddat_attn2_fwd_dropout(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                             const uint8_t* key_mask, int causal, void* ctx, long ldo, float* lse, int B, int Sq, int Skv,
+                             long q_rows_per_sample, long kv_rows_per_sample, int heads, float p, unsigned key0,
+                             unsigned key1, const int* step_ctr, hipStream_t stream);
+int feddat_attn2_bwd_dropout(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                             const uint8_t* key_mask, int causal, const void* ctx, long ldo, const float* lse,
+                             const void* dctx, long lddo, float* dsum_ws, void* dq, long lddq, void* dk, long lddk, void* dv,
+                             long lddv, int B, int Sq, int Skv, long q_rows_per_sample, long kv_rows_per_sample, int heads,
+                             float p, unsigned key0, unsigned key1, const int* step_ctr, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  LayerNorm over the last dim (H <= 2048, H % 4 == 0), fp32 in.
@@ -387,6 +403,14 @@ int feddat_layernorm_bwd_full(const float* dy, const float* x, const float* stat
  * double-LayerNorm adapter variant (src/modeling/models/adapter.py:97-116): y + inp = (dense + inp) + (A(x) + x) - x. */
 int feddat_axpby3(const float* a, float alpha, const float* b, float beta, const float* c, float gamma, float* out_f32,
                   void* out_bf16, long n, hipStream_t stream);
+/* nn.Dropout in train mode on a dense tensor of n elements (n % 4 == 0, n < 2^32), optionally fused with the residual add
+ * that follows it: out = (keep(idx) ? x / (1 - p) : 0) (+ resid), keep() as documented at feddat_attn2_fwd_dropout with
+ * idx = the element's linear index.  Exactly one of x_f32 / x_bf16 is given; out_f32 and / or out_bf16.  Replaces the
+ * hidden-state dropouts of the ALBEF BERT towers: BertEmbeddings (src/modeling/models/xbert.py:216), BertSelfOutput (:360,
+ * with resid = the block's input), BertOutput (:440, ahead of the adapter); the backward applies the same call (same keys)
+ * to the incoming gradient. */
+int feddat_dropout(const float* x_f32, const void* x_bf16, const float* resid, float* out_f32, void* out_bf16, long n,
+                   float p, unsigned key0, unsigned key1, const int* step_ctr, hipStream_t stream);
 /* dst[r] = src[idx[r]], a zero row for idx[r] < 0 (rows of `width` floats; one question's states repeated for each of its k answers,
  * albef_model.py:93-98) and its adjoint over contiguous segments: dst[s] (+)= sum of src rows [off[s], off[s+1]). */
 int feddat_gather_rows(const float* src, const int* idx, float* dst_f32, void* dst_bf16, int rows, int width,

@@ -15,6 +15,7 @@ pin -- ties it in init_weights) and `cls.predictions.decoder.bias` is `cls.predi
 from __future__ import annotations
 
 import math
+import re
 from typing import Dict, List, Sequence
 
 import torch
@@ -131,8 +132,73 @@ def adapter_layer_forward_bert(P: Params, base: str, dense_out, inp, ln_w, ln_b,
     return F.layer_norm(y + inp, (inp.shape[-1],), ln_w, ln_b, eps)
 
 
+# ------------------------------------------------------------------------------------------------ train-mode dropout
+# The reference trains under model.train() with hidden_dropout_prob = attention_probs_dropout_prob = 0.1
+# (src/configs/model_configs.py:44-46) in the two BERT towers: after the embedding LayerNorm (xbert.py:216), on the attention
+# probabilities (:333), on BertSelfOutput's dense output (:360, self- and cross-attention blocks) and on BertOutput's dense
+# output ahead of the adapter (:440).  The ViT has no dropout (vit.py:120: all rates 0).  torch's generator cannot be
+# reproduced on the device, so masks are COUNTER-BASED here and in libfeddat_hip.so (include/feddat_hip.h,
+# feddat_attn2_fwd_dropout): element idx of the tensor a site drops is kept iff
+#     fmix32(fmix32(idx * 0x9E3779B1 + key0) + key1 + step * 0x632BE5AB) >= p * 2^32,
+# (key0, key1) = splitmix64(seed, pass, site).  pass = 0 / 1 / 2 for the P0 / P1 / P2 forward of one train_step
+# (task_trainer.py:283-287,290-295,311-315: three independent draws), step = train_steps since the start of the local
+# update.  SITE PLACEMENT is pinned to the reference: oracle/make_albef_golden.py runs the reference's own modules with
+# nn.Dropout.forward replaced by this mask function keyed on the MODULE's name (fixture g12).
+class _Drop:
+    p, seed, step, pass_id = 0.0, 0, 0, 0
+
+
+DROP = _Drop()
+_KINDS = {"emb": 0, "self_probs": 1, "self_out": 2, "cross_probs": 3, "cross_out": 4, "out": 5}
+_M32 = 0xFFFFFFFF
+
+
+def dropout_site(name: str, kind: str) -> int:
+    """Site number of a dropout module from any parameter / module name inside it: tower (0 encoder, 1 decoder), layer, kind."""
+    tower = 1 if "text_decoder" in name else 0
+    m = re.search(r"layer\.(\d+)\.", name)
+    return (tower * 64 + (int(m.group(1)) if m else 0)) * 8 + _KINDS[kind]
+
+
+def dropout_keys(seed: int, pass_id: int, site: int):
+    M = (1 << 64) - 1
+    z = (seed * 0x9E3779B97F4A7C15 + pass_id * 0xBF58476D1CE4E5B9 + site * 0x94D049BB133111EB + 0x2545F4914F6CDD1D) & M
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & M
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return z & _M32, z >> 32
+
+
+def _fmix32(x):
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & _M32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & _M32
+    return x ^ (x >> 16)
+
+
+def dropout_keep(numel: int, p: float, key0: int, key1: int, step: int) -> torch.Tensor:
+    """bool [numel]: the keep mask (int64 arithmetic masked to 32 bits = the device's uint32 wrap-around)."""
+    idx = torch.arange(numel, dtype=torch.int64)
+    x = _fmix32((idx * 0x9E3779B1 + key0) & _M32)
+    x = _fmix32((x + ((key1 + step * 0x632BE5AB) & _M32)) & _M32)
+    return x >= int(float(torch.tensor(p, dtype=torch.float32)) * 4294967296.0)
+
+
+def drop(x, name: str, kind: str):
+    """nn.Dropout(p) in train mode at the site named by (name, kind): x * keep / (1 - p)."""
+    if DROP.p <= 0:
+        return x
+    k0, k1 = dropout_keys(DROP.seed, DROP.pass_id, dropout_site(name, kind))
+    keep = dropout_keep(x.numel(), DROP.p, k0, k1, DROP.step).view(x.shape)
+    scale = torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - torch.tensor(DROP.p, dtype=torch.float32))
+    return x * (keep.to(x.dtype) * scale)
+
+
 # ------------------------------------------------------------------------------------------------ ViT-B/16
-def _mha(q, k, v, heads, add_mask=None):
+def _mha(q, k, v, heads, add_mask=None, pdrop=None):
     B, Sq, H = q.shape
     Skv = k.shape[1]
     hd = H // heads
@@ -142,7 +208,10 @@ def _mha(q, k, v, heads, add_mask=None):
     s = q @ k.transpose(-1, -2) / math.sqrt(hd)
     if add_mask is not None:
         s = s + add_mask
-    return (s.softmax(-1) @ v).transpose(1, 2).reshape(B, Sq, H)
+    p = s.softmax(-1)
+    if pdrop is not None:
+        p = pdrop(p)                       # attention_probs_dropped = self.dropout(attention_probs)   xbert.py:333
+    return (p @ v).transpose(1, 2).reshape(B, Sq, H)
 
 
 def vit_forward(P: Params, d: AlbefDims, image, mode: str):
@@ -172,15 +241,18 @@ def bert_embeddings(P: Params, tower: str, ids):
     L = ids.shape[1]
     x = P[e + "word_embeddings.weight"][ids] + P[e + "token_type_embeddings.weight"][0] + \
         P[e + "position_embeddings.weight"][:L]
-    return F.layer_norm(x, (x.shape[-1],), P[e + "LayerNorm.weight"], P[e + "LayerNorm.bias"], 1e-12)
+    x = F.layer_norm(x, (x.shape[-1],), P[e + "LayerNorm.weight"], P[e + "LayerNorm.bias"], 1e-12)
+    return drop(x, e, "emb")                                                                  # xbert.py:216
 
 
 def _bert_attention(P, base, h, kv_src, add_mask, heads):
     q = F.linear(h, P[base + "self.query.weight"], P[base + "self.query.bias"])
     k = F.linear(kv_src, P[base + "self.key.weight"], P[base + "self.key.bias"])
     v = F.linear(kv_src, P[base + "self.value.weight"], P[base + "self.value.bias"])
-    ctx = _mha(q, k, v, heads, add_mask)
+    cross = "crossattention" in base
+    ctx = _mha(q, k, v, heads, add_mask, (lambda p: drop(p, base, "cross_probs" if cross else "self_probs")) if DROP.p > 0 else None)
     out = F.linear(ctx, P[base + "output.dense.weight"], P[base + "output.dense.bias"])
+    out = drop(out, base, "cross_out" if cross else "self_out")                              # BertSelfOutput, xbert.py:360
     return F.layer_norm(out + h, (h.shape[-1],), P[base + "output.LayerNorm.weight"], P[base + "output.LayerNorm.bias"], 1e-12)
 
 
@@ -192,6 +264,7 @@ def bert_layer(P: Params, L: str, h, self_mask, enc, enc_mask, heads, mode: str,
         a = _bert_attention(P, L + "crossattention.", a, enc, enc_mask, heads)
     inter = F.gelu(F.linear(a, P[L + "intermediate.dense.weight"], P[L + "intermediate.dense.bias"]))
     dense = F.linear(inter, P[L + "output.dense.weight"], P[L + "output.dense.bias"])
+    dense = drop(dense, L, "out")                                                             # BertOutput, xbert.py:440
     return adapter_layer_forward_bert(P, L + "output.adapter.", dense, a, P[L + "output.LayerNorm.weight"],
                                       P[L + "output.LayerNorm.bias"], 1e-12, mode)
 
@@ -283,8 +356,9 @@ class AlbefDatClient:
     parameters are trainable (main.py:138-159), so both optimizers hold adapter_0 and adapter_1 tensors only."""
 
     def __init__(self, P: Params, d: AlbefDims, lr: float, steps_per_epoch: int, num_epochs: int = 15,
-                 warmup_ratio: float = 0.1, opt_adapters: Sequence[int] = (0, 1)):
+                 warmup_ratio: float = 0.1, opt_adapters: Sequence[int] = (0, 1), dropout: float = 0.0, seed: int = 0):
         self.P, self.d, self.lr = P, d, lr
+        self.dropout, self.seed, self.step_idx = dropout, seed, 0
         for n in list(P):
             if "adapter_1" in n:
                 P[n.replace("adapter_1", "adapter_2")] = P[n].clone()
@@ -297,7 +371,11 @@ class AlbefDatClient:
     def _lr(self):
         return self.lr * O.poly_lr_lambda(self.t, self.warmup, self.total)
 
+    def _set_pass(self, pass_id):
+        DROP.p, DROP.seed, DROP.step, DROP.pass_id = self.dropout, self.seed, self.step_idx, pass_id
+
     def _sub_step(self, batch, mode, adapter_idx, teacher):
+        self._set_pass(1 if mode == "adapter_1" else 2)
         names = [n for n in trainable_names(self.P, adapter_idx) if n in self.opt.t]
         for n in names:
             self.P[n].requires_grad_(True)
@@ -312,10 +390,15 @@ class AlbefDatClient:
         return loss.detach(), logits.detach(), float(L)
 
     def train_step(self, batch):
-        with torch.no_grad():
-            _, logits_all = albef_train_forward(self.P, self.d, batch, "gating")
-        loss_1, logits_1, self.last_L1 = self._sub_step(batch, "adapter_1", 1, logits_all)
-        loss_0, _, self.last_L0 = self._sub_step(batch, "gating", 0, logits_1)
+        self._set_pass(0)
+        try:
+            with torch.no_grad():
+                _, logits_all = albef_train_forward(self.P, self.d, batch, "gating")
+            loss_1, logits_1, self.last_L1 = self._sub_step(batch, "adapter_1", 1, logits_all)
+            loss_0, _, self.last_L0 = self._sub_step(batch, "gating", 0, logits_1)
+        finally:
+            DROP.p = 0.0                   # dropout is a property of train_step only (eval / plain forwards: model.eval())
+        self.step_idx += 1
         self.last_loss_1 = float(loss_1)
         return loss_0
 

@@ -115,11 +115,11 @@ class _Wrapper(nn.Module):
         return [loss, logits]
 
 
-def build_reference_model(d: A.AlbefDims):
+def build_reference_model(d: A.AlbefDims, dropout: float = 0.0):
     ac = {"names": ["adapter_0", "adapter_1", "adapter_2"], "device": "cpu"}
     cfgd = dict(hidden_size=d.hidden, intermediate_size=d.inter, num_attention_heads=d.heads, num_hidden_layers=d.enc_layers,
                 vocab_size=d.vocab, max_position_embeddings=d.max_pos, type_vocab_size=2, layer_norm_eps=1e-12,
-                hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, pad_token_id=d.pad_id,
+                hidden_act="gelu", hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout, pad_token_id=d.pad_id,
                 fusion_layer=d.fusion_layer, encoder_width=d.hidden)
     ce = xb.BertConfig(**cfgd)
     ce.adapter_config = ac
@@ -207,6 +207,40 @@ def ref_local_update(model, batches, lr, num_epochs=15):
 
 def np_(t):
     return t.detach().cpu().numpy().astype(np.float32)
+
+
+def install_counter_dropout(model, seed):
+    """Replace nn.Dropout.forward by the counter-based mask of oracle/albef_oracle.py, keyed on the MODULE's own name: every
+    nn.Dropout of the reference model that fires in train mode must be one of the six kinds the oracle (and the HIP engine)
+    place -- an unmapped one trips the assertion, a site the oracle places where the reference has none would make the
+    fixture's numbers unreachable.  pass = index of the top-level forward inside its train_step (P0 / P1 / P2,
+    task_trainer.py:283-315), step = train_steps done."""
+    import re
+    kinds = [("embeddings.dropout", "emb"), ("crossattention.self.dropout", "cross_probs"), ("attention.self.dropout", "self_probs"),
+             ("crossattention.output.dropout", "cross_out"), ("attention.output.dropout", "self_out")]
+    n_sites = 0
+    for n, m in model.named_modules():
+        if isinstance(m, nn.Dropout):
+            kind = next((k for suf, k in kinds if n.endswith(suf)), None)
+            if kind is None and re.search(r"layer\.\d+\.output\.dropout$", n):
+                kind = "out"
+            m._fd_name, m._fd_site = n, (A.dropout_site(n, kind) if kind else None)
+            n_sites += kind is not None
+    state = {"calls": 0, "fired": set()}
+    model.albef_model.register_forward_pre_hook(lambda mod, inp: state.__setitem__("calls", state["calls"] + 1))
+
+    def fwd(self, x):
+        if not self.training or self.p == 0:
+            return x
+        assert self._fd_site is not None, "unmapped dropout module fired: " + self._fd_name
+        call = state["calls"] - 1
+        k0, k1 = A.dropout_keys(seed, call % 3, self._fd_site)
+        keep = A.dropout_keep(x.numel(), self.p, k0, k1, call // 3).view(x.shape)
+        scale = torch.tensor(1.0) / (torch.tensor(1.0) - torch.tensor(self.p, dtype=torch.float32))
+        state["fired"].add(self._fd_name)
+        return x * (keep.to(x.dtype) * scale)
+    nn.Dropout.forward = fwd
+    return state, n_sites
 
 
 def set_mode(model, mode):
@@ -316,9 +350,39 @@ def golden_round(out, steps=40):
           "mean |dW|", float(np.mean([rec[k] for k in rec if k.startswith("dmean::")])))
 
 
+def golden_dropout(out, steps=3, p=0.1, seed=77):
+    """G12: train_steps of the small configuration UNDER model.train() with the reference's dropout probabilities
+    (hidden_dropout_prob = attention_probs_dropout_prob = 0.1, src/configs/model_configs.py:44-46; task_trainer.py:75) -- the
+    random masks replaced by the counter-based ones (install_counter_dropout), everything else the reference's own code.
+    Pins WHERE the oracle drops (embeddings, attention probabilities, BertSelfOutput of self- and cross-attention,
+    BertOutput ahead of the adapter), that P0 / P1 / P2 draw independent masks, and the 1 / (1 - p) scaling."""
+    d = small_dims()
+    model = build_reference_model(d, dropout=p)
+    state, n_sites = install_counter_dropout(model, seed)
+    for n, q in model.named_parameters():
+        if "adapter" in n:
+            q.requires_grad = True
+    model.train()
+    batches = [A.synthetic_batch(3, d, 900 + s, q_len=12, a_len=5, k=[2, 1, 3], ragged=True) for s in range(steps)]
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rec = {"losses": np.array(ref_local_update(model, batches, lr=1e-4, num_epochs=1), np.float32),
+           "steps": np.array(steps, np.int64), "p": np.array(p, np.float32), "seed": np.array(seed, np.int64)}
+    assert state["calls"] == 3 * steps and len(state["fired"]) == n_sites, (state["calls"], len(state["fired"]), n_sites)
+    for k, v in model.state_dict().items():
+        if "adapter_0" in k or "adapter_1" in k:
+            dw = (v.detach() - init[k]).flatten()
+            idx = torch.linspace(0, dw.numel() - 1, min(512, dw.numel())).long()
+            rec["dnorm::" + k], rec["dmean::" + k], rec["dsamp::" + k] = np_(dw.norm()), np_(dw.abs().mean()), np_(dw[idx])
+    np.savez_compressed(os.path.join(out, "g12_albef_dropout.npz"), **rec)
+    print("G12 losses", rec["losses"], "dropout sites fired", len(state["fired"]))
+
+
 if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden")
     torch.manual_seed(0)
+    if "--only-g12" in sys.argv:
+        golden_dropout(out)
+        sys.exit(0)
     if "--only-g11" in sys.argv:
         golden_round(out)
         sys.exit(0)

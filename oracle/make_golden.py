@@ -243,7 +243,8 @@ def golden_g6(out):
 
 
 def golden_g8(out, steps=40):
-    """G8: one REALISTIC local round of the full 12-layer ViLT-B/32 on the reference: B=4, 384x384, len(loader)=40,
+    """(steps = 40: g8_round40.npz; steps = 80: g8_round80.npz, 1200 scheduler ticks, warm-up 120 ticks = 60 batches.)
+    G8: one REALISTIC local round of the full 12-layer ViLT-B/32 on the reference: B=4, 384x384, len(loader)=40,
     num_epochs=15 -> N=600 scheduler ticks, warm-up 60 ticks = 30 batches, so the last 10 batches run at lr ~ 1e-4
     (task_trainer.py:53-59).  Stored per adapter_0 / adapter_1 / head tensor: the UPDATE dW = W_after - W_init as L2 norm,
     mean |dW| and 1024 strided samples (W_init is the name-seeded fill, regenerated by the tests), so that parity is
@@ -262,7 +263,7 @@ def golden_g8(out, steps=40):
             rec["dmean::" + k] = np_(dw.abs().mean())
             rec["dmax::" + k] = np_(dw.abs().max())
             rec["dsamp::" + k] = np_(dw[idx])
-    np.savez_compressed(os.path.join(out, "g8_round40.npz"), **rec)
+    np.savez_compressed(os.path.join(out, f"g8_round{steps}.npz"), **rec)
     print("G8 losses", losses[:3], "...", losses[-3:])
 
 
@@ -270,8 +271,9 @@ def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     torch.manual_seed(0)
-    if "--only-g8" in sys.argv:
-        golden_g8(out)
+    if "--only-g8" in sys.argv:          # [--steps N]: the same round at another length (g8_round<N>.npz; 80 = the longest
+        steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 40      # len(loader) of configs[2])
+        golden_g8(out, steps)
         return
     if "--only-g6" in sys.argv:          # the other fixtures are unchanged; regenerate just this one
         golden_g6(out)
