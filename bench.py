@@ -177,38 +177,165 @@ def cpu_baseline(params_cpu, batches_cpu, B, res, task, timed_steps=3):
                        f"(best of the sweep)")
 
 
-def bench_albef(args, world, rank, dev, dist):
-    """configs[3]: one ALBEF dual-adapter + MKD train_step per step (one hipGraph replay); with N clients the timed region ends with the FedAvg all-reduce of the 8.95 MB adapter_1 payload."""
-    from feddat_amd import albef_engine, albef_spec
-    from feddat_amd.fedavg import allreduce_average
-    B = args.batch
-    params = albef_spec.random_init(seed=0, image=args.res)
-    eng = albef_engine.AlbefDatEngine(params, dev, batch=B, n_answers=B, image=args.res)
-    batches = [albef_spec.synthetic_batch(B, 1234 + 100 * rank + i, image=args.res, device=dev) for i in range(2)]
-    eng.begin_local_update(steps_per_epoch=max(args.steps + args.warmup, 40))
+def hetero_steps(K, rank):
+    """--hetero: client r's len(loader) from {40, 50, 60, 70, 80}, scaled so that the longest is K."""
+    return max(1, round(K * (40 + 10 * (rank % 5)) / 80))
 
+
+def make_exchange(eng, world, rank, dist):
+    """The round's FedAvg exchange.  Real launch (one GPU per rank, backend "nccl"): the C-ABI collective
+    feddat_fedavg_allreduce on a communicator made through feddat_comm_* (RCCL bound by dlopen, unique id shipped over the
+    torch.distributed rendezvous) -- not torch.distributed's all_reduce.  The single-GPU test rig (several ranks on one
+    device, backend gloo: RCCL refuses two ranks per device) keeps the torch.distributed path."""
+    if dist is None:
+        return None, None
+    from feddat_amd.fedavg import allreduce_average, make_rccl_comm
+    nbytes = eng.comm_flat().numel() * 4
+    if dist.get_backend() == "nccl":
+        comm = make_rccl_comm(world, rank)
+        info = comm.info()
+        v = info["rccl_version"]
+        desc = {"library": "RCCL %d.%d.%d (C ABI: feddat_fedavg_allreduce)" % (v // 10000, v // 100 % 100, v % 100),
+                "ranks_in_communicator": info["ranks"], "payload_bytes": nbytes, "per_round": 1}
+        return (lambda: allreduce_average(eng, world, comm=comm)), desc
+    desc = {"library": "torch.distributed " + dist.get_backend() + " (single-GPU test rig)",
+            "ranks_in_communicator": dist.get_world_size(), "payload_bytes": nbytes, "per_round": 1}
+    return (lambda: allreduce_average(eng, world)), desc
+
+
+def timed_round(step_fn, steps_r, warmup, exchange, dist, dev):
+    """W warm-up steps (+ one exchange), barrier; then this rank's steps_r steps, [barrier], the exchange, barrier -- all
+    inside the timed region.  Returns the round time (max over ranks is taken by the caller) and its split: this rank's
+    compute time, its wait at the barrier for the slowest client, and the all-reduce (HIP events on the launch stream)."""
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    use_graph = not args.no_graph
-    for i in range(args.warmup):
-        eng.train_step(batches[i % 2], use_graph=use_graph)
-    if dist is not None:
-        allreduce_average(eng, world)
+    for i in range(warmup):
+        step_fn(i)
+    if exchange is not None:
+        exchange()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.train_step(batches[i % 2], use_graph=use_graph)
-    if dist is not None:
-        allreduce_average(eng, world)
+    for i in range(steps_r):
+        step_fn(i)
+    torch.cuda.synchronize()
+    t_c = time.perf_counter() - t0
+    t_w, ar_ms = 0.0, 0.0
+    if exchange is not None:
+        dist.barrier()                       # every client has finished its local epoch
+        t_w = time.perf_counter() - t0 - t_c
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        exchange()
+        e1.record()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+    if exchange is not None:
+        ar_ms = e0.elapsed_time(e1)
+    return dict(dt=dt, compute_s=t_c, wait_s=t_w, allreduce_ms=ar_ms, steps=steps_r)
+
+
+def gather_ranks(tr, B, world, rank, dist, dev):
+    """-> (round time = max over ranks, total steps over ranks, per-rank rows) on every rank."""
+    if dist is None:
+        return tr["dt"], tr["steps"], None
+    mine = torch.tensor([tr["dt"], tr["compute_s"], tr["wait_s"], tr["allreduce_ms"], float(tr["steps"])], dtype=torch.float64,
+                        device=dev if dist.get_backend() == "nccl" else "cpu")
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    rows = [dict(rank=r, steps=int(t[4]), samples_per_sec=round(B * float(t[4]) / float(t[1]), 1),
+                 compute_s=round(float(t[1]), 4), wait_s=round(float(t[2]), 4), allreduce_ms=round(float(t[3]), 3))
+            for r, t in enumerate(allr)]
+    return max(float(t[0]) for t in allr), int(sum(float(t[4]) for t in allr)), rows
+
+
+def round_split(rows, dt):
+    if rows is None:
+        return None
+    return {"round_s": round(dt, 4), "compute_s_max": max(r["compute_s"] for r in rows),
+            "compute_s_min": min(r["compute_s"] for r in rows), "wait_s_mean": round(sum(r["wait_s"] for r in rows) / len(rows), 4),
+            "allreduce_ms_max": max(r["allreduce_ms"] for r in rows)}
+
+
+def albef_roofline(L, eng, batches):
+    """K1 over the GEMM launches of one ALBEF train_step and K2b (attn2) as its own entry, durations measured IN the step
+    (tools/step_breakdown.measure: every C-ABI call of an eager step bracketed by HIP events on its launch stream, the
+    step queued behind a spin kernel); for the measurement the two passes run on ONE stream so that a bracket times its
+    own kernel and not its neighbour on the other stream."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from step_breakdown import measure
+    side, eng.side = eng.side, torch.cuda.current_stream()
+    try:
+        agg, step_ms, empty_us = measure(eng, L, batches, steps=2, detail=True)
+    finally:
+        eng.side = side
+    g = {k[1:5]: v for k, v in agg.items() if isinstance(k, tuple) and k[0] == "gemm"}
+    tot_t = sum(ms for _, ms in g.values()) * 1e-3
+    tot_f = sum(2.0 * M * N * K * n for (M, N, K, _), (n, _) in g.items())
+    launches = sum(n for n, _ in g.values())
+    alg = sum(gemm_algorithmic_bytes(M, N, K, epi) * n for (M, N, K, epi), (n, _) in g.items()) / launches
+    big = sorted(g.items(), key=lambda kv: -kv[1][1])[:10]
+    rows = [dict(M=M, N=N, K=K, epi=epi, count=n, us=round(ms / n * 1e3, 2),
+                 tflops=round(2.0 * M * N * K * n / (ms * 1e-3) / 1e12, 1)) for (M, N, K, epi), (n, ms) in big]
+    att = {k: v for k, v in agg.items() if isinstance(k, tuple) and k[0] in ("attn2_fwd", "attn2_bwd")}
+    # matmul units: forward 2 (QK^T, PV); backward 5 executed (S, dP in both kernels counted once each, dV, dK, dQ) + 2 recomputed
+    a_f = sum((2 if k[0] == "attn2_fwd" else 7) * 2.0 * k[1] * k[4] * k[2] * k[3] * 64 * n * (0.5 if k[5] else 1.0)
+              for k, (n, _) in att.items())
+    a_t = sum(ms for _, ms in att.values()) * 1e-3
+    other = {str(k): round(v[1], 4) for k, v in agg.items() if not isinstance(k, tuple)}
+    return {"kernel": "gemm_nt_v3_kernel / gemm_nt_v2_kernel / gemm_nt_mid_kernel (K1: every GEMM launch of one ALBEF train_step, "
+                      "FLOP-weighted, durations measured in-step)",
+            "bound": "mfma", "achieved": round(tot_f / tot_t / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+            "frac": round(tot_f / tot_t / PEAK_BF16, 4), "traffic": None, "algorithmic_bytes_per_launch": round(alg),
+            "launches_per_step": launches, "gemm_ms_per_step": round(tot_t * 1e3, 3), "shapes_top10_by_time": rows,
+            "attn2": {"kernel": "attn2_fwd_kernel / attn2_bwd_dq_kernel / attn2_bwd_dkv_kernel (K2b)", "bound": "mfma",
+                      "achieved": round(a_f / a_t / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                      "frac": round(a_f / a_t / PEAK_BF16, 4), "ms_per_step": round(a_t * 1e3, 3),
+                      "launches_per_step": sum(n for n, _ in att.values()),
+                      "flops_counted": "executed matmul units (fwd 2, bwd 7 incl. the 2 recomputed), causal halved"},
+            "in_step": {"eager_step_ms_one_stream": round(step_ms, 3), "empty_bracket_us": round(empty_us, 2),
+                        "other_ops_ms_per_step": other}}
+
+
+def albef_cpu_baseline(B_cpu=4, timed_steps=2):
+    """The ALBEF oracle (oracle/albef_oracle.py, pinned to the reference's own modules: G10 / G11 / G12) on this node's host
+    cores, full architecture, a BOUNDED sample: B_cpu-sample batches of the same synthetic recipe, 1 warm-up + 2 timed
+    train_steps (dropout off, as the GPU line)."""
+    from oracle import albef_oracle as A
+    d = A.AlbefDims()
+    ncpu = os.cpu_count()
+    nt = min(ncpu, 32)
+    torch.set_num_threads(nt)
+    P = A.make_params(d)
+    c = A.AlbefDatClient(P, d, lr=1e-4, steps_per_epoch=50)
+    bs = [A.synthetic_batch(B_cpu, d, 1234 + i) for i in range(1 + timed_steps)]
+    c.train_step(bs[0])
+    t1 = time.time()
+    for i in range(timed_steps):
+        c.train_step(bs[1 + i])
+    dt = time.time() - t1
+    return dict(value=round(B_cpu * timed_steps / dt, 3), unit="samples/s", cores=nt, host_cores=ncpu, kind="port",
+                sample=f"{timed_steps} timed train_steps after 1 warm-up at B={B_cpu} (the GPU line runs B=32/client), 384x384, "
+                       f"25-token questions, one 4-token answer, ViT-B/16 + BERT-base 12 + 6 layers, fp32, torch "
+                       f"{torch.__version__} CPU, {nt} threads")
+
+
+def bench_albef(args, world, rank, dev, dist):
+    """configs[3]: one ALBEF dual-adapter + MKD train_step per step (one hipGraph replay); with N clients the timed region ends with the FedAvg all-reduce of the 8.95 MB adapter_1 payload."""
+    from feddat_amd import albef_engine, albef_spec, lib as L
+    B = args.batch
+    params = albef_spec.random_init(seed=0, image=args.res)
+    eng = albef_engine.AlbefDatEngine(params, dev, batch=B, n_answers=B, image=args.res, dropout=args.albef_dropout,
+                                      seed=1234 + rank)
+    batches = [albef_spec.synthetic_batch(B, 1234 + 100 * rank + i, image=args.res, device=dev) for i in range(2)]
+    eng.begin_local_update(steps_per_epoch=max(args.steps + args.warmup, 40))
+    use_graph = not args.no_graph
+    steps_r = hetero_steps(args.steps, rank) if args.hetero else args.steps
+    exchange, coll = make_exchange(eng, world, rank, dist)
+    tr = timed_round(lambda i: eng.train_step(batches[i % 2], use_graph=use_graph), steps_r, args.warmup, exchange, dist, dev)
+    dt, total_steps, rows = gather_ranks(tr, B, world, rank, dist, dev)
     loss = float(eng.acts["gating"]["loss"][0])
     if not (loss == loss):
         raise RuntimeError("non-finite loss")
@@ -217,15 +344,32 @@ def bench_albef(args, world, rank, dev, dist):
         # executed FLOPs per sample: 2 ViT forwards + 2 backwards (dX only, weight grads of the adapters only) dominate
         vit_fwd = 12 * (2.0 * Ni * 768 * (3 * 768 + 768 + 2 * 3072) + 4.0 * Ni * Ni * 768)
         flops = 2 * vit_fwd + 2 * (vit_fwd * 11 / 12 + 12 * 4.0 * Ni * Ni * 768 * 1.5)
-        sps = world * B * args.steps / dt
-        print(json.dumps({
+        sps = B * total_steps / dt
+        out = {
             "metric": "VQA samples/sec, ALBEF dual-adapter local step", "value": round(sps, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[3]: ALBEF (ViT-B/16 577 tokens + BERT-base 12 + 6 layers) dual-adapter + MKD, "
-                                   f"batch={B}/client, {args.res}x{args.res}, 25-token questions, one 4-token answer each",
-                       "clients": world, "hip_graph": use_graph, "last_loss_0": round(loss, 4)},
-            "mfma_frac_vit_flops_only": round(flops * B * args.steps / dt / PEAK_BF16, 4)}), flush=True)
+                                   f"batch={B}/client, {args.res}x{args.res}, 25-token questions, one 4-token answer each, "
+                                   f"BERT dropout {args.albef_dropout}" + (" (0 = the parity configuration, SURVEY 8d)"
+                                                                            if args.albef_dropout == 0 else ""),
+                       "clients": world, "hip_graph": use_graph, "hetero_steps": bool(args.hetero), "collective": coll,
+                       "last_loss_0": round(loss, 4)},
+            "samples_per_sec_per_gpu": round(sps / world, 2),
+            "mfma_frac_vit_flops_only": round(flops * B * total_steps / world / dt / PEAK_BF16, 4)}
+        if rows is not None:
+            out["per_rank"], out["round_split"] = rows, round_split(rows, dt)
+        if not args.no_roofline:
+            try:
+                out["roofline"] = albef_roofline(L, eng, batches)
+            except Exception as e:
+                out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = albef_cpu_baseline()
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -263,6 +407,12 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="configs[4]: e4m3 MFMA for the QKV / FFN1 forward products of the frozen backbone (bf16 adapters); "
                          "quoted at --batch 64")
+    ap.add_argument("--hetero", action="store_true",
+                    help="N > 1, SURVEY.md 8d config 3: rank r runs K * {40,50,60,70,80}[r % 5] / 80 steps (heterogeneous "
+                         "len(loader)); the imbalance is absorbed at the round's barrier and shows up as wait_s")
+    ap.add_argument("--albef-dropout", dest="albef_dropout", type=float, default=0.0,
+                    help="--workload albef: BERT hidden / attention dropout inside train_step (reference recipe: 0.1; the "
+                         "default 0 is the deterministic configuration SURVEY.md 8d quotes config 4 in)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -301,7 +451,6 @@ def main():
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
     from feddat_amd import engine, lib as L, vilt_spec
-    from feddat_amd.fedavg import allreduce_average
     dev = torch.device("cuda", local)
     if args.workload == "albef":
         return bench_albef(args, world, rank, dev, dist)
@@ -316,25 +465,10 @@ def main():
     steps_per_epoch = max(args.steps + args.warmup, 40)
     eng.begin_local_update(task, steps_per_epoch=steps_per_epoch)
     use_graph = not args.no_graph
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        eng.train_step(batches[i % nb], use_graph=use_graph)
-    if dist is not None:
-        allreduce_average(eng, world)       # warm the communicator
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.train_step(batches[i % nb], use_graph=use_graph)
-    if dist is not None:
-        allreduce_average(eng, world)       # the round's FedAvg exchange
-    barrier()
-    dt = time.perf_counter() - t0
+    steps_r = hetero_steps(args.steps, rank) if args.hetero else args.steps
+    exchange, coll = make_exchange(eng, world, rank, dist)
+    tr = timed_round(lambda i: eng.train_step(batches[i % nb], use_graph=use_graph), steps_r, args.warmup, exchange, dist, dev)
+    dt, total_steps, rank_rows = gather_ranks(tr, B, world, rank, dist, dev)
     loss = float(eng.loss_buf["p2"][0])
     host_ms = None
     if args.host_input and world == 1:
@@ -352,10 +486,6 @@ def main():
             torch.cuda.synchronize()
             res_ms[mode] = (time.perf_counter() - t1) / args.steps * 1e3
         host_ms = res_ms
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
     if not (loss == loss) or abs(loss) > 1e6:
         raise RuntimeError(f"non-finite loss {loss}")
 
@@ -363,7 +493,7 @@ def main():
     if rank == 0:
         S = eng.S
         gemms, gemm_flops, exec_flops = flops_tables(B, S)
-        sps = world * B * args.steps / dt
+        sps = B * total_steps / dt
         extra_host = {} if host_ms is None else {
             "host_input_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()},
             "host_input_samples_per_sec": {k: round(B * 1e3 / v, 1) for k, v in host_ms.items()}}
@@ -378,16 +508,15 @@ def main():
                                    "384x384 synthetic + 40-token questions, MKD on"
                                    + (f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else ""),
                        "batch_per_client": B, "seq_len": S, "clients": world, "hip_graph": use_graph,
-                       "ranks": (dist.get_world_size() if dist is not None else 1),
-                       "collective": (("RCCL" if os.environ.get("FEDDAT_DIST_BACKEND", "nccl") == "nccl" else
-                                       os.environ["FEDDAT_DIST_BACKEND"]) + " all-reduce of the 3.58 MB adapter_1 buffer, "
-                                      "once per round") if dist is not None else None,
-                       "last_loss_0": round(loss, 4)},
+                       "ranks": (dist.get_world_size() if dist is not None else 1), "hetero_steps": bool(args.hetero),
+                       "collective": coll, "last_loss_0": round(loss, 4)},
             "samples_per_sec_per_gpu": round(sps / world, 2),
-            "mfma_frac_executed_flops": round(exec_flops * args.steps / dt / PEAK_BF16, 4),
+            "mfma_frac_executed_flops": round(exec_flops * total_steps / world / dt / PEAK_BF16, 4),
             "mfma_frac_reference_flops": round(sps / world * REF_FLOPS_PER_SAMPLE / PEAK_BF16, 4),
         }
         out.update(extra_host)
+        if rank_rows is not None:      # configs[2]: per-GPU rate and the round's split (compute / wait at the barrier / all-reduce)
+            out["per_rank"], out["round_split"] = rank_rows, round_split(rank_rows, dt)
         if not args.no_roofline:
             try:
                 out["roofline"] = roofline_block(L, eng, batches, gemms)

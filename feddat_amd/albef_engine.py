@@ -258,7 +258,7 @@ class AlbefDatEngine:
 
     def _drop(self, pass_id, tower: int, layer: int, kind: str):
         """(p, key0, key1, step counter) of one dropout site of pass `pass_id` (0 / 1 / 2 = P0 / P1 / P2), or None when the
-        pass runs without dropout (pass_id None: eval / plain forwards, or dropout = 0).  Site numbering as the oracle's
+        pass runs without dropout (pass_id None: eval / plain forwards, or dropout = 0).  Site numbering: (tower * 64 + layer) * 8 + kind
         (tower 0 = text encoder, 1 = decoder)."""
         if pass_id is None or self.dropout <= 0:
             return None

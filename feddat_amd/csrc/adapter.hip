@@ -18,6 +18,8 @@
 //     each other, so a store in flight turns every later wait into vmcnt(0) = an HBM write round trip.
 // Adapter weights (72 KiB per matrix, bf16, fragment-major copies) are read through L1/L2.
 // HBM-bound: 2 x T x 768 x 4 B algorithmic bytes per forward call (+ T x 768 x 2 B with the fused LayerNorm).
+#include <type_traits>
+
 #include "common.hip.h"
 
 namespace {
@@ -516,7 +518,9 @@ __device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* 
             xk[k >> 1][k & 1] = o;
         }
 
-        // 4. LayerNorm statistics (two passes, fixed summation order)
+        // 4. LayerNorm statistics with ONE block barrier: every wave reduces its own 192 columns of each token exactly (mean,
+        // then centred second moment, both in registers + two shuffles), the four (mean_w, M2_w) pairs are combined with the
+        // pairwise formula M2 = sum M2_w + 192 sum (mean_w - mean)^2 -- as robust as the two-pass form over all 768 columns
         if (ln.gamma) {
             float s1 = 0.f;
 #pragma unroll
@@ -526,23 +530,28 @@ __device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* 
             }
             s1 += __shfl_xor(s1, 16, 64);
             s1 += __shfl_xor(s1, 32, 64);
-            if (g == 0) lnred[wave * 16 + i16] = s1;
-            __syncthreads();
-            mean = ((lnred[i16] + lnred[16 + i16]) + (lnred[32 + i16] + lnred[48 + i16])) * (1.0f / H);
+            const float mw = s1 * (1.0f / WCOLS);
             float s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < CT / 4; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = xk[k >> 1][k & 1][e] - mean;
+                    const float d = xk[k >> 1][k & 1][e] - mw;
                     s2 += d * d;
                 }
             s2 += __shfl_xor(s2, 16, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (g == 0) lnred[64 + wave * 16 + i16] = s2;
+            if (g == 0) {
+                lnred[wave * 32 + 2 * i16] = mw;
+                lnred[wave * 32 + 2 * i16 + 1] = s2;
+            }
             __syncthreads();
-            const float var = ((lnred[64 + i16] + lnred[80 + i16]) + (lnred[96 + i16] + lnred[112 + i16])) * (1.0f / H);
-            rstd = rsqrtf(var + ln.eps);
+            const float m0 = lnred[2 * i16], m1 = lnred[32 + 2 * i16], m2 = lnred[64 + 2 * i16], m3 = lnred[96 + 2 * i16];
+            mean = ((m0 + m1) + (m2 + m3)) * 0.25f;
+            const float q0 = m0 - mean, q1 = m1 - mean, q2 = m2 - mean, q3 = m3 - mean;
+            const float M2 = ((lnred[2 * i16 + 1] + lnred[32 + 2 * i16 + 1]) + (lnred[64 + 2 * i16 + 1] + lnred[96 + 2 * i16 + 1])) +
+                             (float)WCOLS * ((q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3));
+            rstd = rsqrtf(M2 * (1.0f / H) + ln.eps);
             if (g == 0) {
                 lnred[128 + wave * 32 + 2 * i16] = mean;
                 lnred[128 + wave * 32 + 2 * i16 + 1] = rstd;
@@ -562,33 +571,42 @@ __device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* 
         }
         FD_WAIT_VM0();                         // next tile's DMA has landed; no store is issued before this point
         const bool st_on = !(dbg & 1);
-        if (z_save && wave < NT && i16 < nvalid && st_on) {
+        // full tiles (all of them when the segment is a multiple of 16 rows) store without per-access predicates: the exec-mask
+        // branch around every guarded store keeps the scheduler from batching the 24 + stores of a wave
+        auto emit = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            if (z_save && wave < NT && (FULL || i16 < nvalid)) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a)
-                *reinterpret_cast<f32x4*>(z_save + (size_t)(row0 + i16) * (2 * R) + a * R + wave * 16 + 4 * g) = z_keep[a];
-        }
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
-            if (r < nvalid && st_on) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
-        }
-        if (ln.gamma) {
-            bf16* yrow = ln.y16 + (size_t)row0 * H + wave * WCOLS;
+                for (int a = 0; a < NA; ++a)
+                    *reinterpret_cast<f32x4*>(z_save + (size_t)(row0 + i16) * (2 * R) + a * R + wave * 16 + 4 * g) = z_keep[a];
+            }
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
-                const float m = lnred[128 + wave * 32 + 2 * r], rs = lnred[128 + wave * 32 + 2 * r + 1];
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(sgam + wave * WCOLS + c * 4);
-                const f32x4 bt = *reinterpret_cast<const f32x4*>(sbet + wave * WCOLS + c * 4);
-                f32x4 y;
+                if (FULL || r < nvalid) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
+            }
+            if (ln.gamma) {
+                bf16* yrow = ln.y16 + (size_t)row0 * H + wave * WCOLS;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - m) * rs * gm[e] + bt[e];
-                if (r < nvalid && st_on) *reinterpret_cast<bf16x4*>(yrow + (size_t)r * H + c * 4) = cvt4(y);
+                for (int j = 0; j < NLD; ++j) {
+                    const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+                    const float m = lnred[128 + wave * 32 + 2 * r], rs = lnred[128 + wave * 32 + 2 * r + 1];
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(sgam + wave * WCOLS + c * 4);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(sbet + wave * WCOLS + c * 4);
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - m) * rs * gm[e] + bt[e];
+                    if (FULL || r < nvalid) *reinterpret_cast<bf16x4*>(yrow + (size_t)r * H + c * 4) = cvt4(y);
+                }
+                if (wave == 0 && g == 0 && (FULL || i16 < nvalid) && ln.stats) {
+                    ln.stats[2 * (size_t)(row0 + i16)] = mean;
+                    ln.stats[2 * (size_t)(row0 + i16) + 1] = rstd;
+                }
             }
-            if (wave == 0 && g == 0 && i16 < nvalid && ln.stats && st_on) {
-                ln.stats[2 * (size_t)(row0 + i16)] = mean;
-                ln.stats[2 * (size_t)(row0 + i16) + 1] = rstd;
-            }
+        };
+        if (st_on) {
+            if (nvalid == 16) emit(std::true_type{});
+            else emit(std::false_type{});
         }
         __syncthreads();                       // every wave: next tile visible, this buffer consumed
         if (t + 2 * tstep < ntiles && !(dbg & 4)) {
@@ -737,25 +755,32 @@ __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float*
         }
         FD_WAIT_VM0();                         // next tile's DMA has landed; no store is issued before this point
         const bool st_on = !(dbg & 1);
-        if (exp_z && i16 < nvalid && st_on) {
-            *reinterpret_cast<f32x4*>(z_out + (size_t)(row0 + i16) * R + wave * 16 + 4 * g) = z_keep;
-            *reinterpret_cast<f32x4*>(dz_out + (size_t)(row0 + i16) * R + wave * 16 + 4 * g) = dz_keep;
-        }
-        if (dx) {
-            float* orow = dx + (size_t)row0 * H + wave * WCOLS;
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
-                if (r < nvalid && st_on) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
+        auto emit = [&](auto full_tag) {        // full tiles: no per-access predicates (see ws_fwd_body)
+            constexpr bool FULL = decltype(full_tag)::value;
+            if (exp_z && (FULL || i16 < nvalid)) {
+                *reinterpret_cast<f32x4*>(z_out + (size_t)(row0 + i16) * R + wave * 16 + 4 * g) = z_keep;
+                *reinterpret_cast<f32x4*>(dz_out + (size_t)(row0 + i16) * R + wave * 16 + 4 * g) = dz_keep;
             }
-            if (dx16) {
-                bf16* brow = dx16 + (size_t)row0 * H + wave * WCOLS;
+            if (dx) {
+                float* orow = dx + (size_t)row0 * H + wave * WCOLS;
 #pragma unroll
                 for (int j = 0; j < NLD; ++j) {
                     const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
-                    if (r < nvalid && st_on) *reinterpret_cast<bf16x4*>(brow + (size_t)r * H + c * 4) = cvt4(v[j]);
+                    if (FULL || r < nvalid) *reinterpret_cast<f32x4*>(orow + (size_t)r * H + c * 4) = v[j];
+                }
+                if (dx16) {
+                    bf16* brow = dx16 + (size_t)row0 * H + wave * WCOLS;
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) {
+                        const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+                        if (FULL || r < nvalid) *reinterpret_cast<bf16x4*>(brow + (size_t)r * H + c * 4) = cvt4(v[j]);
+                    }
                 }
             }
+        };
+        if (st_on) {
+            if (nvalid == 16) emit(std::true_type{});
+            else emit(std::false_type{});
         }
         __syncthreads();                       // every wave: next tile visible, this buffer consumed
         if (t + 2 * tstep < ntiles && !(dbg & 4)) {

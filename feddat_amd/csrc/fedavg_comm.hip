@@ -15,6 +15,8 @@ typedef int (*GetUniqueIdFn)(ncclUniqueId_*);
 typedef int (*CommInitRankFn)(void**, int, ncclUniqueId_, int);
 typedef int (*CommDestroyFn)(void*);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, void*, hipStream_t);
+typedef int (*GetVersionFn)(int*);
+typedef int (*CommQueryFn)(void*, int*);
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;
 
 struct Rccl {
@@ -23,6 +25,8 @@ struct Rccl {
     CommInitRankFn init_rank = nullptr;
     CommDestroyFn destroy = nullptr;
     AllReduceFn all_reduce = nullptr;
+    GetVersionFn get_version = nullptr;      // optional (diagnostics only)
+    CommQueryFn comm_count = nullptr, comm_user_rank = nullptr;
     bool ok = false;
 };
 Rccl g_rccl;
@@ -39,6 +43,9 @@ const Rccl& rccl() {
         g_rccl.init_rank = (CommInitRankFn)dlsym(g_rccl.h, "ncclCommInitRank");
         g_rccl.destroy = (CommDestroyFn)dlsym(g_rccl.h, "ncclCommDestroy");
         g_rccl.all_reduce = (AllReduceFn)dlsym(g_rccl.h, "ncclAllReduce");
+        g_rccl.get_version = (GetVersionFn)dlsym(g_rccl.h, "ncclGetVersion");
+        g_rccl.comm_count = (CommQueryFn)dlsym(g_rccl.h, "ncclCommCount");
+        g_rccl.comm_user_rank = (CommQueryFn)dlsym(g_rccl.h, "ncclCommUserRank");
         g_rccl.ok = g_rccl.get_id && g_rccl.init_rank && g_rccl.destroy && g_rccl.all_reduce;
     });
     return g_rccl;
@@ -66,6 +73,25 @@ extern "C" int feddat_comm_destroy(void* comm) {
     const Rccl& r = rccl();
     if (!r.ok) return FEDDAT_ELAUNCH;
     return r.destroy(comm) == 0 ? FEDDAT_OK : FEDDAT_ELAUNCH;
+}
+
+extern "C" int feddat_comm_info(void* comm, int* rccl_version, int* n_ranks, int* rank) {
+    const Rccl& r = rccl();
+    if (!r.ok) return FEDDAT_ELAUNCH;
+    if (rccl_version) {
+        *rccl_version = 0;
+        if (r.get_version && r.get_version(rccl_version) != 0) return FEDDAT_ELAUNCH;
+    }
+    if (n_ranks || rank) FD_CHECK_ARG(comm);
+    if (n_ranks) {
+        *n_ranks = 0;
+        if (r.comm_count && r.comm_count(comm, n_ranks) != 0) return FEDDAT_ELAUNCH;
+    }
+    if (rank) {
+        *rank = -1;
+        if (r.comm_user_rank && r.comm_user_rank(comm, rank) != 0) return FEDDAT_ELAUNCH;
+    }
+    return FEDDAT_OK;
 }
 
 extern "C" int feddat_fedavg_allreduce(void* comm, float* flat, float* scratch, long n, float num, float total,

@@ -63,6 +63,7 @@ _SIGS = {
     "feddat_comm_create": [vp, i32, i32, C.POINTER(vp)],
     "feddat_comm_destroy": [vp],
     "feddat_fedavg_allreduce": [vp, vp, vp, i64, f32, f32, vp],
+    "feddat_comm_info": [vp, vp, vp, vp],
     "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
     "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
     "feddat_gemm_fp8_nt": [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp],
@@ -149,7 +150,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes", "_table_entries")) else i32
-    if lib.feddat_abi_version() != 3:
+    if lib.feddat_abi_version() != 4:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
     if os.environ.get("FEDDAT_GEMM_DEBUG"):       # tools/ ablations: the env var is read HERE, never by the library
         lib.feddat_set_debug_flags(int(os.environ["FEDDAT_GEMM_DEBUG"]))
@@ -204,6 +205,12 @@ class RcclComm:
         _dev(flat, scratch)
         _chk(load().feddat_fedavg_allreduce(self._h, _p(flat), _p(scratch), flat.numel(), float(num), float(total),
                                             _stream()), "feddat_fedavg_allreduce")
+
+    def info(self):
+        """{'rccl_version': ncclGetVersion code, 'ranks': ranks of the communicator, 'rank': this rank} from the library."""
+        v, n, r = C.c_int(0), C.c_int(0), C.c_int(0)
+        _chk(load().feddat_comm_info(self._h, C.byref(v), C.byref(n), C.byref(r)), "feddat_comm_info")
+        return {"rccl_version": v.value, "ranks": n.value, "rank": r.value}
 
     def close(self):
         if self._h:

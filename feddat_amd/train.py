@@ -232,6 +232,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--albef_dims", type=str, default="",
                    help="ALBEF only: override depths for quick runs, e.g. vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2")
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
+    p.add_argument("--exchange", default="rccl_cabi", choices=["rccl_cabi", "torch"],
+                   help="the round's FedAvg collective: rccl_cabi = feddat_fedavg_allreduce on a communicator made through "
+                        "the C ABI (RCCL bound by dlopen; also taken with ONE rank, where it is the identity); torch = "
+                        "torch.distributed all_reduce (always used when the process group is not RCCL, i.e. the gloo test rigs)")
     p.add_argument("--save_every", type=int, default=0,
                    help="write <output_dir>/round state every N rounds (0 = never, like the reference); "
                         "--checkpoint <dir> resumes from it")
@@ -303,6 +307,14 @@ def main(argv=None):
             if t in my_tasks}
     server_flat = eng.comm_flat().clone()
     acc = torch.zeros_like(server_flat)
+    # the exchange: one C-ABI collective per round (main.py:510 get_average_net -> feddat_fedavg_allreduce); the local
+    # pre-sum below has already applied num / total, so the collective runs with num = total = 1 (a plain SUM)
+    comm, comm_scratch = None, None
+    if args.exchange == "rccl_cabi" and (world == 1 or dist.get_backend() == "nccl"):
+        from .fedavg import make_rccl_comm
+        comm = make_rccl_comm(world, rank) if world > 1 else L.RcclComm(1, 0, lambda ident: ident)
+        comm_scratch = torch.empty_like(acc)
+        log.info("FedAvg exchange: feddat_fedavg_allreduce, %s", comm.info())
     comm_names = model.comm_state_dict_names
     first_round = 0
     # requires_grad flags of the SERVER model.  Clients train on deepcopy(server) (main.py:472), so whatever train_step
@@ -331,8 +343,10 @@ def main(argv=None):
             L.fedavg_accumulate(acc, eng.comm_flat(), 1.0, float(len(tasks)), k == 0)
         if not my_tasks:
             acc.zero_()
-        if world > 1:
-            all_reduce_sum(acc)             # RCCL over xGMI, in place on the 3.58 MB device buffer
+        if comm is not None:
+            comm.fedavg_allreduce(acc, comm_scratch, 1.0, 1.0)      # RCCL over xGMI on the 3.58 MB device buffer
+        elif world > 1:
+            all_reduce_sum(acc)
         server_flat.copy_(acc)
         if args.save_every and ((comm_round + 1) % args.save_every == 0 or comm_round == args.comm_rounds - 1):
             from . import checkpoint
@@ -364,6 +378,10 @@ def main(argv=None):
             server_flags.update({0: False, 1: True})
     eng.comm_flat().copy_(server_flat)
     eng.repack_adapter(1)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
+    model.exchange_used = "feddat_fedavg_allreduce" if comm is not None else ("torch.distributed" if world > 1 else "none")
     if world > 1:
         dist.destroy_process_group()
     return model

@@ -29,7 +29,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_EINVAL 1
 #define FEDDAT_ELAUNCH 2
 
-#define FEDDAT_ABI_VERSION 3   /* 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
+#define FEDDAT_ABI_VERSION 4   /* 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -439,6 +439,10 @@ int feddat_comm_unique_id(void* id_128_bytes);
 int feddat_comm_create(const void* id_128_bytes, int world, int rank, void** comm_out);
 int feddat_comm_destroy(void* comm);
 int feddat_fedavg_allreduce(void* comm, float* flat, float* scratch, long n, float num, float total, hipStream_t stream);
+/* What the communicator is: the RCCL version the library bound at run time (ncclGetVersion code, e.g. 22105 = 2.21.5),
+ * the number of ranks the communicator spans and this process's rank in it.  Any out pointer may be NULL; comm may be
+ * NULL when only the version is asked for.  (bench.py prints these next to the N > 1 line.) */
+int feddat_comm_info(void* comm, int* rccl_version, int* n_ranks, int* rank);
 
 /* ---------------------------------------------------------------------------------------------
  * hardware-semantics probes used by tests/ (MFMA operand pairing, ds_read_b64_tr_b16 layout)

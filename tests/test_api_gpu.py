@@ -16,8 +16,8 @@ DEV = "cuda"
 def api():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    from feddat_amd import modeling, train
-    return types.SimpleNamespace(modeling=modeling, train=train)
+    from feddat_amd import lib, modeling, train
+    return types.SimpleNamespace(modeling=modeling, train=train, L=lib)
 
 
 def _dev(b):
@@ -164,6 +164,24 @@ def test_main_rounds_and_resume(api, tmp_path):
         pa = load_file(str(tmp_path / "a" / f"personal_{t}.safetensors"))
         pb = load_file(str(tmp_path / "b2" / f"personal_{t}.safetensors"))
         assert pa.keys() == pb.keys() and all(torch.equal(pa[k], pb[k]) for k in pa), t
+
+
+def test_main_default_exchange_is_the_c_abi_collective(api, tmp_path):
+    """train.main with one rank: the round's FedAvg goes through feddat_fedavg_allreduce on a communicator made by
+    feddat_comm_* (RCCL, one rank: the identity) -- the default exchange, not torch.distributed -- and gives the bits of
+    --exchange torch (no collective at world 1)."""
+    common = ["--ordered_cl_tasks", "art,gqa", "--num_layers", "2", "--image_size", "224", "--batch_size", "2",
+              "--synthetic_steps", "2", "--no_hip_graph", "--comm_rounds", "2"]
+    a = api.train.main(common)
+    assert a.exchange_used == "feddat_fedavg_allreduce"
+    sd_a = {k: v.clone() for k, v in a.state_dict().items()}
+    b = api.train.main(common + ["--exchange", "torch"])
+    assert b.exchange_used == "none"
+    sd_b = b.state_dict()
+    for n in a.comm_state_dict_names:
+        assert torch.isfinite(sd_a[n]).all() and torch.equal(sd_a[n], sd_b[n]), n
+    info = api.L.RcclComm(1, 0, lambda ident: ident).info()
+    assert info["ranks"] == 1 and info["rank"] == 0 and info["rccl_version"] > 20000, info
 
 
 def test_device_prefetcher_matches_synchronous_upload(api):

@@ -597,8 +597,10 @@ def test_adapter_fwd_with_fused_layernorm(L, golden_dir):
     L.adapter_fwd_ln(x, out_b, segs, T, gamma, beta, 1e-12, y_b, st_b)
     assert torch.equal(out_a, out_b)
     assert (st_a - st_b).abs().max() < 1e-4 * st_a.abs().max()
-    dy_ = (y_a.float() - y_b.float()).abs()                              # at most one bf16 ulp (summation order of the stats)
-    assert bool((dy_ <= torch.maximum(y_a.float().abs(), y_b.float().abs()) * 2 ** -7 + 1e-30).all())
+    # at most one bf16 ulp (the fused kernel combines per-wave (mean, M2) pairs, the stand-alone one sums all 768 columns in
+    # two passes: mean / rstd agree to ~1e-7 relative), or 1e-5 absolute where (x - mean) rstd gamma + beta cancels to ~0
+    dy_ = (y_a.float() - y_b.float()).abs()
+    assert bool((dy_ <= torch.maximum(y_a.float().abs(), y_b.float().abs()) * 2 ** -7 + 1e-5).all())
     assert ((y_a.float() - y_b.float()).abs() > 0).float().mean() < 0.02
 
 

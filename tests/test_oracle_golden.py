@@ -175,3 +175,22 @@ def test_g8_oracle_reproduces_reference_round_of_40_steps(golden_dir):
     for k in [k.split("::", 1)[1] for k in g if k.startswith("dsamp::")]:
         mx, mean, ref_mean, dnorm = delta_vs_golden(g, k, P[k] - init[k])
         assert mx < 3e-5 and mean < 0.01 * ref_mean, (k, mx, mean, ref_mean)
+
+
+def test_g8_oracle_reproduces_reference_round_of_80_steps(golden_dir):
+    """The longest round configs[2] names: len(loader) = 80 (1200 scheduler ticks, warm-up 60 batches, 20 batches at full
+    lr; the weights move up to ~5e-3).  The oracle against the reference's own run -- this is what allows the GPU test
+    (tests/test_round40_gpu.py::test_round_of_80_steps_*) to take the live oracle as the full-tensor reference."""
+    from tests.golden_util import delta_vs_golden
+    g = load(golden_dir, "g8_round80.npz")
+    steps = int(g["steps"])
+    assert steps == 80
+    d = O.ViltDims(layers=12)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    init = {k: v.clone() for k, v in P.items()}
+    c = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=steps)
+    losses = [float(c.train_step(O.synthetic_batch(4, 384, 8000 + s))[0]) for s in range(steps)]
+    assert np.abs(np.array(losses) - g["losses"]).max() < 1e-3
+    for k in [k.split("::", 1)[1] for k in g if k.startswith("dsamp::")]:
+        mx, mean, ref_mean, dnorm = delta_vs_golden(g, k, P[k] - init[k])
+        assert mx < 6e-5 and mean < 0.01 * ref_mean, (k, mx, mean, ref_mean)

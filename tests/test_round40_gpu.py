@@ -62,6 +62,63 @@ def test_realistic_round_40_steps_vs_reference_golden(engine, golden_dir):
     print(f"40-step round: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f}, worst norm ratio {worst_norm:.4f}")
 
 
+@pytest.fixture(scope="module")
+def round80(engine, golden_dir):
+    """One 80-step round (configs[2]'s longest len(loader)) of the 12-layer model on the engine (hipGraph replay) and,
+    batch for batch, on the CPU oracle (which reproduces the reference's own 80-step run to < 6e-5:
+    tests/test_oracle_golden.py::test_g8_oracle_reproduces_reference_round_of_80_steps).  -> per-tensor errors of the
+    UPDATE over ALL elements vs the oracle, and over the fixture's samples vs the reference."""
+    g = load(golden_dir, "g8_round80.npz")
+    steps = int(g["steps"])
+    d = O.ViltDims(layers=12)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    P0 = {k: v.clone() for k, v in P.items()}
+    eng = engine.ViltDatEngine(P, ["art"], DEV, batch=4, res=384, layers=12)
+    eng.begin_local_update("art", steps_per_epoch=steps)
+    client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=steps)
+    torch.set_num_threads(min(torch.get_num_threads(), 32))
+    losses = []
+    for s in range(steps):
+        b = O.synthetic_batch(4, 384, 8000 + s)
+        client.train_step(b)
+        losses.append(float(eng.train_step(_dev(b), use_graph=True)[0]))
+    sd = eng.state_dict()
+    rows = {}
+    for k in [k.split("::", 1)[1] for k in g if k.startswith("dsamp::")]:
+        d_ref, d_got = P[k] - P0[k], sd[k].cpu() - P0[k]
+        err = (d_got - d_ref).abs()
+        smx, smean, ref_mean, dnorm = delta_vs_golden(g, k, d_got)
+        rows[k] = dict(max=float(err.max()), ratio=float(err.mean()) / float(d_ref.abs().mean()), samp_max=smx,
+                       samp_ratio=smean / ref_mean, norm_ratio=dnorm / float(g["dnorm::" + k]),
+                       share_gt_5e4=float((err > 5e-4).float().mean()), moved=float(d_ref.abs().max()))
+    return dict(rows=rows, losses=np.array(losses), ref_losses=g["losses"])
+
+
+def test_round_of_80_steps_measured_bound(round80):
+    """What the bf16 path delivers at the longest round length, asserted so that a regression fails: per tensor, on the
+    update, mean |ddW| <= 0.06 mean |dW| (measured 0.038), update norm within 3 %, max |ddW| < 2.0e-3 (measured 1.5e-3: above
+    the north-star's 1e-3, see the strict xfail below), at most 0.3 % of a tensor's elements off by more than 5e-4, loss
+    trajectory within 5 %.  The reference moves these weights by up to 5e-3 over the round."""
+    rows = round80["rows"]
+    rel = np.abs(round80["losses"] - round80["ref_losses"]) / np.maximum(round80["ref_losses"], 1.0)
+    assert rel[:10].max() < 3e-3 and rel.max() < 5e-2
+    worst = {m: max(r[m] for r in rows.values()) for m in ("max", "ratio", "samp_max", "samp_ratio", "norm_ratio", "share_gt_5e4")}
+    print("80-step round:", {k: float(f"{v:.3g}") for k, v in worst.items()})
+    assert max(r["moved"] for r in rows.values()) > 3e-3               # the round really moves the weights
+    for k, r in rows.items():
+        assert r["max"] < 2.0e-3 and r["samp_max"] < 2.0e-3, (k, r)
+        assert r["ratio"] < 0.06 and r["samp_ratio"] < 0.08, (k, r)
+        assert r["norm_ratio"] < 0.03 and r["share_gt_5e4"] < 3e-3, (k, r)
+
+
+@pytest.mark.xfail(strict=True, reason="north_star: max |ddW| < 1e-3 after one FL round.  Holds up to ~55 steps; at 80 steps the "
+                   "bf16 path measures 1.2-1.5e-3.  tools/rounding_site_rank.py (DESIGN.md section 5): EVERY bf16 rounding site alone "
+                   "-- frozen weights, LN outputs, qkv, probabilities, gelu(u), the backward's dY copies -- reproduces the full "
+                   "error, so no single site can be promoted to close it; 10 mantissa bits everywhere would")
+def test_round_of_80_steps_north_star_target(round80):
+    assert max(r["max"] for r in round80["rows"].values()) < 1e-3
+
+
 def test_full_size_step_b32_vs_oracle(engine):
     B, res = 32, 384
     d = O.ViltDims(layers=12)

@@ -21,7 +21,7 @@ _SKIP = {"load", "make_segs", "make_wgrad_segs", "adapter_wgrad_workspace_elems"
 
 def measure(eng, L, batches, steps=3, detail=True, plug_s=0.03):
     """-> (agg: key -> [launches per step, ms per step (bracket overhead removed)], eager step ms, empty bracket us).
-    GEMM keys (detail): ('gemm', M, N, K, epi, skinny)."""
+    GEMM keys (detail): ('gemm', M, N, K, epi, skinny); general attention: ('attn2_fwd' | 'attn2_bwd', B, Sq, Skv, heads, causal)."""
     names = [n for n in dir(L) if callable(getattr(L, n)) and not n.startswith("_") and n not in _SKIP
              and getattr(getattr(L, n), "__module__", "") == L.__name__ and n[0].islower()]
     orig = {n: getattr(L, n) for n in names}
@@ -40,6 +40,10 @@ def measure(eng, L, batches, steps=3, detail=True, plug_s=0.03):
                 A, B, epi = a[0], a[1], a[2]
                 M = k.get("M") or A.shape[0]
                 key = ("gemm", M, B.shape[0], A.shape[1], epi, bool(k.get("skinny_workspace") is not None and M <= 64))
+            elif n == "attn2_fwd" and detail:        # (name, B, Sq, Skv, heads, causal)
+                key = (n, a[5], a[6], a[7], a[8], bool(k.get("causal", False)))
+            elif n == "attn2_bwd" and detail:
+                key = (n, a[10], a[11], a[12], a[13], bool(k.get("causal", False)))
             rec.append((key, e0, e1))
             return r
         return g
