@@ -1217,6 +1217,9 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         a2.dbg = dbg;
         int n_cu = 0;
         if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+        // tools/overlap_probe.py: bits 28..31 of the debug flags cap the persistent grid at 16 x value workgroups, so that a
+        // launch on a side stream leaves compute units to the kernels of the main stream
+        if (const int cap16 = (dbg >> 28) & 0xf) n_cu = n_cu < cap16 * 16 ? n_cu : cap16 * 16;
         const int tiles_n = N / V2_BN;
         // balanced M tiles of <= BM rows; XCD-aware tile order: split the XCDs over N as well when B (N x K bf16) would
         // not stay in a 4 MiB L2 and the launch takes more than one round of tiles

@@ -19,6 +19,7 @@ params = vilt_spec.random_init(12, ["c0"], seed=0, device="cpu")
 class Probe(engine.ViltDatEngine):
     side_work = False
     join_late = False
+    cap16 = 0          # persistent GEMM grids of the side work capped at 16 x cap16 workgroups (0 = all CUs)
 
     def _step_kernels(self):
         if not self.side_work:
@@ -32,10 +33,12 @@ class Probe(engine.ViltDatEngine):
         side = self._side
         side.wait_stream(cur)
         with torch.cuda.stream(side):              # stand-in for the next batch's embeddings + layer-0 body
+            L.set_debug_flags(self.cap16 << 28)
             self._embed()
             l0 = self.l0
             self._layer_body(0, self.h0, self.R, B, l0["qkv"], l0["ctx"], l0["lse"], l0["h2"], l0["h3"], st1=self.st0,
                              st2=self.st0, mask=self.key_mask2[:B])
+            L.set_debug_flags(0)
         pooled_g, pooled_s = self.pooled[:B], self.pooled[B:]
         logits_both = self._head_fwd(self.pooled[:2 * B], "both", task)
         logits_all, logits_1 = logits_both[:B], logits_both[B:]
@@ -63,9 +66,9 @@ class Probe(engine.ViltDatEngine):
         L.step_tick(self.ad[0].state, 2, 1)
 
 
-def run(side, late):
+def run(side, late, cap16=0):
     eng = Probe(params, ["c0"], dev, batch=32, res=384, layers=12)
-    eng.side_work, eng.join_late = side, late
+    eng.side_work, eng.join_late, eng.cap16 = side, late, cap16
     eng.begin_local_update("c0", steps_per_epoch=400)
     b = vilt_spec.synthetic_batch(32, 384, 7, device=dev)
     for _ in range(5):
@@ -78,6 +81,13 @@ def run(side, late):
     return (time.perf_counter() - t0) / 100 * 1e3
 
 
-for name, side, late in (("as built", False, False), ("+ layer-0 body on a side stream, joined before the backward", True, False),
-                         ("+ layer-0 body on a side stream, joined after the backward", True, True), ("as built", False, False)):
-    print(f"{name:70s} {run(side, late):.3f} ms/step")
+for name, side, late, cap in (("as built", False, False, 0),
+                              ("+ layer-0 body on a side stream, joined before the backward", True, False, 0),
+                              ("+ the same, its GEMM grids capped at 224 workgroups", True, False, 14),
+                              ("+ the same, capped at 192", True, False, 12),
+                              ("+ the same, capped at 128", True, False, 8),
+                              ("+ the same, capped at 64", True, False, 4),
+                              ("+ layer-0 body on a side stream, joined after the backward", True, True, 0),
+                              ("+ the same, capped at 128", True, True, 8),
+                              ("as built", False, False, 0)):
+    print(f"{name:70s} {run(side, late, cap):.3f} ms/step", flush=True)
