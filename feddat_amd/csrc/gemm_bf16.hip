@@ -776,7 +776,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// v3 (experimental, debug flag 1): ONE wave per SIMD.  192 x 192 x 64 tile, 4 waves (2 x 2, 96 x 96 per wave = 6 x 6
+// v3 (the default for the plain and residual epilogues; debug flag 1 keeps everything on v2, flag 2 forces v3): ONE wave per SIMD.  192 x 192 x 64 tile, 4 waves (2 x 2, 96 x 96 per wave = 6 x 6
 // MFMA tiles: 72 MFMAs per 24 fragment reads), persistent blocks and the continuous k-tile stream of v2.  The
 // accumulators are pinned to AGPRs by issuing the MFMA as inline asm ("+a"): with the builtin hipcc parked part of the
 // 144 accumulator registers in other registers and moved them around every MFMA.  Every MFMA is followed by exactly one
@@ -810,7 +810,12 @@ template <int RT> struct V3Cfg {
     static constexpr int NP = RT + 6;                         // staging pieces per wave and k-tile (A: RT, B: 6)
 };
 
-template <int EPI, int RT>
+// FAKE = 1 (tools/ timing probe, debug flag 512; results are WRONG): no epilogue at the tile boundary; instead every k-tile
+// issues, between the MFMAs of its second half, the share of an epilogue a DEFERRED form would issue there -- 3 of the 36
+// sub-tiles' conversions / activation math and their 8-byte row-per-lane stores (inline asm: invisible to hipcc's vmcnt
+// bookkeeping, so the staging loads keep their counted waits) plus the aux / residual loads.  Answers one question before
+// the real thing is built: does the k-loop absorb the epilogue's issue slots and stores?
+template <int EPI, int RT, int FAKE = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     using Cfg = V3Cfg<RT>;
     constexpr int NP = Cfg::NP, NM = 6 * RT;                  // MFMAs per k-half
@@ -897,8 +902,32 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) read_frag(0, 0, q);
 
+    auto fake_slice = [&](const int sidx, const int kt) {       // FAKE only: sub-tile (2 sidx, sidx) stands in for slice kt
+        const int row = min(m0 + wm * (16 * RT) + 32 * sidx + frow, g.M - 1);
+        const int col = n0 + wn * 96 + 16 * (kt % 6) + 4 * fg;
+        f32x4 v = acc[2 * sidx][sidx];
+        if (EPI == FEDDAT_EPI_RESID_F32 || EPI == FEDDAT_EPI_F32) {
+            if (EPI == FEDDAT_EPI_RESID_F32) v = v + *reinterpret_cast<const f32x4*>(g.resid + (size_t)row * g.ldr + col);
+            const float* dst = g.out_f32 + (size_t)row * g.ldo32 + col;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+            return;
+        }
+        if (EPI == FEDDAT_EPI_MUL_DGELU) {
+            const bf16x4 u4 = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+            v = v * gelu_grad4_pk(f32x4{(float)u4[0], (float)u4[1], (float)u4[2], (float)u4[3]});
+        }
+        if (EPI == FEDDAT_EPI_GELU) {
+            const bf16x4 u16 = cvt4(v);
+            const bf16* dst2 = g.out2_bf16 + (size_t)row * g.ldo2 + col;
+            asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(dst2), "v"(u16) : "memory");
+            v = gelu4_pk(v);
+        }
+        const bf16x4 o16 = cvt4(v);
+        const bf16* dst = g.out_bf16 + (size_t)row * g.ldo16 + col;
+        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(o16) : "memory");
+    };
     // one k-tile; FIRST: the tile's first k-tile, whose half 0 starts the accumulators from the constant 0
-    auto k_tile = [&](auto first_tag, const int st) {
+    auto k_tile = [&](auto first_tag, const int st, const int kt = 0) {
         constexpr bool FIRST = decltype(first_tag)::value;
         // ---- half 0: MFMA (i, j) then filler #(6 i + j): NP fragment reads, then per piece its write and its reload
 #pragma unroll
@@ -930,6 +959,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
                 const int f = 6 * i + j;
                 __builtin_amdgcn_sched_barrier(0);
                 if (f >= 12 && f < 12 + NP) read_frag(st ^ 1, 0, f - 12);
+                if (FAKE && RT == 6 && (f == 28 || f == 30 || f == 32) && kt < 12) fake_slice((f - 28) / 2, kt);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
@@ -937,16 +967,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     char* stg = smem + Cfg::EPI_OFF + wave * V2_EPI_WAVE;
     int it = 0;
     for (int tile = 0; tile < my_tiles; ++tile) {
-        k_tile(std::true_type{}, it & 1);
+        k_tile(std::true_type{}, it & 1, 0);
         ++it;
-        for (int kt = 1; kt < nk; ++kt, ++it) k_tile(std::false_type{}, it & 1);
+        for (int kt = 1; kt < nk; ++kt, ++it) k_tile(std::false_type{}, it & 1, kt);
         // The compiler cannot see that the asm blocks are MFMAs: it would read their results right behind them.  The wait
         // states are attached to the accumulators themselves (in / out operands), row by row.
 #pragma unroll
         for (int i = 0; i < RT; ++i)
             asm volatile("s_nop 15\n\ts_nop 15"
                          : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
-        if (!(a.dbg & 8)) {
+        if (!(a.dbg & 8) && !FAKE) {
             const int mb = m0 + wm * (16 * RT), nb = n0 + wn * 96, me = m_last + 1;
             if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU)
                 v2_epilogue_bf16<EPI, RT, true>(g, acc, stg, mb, nb, me, lane);
@@ -1251,6 +1281,16 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         // nothing cache-warm, it is behind (86 / 89 us against 82 / 81: tools/step_breakdown.py --detail); debug flag 1
         // keeps everything on v2, flag 2 forces v3
         const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU;
+        if (dbg & 512) {        // tools/gemm_defer_probe.py: the deferred-epilogue timing probe (RT = 6; wrong results)
+            static const V2Kernel fk[5] = {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 6, 1>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 6, 1>,
+                                           gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 6, 1>, gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 6, 1>,
+                                           gemm_nt_v3_kernel<FEDDAT_EPI_F32, 6, 1>};
+            a2 = a3;
+            if (fd_set_max_lds((const void*)fk[epi], V3Cfg<6>::LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+            const int total3 = a2.tiles_m * (N / V2_BN);
+            hipLaunchKernelGGL(fk[epi], dim3(total3 < n_cu ? total3 : n_cu), dim3(256), V3Cfg<6>::LDS, stream, a2);
+            FD_LAUNCH_RET();
+        }
         if (((dbg & 2) || v3_pick) && !(dbg & 1)) {
             const bool rt8 = (dbg & 64) ? true : (dbg & 32) ? false : wm4;
             const V2Kernel k3 = v3_kernel_table()[rt8 ? 1 : 0][epi];

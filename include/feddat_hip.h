@@ -39,8 +39,11 @@ int feddat_abi_version(void);
  * it: create = switch to `device`, look up its CU count and set every kernel's attributes there (so that no later launch
  * pays for it, e.g. inside a stream capture); destroy frees only the handle.  The composite entry points
  * (feddat_vilt_layer_fwd/bwd) take a ctx.
- * feddat_set_debug_flags: GEMM ablation switches used by tools/ (8 = skip epilogue, 32/64 = force 192-/256-row tiles,
- * bits 8.. = cap on persistent blocks); process-wide, 0 by default, never read from the environment by the library.
+ * feddat_set_debug_flags: ablation switches used by tools/ only (GEMM: 1 / 2 = everything on the two-wave-group / the
+ * one-wave-per-SIMD kernel, 8 = skip epilogue, 32 / 64 = force 192- / 256-row tiles, 256 = K = 32 fp8 MFMA, 512 = deferred-
+ * epilogue timing probe, bits 28..31 = cap the persistent grid at 16 x value workgroups; adapters: bits 24..26).  The one piece
+ * of process-wide mutable state in the library: 0 by default, never read from the environment, and no production path sets
+ * it -- with flags = 0 every launch is a pure function of its arguments.
  * ------------------------------------------------------------------------------------------- */
 typedef struct feddat_ctx feddat_ctx;
 int feddat_ctx_create(int device, feddat_ctx** ctx);
@@ -53,8 +56,10 @@ int feddat_set_debug_flags(int flags);
  * Replaces the frozen nn.Linear calls inside HF ViltLayer (reference call site src/modeling/vilt.py:127;
  * FFN-out dense+residual: src/modeling/adaptered_output.py:74-76) and, with B = W^T, their dX-only
  * backward (autograd through frozen weights, src/train/visionlanguage_tasks/task_trainer.py:302,323).
- * Requirements: K % 64 == 0, lda/ldb % 8 == 0, and N % 192 == 0 with M >= 1024 (persistent ping-pong kernel, 192 x 192 or
- * 256 x 192 tiles chosen per shape) or else N % 128 == 0 (128 x 128 kernel).  Row strides (lda, ldr, ldo*) are in elements
+ * Requirements: K % 64 == 0, lda/ldb % 8 == 0, and N % 192 == 0 with M >= 1024 (the two persistent kernels, 192 x 192 or
+ * 256 x 192 tiles chosen per shape: one wave per SIMD with AGPR-pinned accumulators for the plain / residual epilogues, two
+ * ping-pong wave groups for the GELU and gelu' epilogues; bit-identical results) or else N % 128 == 0 (128 x 128 kernel),
+ * or M < 1024 with N % 64 == 0 (64 x 64 small-tile kernel).  Row strides (lda, ldr, ldo*) are in elements
  * and may exceed the row length (strided operands).
  * ------------------------------------------------------------------------------------------- */
 #define FEDDAT_EPI_BF16 0       /* out_bf16 = acc + bias                                    */
@@ -67,7 +72,8 @@ int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, i
                         int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream);
 /* configs[4]: fp8 (OCP e4m3) MFMA for frozen linears.  A8 [M,K] and B8 [N,K] are e4m3 with per-row scales (a_scale [M],
  * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias, epilogue BF16 or GELU as above).
- * Same persistent kernel and data movement as the bf16 form (128 fp8 per 128-byte LDS row), v_mfma_f32_16x16x32_fp8_fp8.
+ * Same persistent kernel and data movement as the bf16 form (128 fp8 per 128-byte LDS row); the MFMA is the CDNA4
+ * block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the bf16 rate).
  * Requirements: M >= 1024, N % 192 == 0, K % 128 == 0, lda / ldb % 16 == 0, 16-byte aligned outputs.
  * feddat_quant_rows_fp8: fp32 [rows, cols] -> e4m3 + per-row scale amax / 448 (weights at load time; any activation);
  * feddat_layernorm_fwd_fp8: LayerNorm whose output leaves as e4m3 + per-row scale (optionally also bf16). */
