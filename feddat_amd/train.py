@@ -309,12 +309,12 @@ def main(argv=None):
     acc = torch.zeros_like(server_flat)
     # the exchange: one C-ABI collective per round (main.py:510 get_average_net -> feddat_fedavg_allreduce); the local
     # pre-sum below has already applied num / total, so the collective runs with num = total = 1 (a plain SUM)
-    comm, comm_scratch = None, None
+    rccl, rccl_scratch = None, None
     if args.exchange == "rccl_cabi" and (world == 1 or dist.get_backend() == "nccl"):
         from .fedavg import make_rccl_comm
-        comm = make_rccl_comm(world, rank) if world > 1 else L.RcclComm(1, 0, lambda ident: ident)
-        comm_scratch = torch.empty_like(acc)
-        log.info("FedAvg exchange: feddat_fedavg_allreduce, %s", comm.info())
+        rccl = make_rccl_comm(world, rank) if world > 1 else L.RcclComm(1, 0, lambda ident: ident)
+        rccl_scratch = torch.empty_like(acc)
+        log.info("FedAvg exchange: feddat_fedavg_allreduce, %s", rccl.info())
     comm_names = model.comm_state_dict_names
     first_round = 0
     # requires_grad flags of the SERVER model.  Clients train on deepcopy(server) (main.py:472), so whatever train_step
@@ -343,8 +343,8 @@ def main(argv=None):
             L.fedavg_accumulate(acc, eng.comm_flat(), 1.0, float(len(tasks)), k == 0)
         if not my_tasks:
             acc.zero_()
-        if comm is not None:
-            comm.fedavg_allreduce(acc, comm_scratch, 1.0, 1.0)      # RCCL over xGMI on the 3.58 MB device buffer
+        if rccl is not None:
+            rccl.fedavg_allreduce(acc, rccl_scratch, 1.0, 1.0)      # RCCL over xGMI on the 3.58 MB device buffer
         elif world > 1:
             all_reduce_sum(acc)
         server_flat.copy_(acc)
@@ -378,10 +378,10 @@ def main(argv=None):
             server_flags.update({0: False, 1: True})
     eng.comm_flat().copy_(server_flat)
     eng.repack_adapter(1)
-    if comm is not None:
+    if rccl is not None:
         torch.cuda.synchronize()
-        comm.close()
-    model.exchange_used = "feddat_fedavg_allreduce" if comm is not None else ("torch.distributed" if world > 1 else "none")
+        rccl.close()
+    model.exchange_used = "feddat_fedavg_allreduce" if rccl is not None else ("torch.distributed" if world > 1 else "none")
     if world > 1:
         dist.destroy_process_group()
     return model
