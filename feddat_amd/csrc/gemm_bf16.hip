@@ -1160,16 +1160,19 @@ int fd_prepare_gemm_kernels() {
 // tile and k-tile, unit block scales, twice the bf16 rate (debug flag 256: the K = 32 fp8 instruction it replaced, which
 // issues at the bf16 rate) -- and the dequantising epilogue differ.
 extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb,
-                                  const float* b_scale, int M, int N, int K, int epi, const float* bias, void* out_bf16,
-                                  int ldo16, void* out2_bf16, int ldo2, hipStream_t stream) {
+                                  const float* b_scale, int M, int N, int K, int epi, const float* bias, const void* aux,
+                                  int ldaux, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream) {
     FD_CHECK_ARG(A8 && B8 && a_scale && b_scale && out_bf16 && M >= 1024 && N > 0 && N % V2_BN == 0 && K > 0 && K % 128 == 0);
-    FD_CHECK_ARG(epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU);
+    FD_CHECK_ARG(epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU);
+    FD_CHECK_ARG(epi != FEDDAT_EPI_MUL_DGELU || (aux && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0 &&
+                                                (size_t)M * ldaux * 2 < (1ull << 32)));
     FD_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
     FD_CHECK_ARG(!out2_bf16 || (ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0));
     GemmArgsV2 a2;
     GemmArgs& g = a2.g;
     g = GemmArgs{};
     g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.bias = bias; g.sa = a_scale; g.sw = b_scale;
+    g.aux = (const bf16*)aux; g.ldaux = ldaux;
     g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
     a2.dbg = fd_debug_flags() & 8;       // tools/ ablation: 8 = skip the epilogue (k-loop timing)
@@ -1192,11 +1195,13 @@ extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale,
     };
     GemmArgsV2 a3 = a2, a4 = a2;
     const int rounds3 = plan(192, a3), rounds4 = plan(256, a4);
-    const bool wm4 = rounds4 * 12 < rounds3 * 10;
+    const bool wm4 = rounds4 * 12 < rounds3 * 10 && epi != FEDDAT_EPI_MUL_DGELU;      // . gelu' stays on 192-row tiles (spills)
     a2 = wm4 ? a4 : a3;
     using KernelFn = void (*)(GemmArgsV2);
     KernelFn kern;
-    if (fd_debug_flags() & 256) {      // tools/ A/B only: the CDNA3-style K = 32 fp8 instruction (bf16 issue rate)
+    if (epi == FEDDAT_EPI_MUL_DGELU) {
+        kern = gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3, true>;
+    } else if (fd_debug_flags() & 256) {      // tools/ A/B only: the CDNA3-style K = 32 fp8 instruction (bf16 issue rate)
         if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, true>;
         else kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true, true>;
     } else if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true>;

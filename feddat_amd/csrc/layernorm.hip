@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
                                                         const float* __restrict__ stats,
                                                         const float* __restrict__ gamma, const float* __restrict__ dres,
                                                         long dres_stride, int rows, int H, float* __restrict__ out32,
-                                                        long out_stride, bf16* __restrict__ out16) {
+                                                        long out_stride, bf16* __restrict__ out16,
+                                                        unsigned char* __restrict__ out8 = nullptr,
+                                                        float* __restrict__ out8_scale = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -134,6 +136,28 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
             }
             if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)row * out_stride + i * 4) = o;
             if (out16) *reinterpret_cast<bf16x4*>(out16 + (size_t)row * H + i * 4) = cvt4(o);
+            gg[c] = o;
+        }
+    }
+    if (!out8) return;
+    // e4m3 copy with a per-row scale (configs[4]: the A operand of the fp8 dX product that follows), as in ln_fwd_kernel
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + c * 64 < nc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(gg[c][e]));
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) out8_scale[row] = sc;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(gg[c][0] * inv, gg[c][1] * inv, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(gg[c][2] * inv, gg[c][3] * inv, pk, true);
+            *reinterpret_cast<int*>(out8 + (size_t)row * H + i * 4) = pk;
         }
     }
 }
@@ -242,6 +266,22 @@ extern "C" int feddat_layernorm_bwd_dx(const void* dy_bf16, const float* dy_f32,
                        (bf16*)out_bf16)
     if (H <= 768) LN_BWD(3); else if (H <= 1536) LN_BWD(6); else LN_BWD(8);
 #undef LN_BWD
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_layernorm_bwd_dx_fp8(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x,
+                                           long x_stride, const float* stats, const float* gamma, const float* dres,
+                                           long dres_stride, int rows, int H, float* out_f32, long out_stride,
+                                           void* out_bf16, void* out_fp8, float* out_scale, hipStream_t stream) {
+    FD_CHECK_ARG((dy_bf16 != nullptr) != (dy_f32 != nullptr));
+    FD_CHECK_ARG(x && stats && gamma && rows > 0 && H > 0 && H % 4 == 0 && H <= 2048 && out_fp8 && out_scale);
+    FD_CHECK_ARG(dy_stride % 4 == 0 && x_stride % 4 == 0 && (!dres || dres_stride % 4 == 0) && (!out_f32 || out_stride % 4 == 0));
+#define LN_BWD8(MC)                                                                                               \
+    hipLaunchKernelGGL(ln_bwd_dx_kernel<MC>, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)dy_bf16, dy_f32, \
+                       dy_stride, x, x_stride, stats, gamma, dres, dres_stride, rows, H, out_f32, out_stride,          \
+                       (bf16*)out_bf16, (unsigned char*)out_fp8, out_scale)
+    if (H <= 768) LN_BWD8(3); else if (H <= 1536) LN_BWD8(6); else LN_BWD8(8);
+#undef LN_BWD8
     FD_LAUNCH_RET();
 }
 

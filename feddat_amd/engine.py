@@ -66,10 +66,12 @@ class ViltDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], tasks: Sequence[str], device, batch: int, res: int,
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
                  weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False):
-        """fp8=True (BASELINE.json configs[4]): the QKV and FFN1 products of the frozen backbone's FORWARD run on fp8 MFMA
-        (e4m3 weights with per-output-channel scales, quantised once here; activations quantised per token row by the
-        LayerNorm kernel that produces them); everything else -- adapters, attention, the other two linears whose inputs
-        are not LayerNorm outputs, the whole backward -- stays bf16 / fp32."""
+        """fp8=True (BASELINE.json configs[4]): four frozen products per layer run on the block-scaled fp8 MFMA with e4m3
+        operands -- forward QKV and FFN1 (activations quantised per token row by the LayerNorm kernel that produces them) and
+        the dX products FFN2^T and attention-output^T (the gradient rows quantised per row: by feddat_quant_rows_fp8 behind the
+        adapter backward, by the LayerNorm backward itself); weights quantised once here per output channel of each product.
+        Everything else -- adapters, attention, the products whose A operand comes out of a GEMM or attention epilogue --
+        stays bf16 / fp32."""
         L.load()
         self.dev = torch.device(device)
         self.tasks = list(tasks)
@@ -135,6 +137,9 @@ class ViltDatEngine:
             if self.fp8:
                 extra["wqkv8"], extra["sqkv"] = fp8_of(wqkv)
                 extra["w18"], extra["s1"] = fp8_of(w1)
+                # dX products whose A operand (a gradient) is produced by a row kernel: FFN2^T and attention-output^T
+                extra["w2T8"], extra["s2T"] = fp8_of(w2.t().contiguous())
+                extra["woT8"], extra["soT"] = fp8_of(wo.t().contiguous())
             self.layers.append(dict(
                 extra, wqkv=bf16_of(wqkv), wqkvT=bf16_T(wqkv), bqkv=bqkv,
                 wo=bf16_of(wo), woT=bf16_T(wo), bo=P(Lp + "attention.output.dense.bias"),
@@ -189,6 +194,8 @@ class ViltDatEngine:
         if self.fp8:                   # LN output as e4m3 + per-row scale (operand of the fp8 products)
             self.x8 = torch.empty(R2, H, dtype=torch.uint8, device=dev)
             self.xs = f32(R2)
+            self.g8 = torch.empty(R2, H, dtype=torch.uint8, device=dev)     # gradient rows as e4m3 + per-row scale
+            self.gsc = f32(R2)
         self.f16 = b16(R2, I)          # gelu(u), transient
         # layer 0 (shared body, R rows): only h3 is kept
         self.l0 = dict(qkv=b16(R, 3 * H), ctx=b16(R, H), lse=f32(B, self.heads, self.S), h2=f32(R, H), h3=f32(R, H))
@@ -544,6 +551,22 @@ class ViltDatEngine:
         for i in range(top - 1, 0, -1):
             # one C-ABI call per layer (feddat_vilt_layer_bwd): adapter backward + its weight gradients, FFN2^T (. gelu'),
             # FFN1^T, LN2 backward (+ residual), attention-out^T, attention backward, QKV^T, LN1 backward (+ residual)
+            if self._fp8_rows(R2):      # configs[4]: FFN2^T and attention-output^T on the fp8 MFMA, e4m3 gradient rows
+                a, W = self.act[i], self.layers[i]
+                L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, z_out=self.z, dz_out=self.dz,
+                              z_saved=self.zsave[i])
+                L.quant_rows_fp8(oth, self.g8, self.gsc)
+                self._adapter_wgrads(i, a["h3"], 0, cur)
+                L.gemm_fp8_nt(self.g8, self.gsc, W["w2T8"], W["s2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
+                L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
+                L.layernorm_bwd_dx_fp8(a["h2"], a["st2"], W["ln2g"], R2, H, self.g8, self.gsc, dy_bf16=self.dx16, dres=oth,
+                                       out_f32=cur)
+                L.gemm_fp8_nt(self.g8, self.gsc, W["woT8"], W["soT"], L.EPI_BF16, out_bf16=self.dctx)
+                L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=m2)
+                L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
+                L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
+                cur, oth = oth, cur
+                continue
             if not self.use_layer_calls:
                 a, W = self.act[i], self.layers[i]
                 L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,

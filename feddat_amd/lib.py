@@ -66,7 +66,8 @@ _SIGS = {
     "feddat_comm_info": [vp, vp, vp, vp],
     "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
     "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
-    "feddat_gemm_fp8_nt": [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp],
+    "feddat_gemm_fp8_nt": [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp],
+    "feddat_layernorm_bwd_dx_fp8": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp],
     "feddat_quant_rows_fp8": [vp, i64, i32, i32, vp, vp, vp],
     "feddat_layernorm_fwd_fp8": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
     "feddat_gemm_bf16_nt_skinny": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32,
@@ -271,14 +272,15 @@ def gemm_bf16_nt(A, B, epi, *, bias=None, resid=None, aux=None, out_f32=None, ou
     _chk(rc, "feddat_gemm_bf16_nt")
 
 
-def gemm_fp8_nt(A8, a_scale, B8, b_scale, epi, *, bias=None, out_bf16=None, out2_bf16=None):
-    """C = (A8 @ B8^T) * a_scale[:, None] * b_scale[None, :] (+ bias; epilogue EPI_BF16 or EPI_GELU); A8 / B8: e4m3 bytes as
-    uint8 / float8 tensors [M,K] / [N,K]."""
-    _dev(A8, B8, a_scale, b_scale, out_bf16)
+def gemm_fp8_nt(A8, a_scale, B8, b_scale, epi, *, bias=None, aux=None, out_bf16=None, out2_bf16=None):
+    """C = (A8 @ B8^T) * a_scale[:, None] * b_scale[None, :] (+ bias; epilogue EPI_BF16, EPI_GELU or EPI_MUL_DGELU with aux);
+    A8 / B8: e4m3 bytes as uint8 / float8 tensors [M,K] / [N,K]."""
+    _dev(A8, B8, a_scale, b_scale, out_bf16, aux)
     M, K = A8.shape
     N = B8.shape[0]
     _chk(load().feddat_gemm_fp8_nt(_p(A8), A8.stride(0), _p(a_scale), _p(B8), B8.stride(0), _p(b_scale), M, N, K, epi,
-                                   _p(bias), _p(out_bf16), out_bf16.stride(0), _p(out2_bf16),
+                                   _p(bias), _p(aux), 0 if aux is None else aux.stride(0), _p(out_bf16), out_bf16.stride(0),
+                                   _p(out2_bf16),
                                    0 if out2_bf16 is None else out2_bf16.stride(0), _stream()), "feddat_gemm_fp8_nt")
 
 
@@ -351,6 +353,15 @@ def layernorm_bwd_dx(x, stats, gamma, rows, H, *, dy_bf16=None, dy_f32=None, dy_
                                         H if dres_stride is None else dres_stride, rows, H, _p(out_f32),
                                         H if out_stride is None else out_stride, _p(out_bf16), _stream()),
          "feddat_layernorm_bwd_dx")
+
+
+def layernorm_bwd_dx_fp8(x, stats, gamma, rows, H, out_fp8, out_scale, *, dy_bf16=None, dy_f32=None, dres=None, out_f32=None,
+                         out_bf16=None):
+    """layernorm_bwd_dx whose result also leaves as e4m3 rows + per-row scale (the A operand of an fp8 dX product)."""
+    _dev(x, out_fp8, out_scale)
+    _chk(load().feddat_layernorm_bwd_dx_fp8(_p(dy_bf16), _p(dy_f32), H, _p(x), H, _p(stats), _p(gamma), _p(dres), H, rows, H,
+                                            _p(out_f32), H, _p(out_bf16), _p(out_fp8), _p(out_scale), _stream()),
+         "feddat_layernorm_bwd_dx_fp8")
 
 
 def layernorm_bwd_full(dy, x, stats, gamma, rows, H, dx, dgamma, dbeta):

@@ -71,14 +71,16 @@ int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, i
                         const float* bias, const float* resid, int ldr, const void* aux, int ldaux, float* out_f32,
                         int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream);
 /* configs[4]: fp8 (OCP e4m3) MFMA for frozen linears.  A8 [M,K] and B8 [N,K] are e4m3 with per-row scales (a_scale [M],
- * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias, epilogue BF16 or GELU as above).
+ * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias; epilogue BF16, GELU or MUL_DGELU (aux_bf16 =
+ * the saved pre-GELU u) as above -- the last one is the dX product of FFN2 with A8 = the e4m3 row-quantised gradient).
  * Same persistent kernel and data movement as the bf16 form (128 fp8 per 128-byte LDS row); the MFMA is the CDNA4
  * block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the bf16 rate).
  * Requirements: M >= 1024, N % 192 == 0, K % 128 == 0, lda / ldb % 16 == 0, 16-byte aligned outputs.
  * feddat_quant_rows_fp8: fp32 [rows, cols] -> e4m3 + per-row scale amax / 448 (weights at load time; any activation);
  * feddat_layernorm_fwd_fp8: LayerNorm whose output leaves as e4m3 + per-row scale (optionally also bf16). */
 int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb, const float* b_scale, int M,
-                       int N, int K, int epi, const float* bias, void* out_bf16, int ldo16, void* out2_bf16, int ldo2,
+                       int N, int K, int epi, const float* bias, const void* aux_bf16, int ldaux, void* out_bf16, int ldo16,
+                       void* out2_bf16, int ldo2,
                        hipStream_t stream);
 int feddat_quant_rows_fp8(const float* x, long ld, int rows, int cols, void* y_fp8, float* scale, hipStream_t stream);
 int feddat_layernorm_fwd_fp8(const float* x, long x_stride, const float* gamma, const float* beta, float eps, int rows,
@@ -150,6 +152,12 @@ int feddat_layernorm_fwd(const float* x, long x_stride, const float* gamma, cons
 int feddat_layernorm_bwd_dx(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x, long x_stride,
                             const float* stats, const float* gamma, const float* dres, long dres_stride, int rows,
                             int H, float* out_f32, long out_stride, void* out_bf16, hipStream_t stream);
+/* The same, its result additionally leaving as e4m3 rows + per-row scale (amax / 448): configs[4], the A operand of the
+ * fp8 dX product that follows (attention-output^T after layernorm_after's backward). */
+int feddat_layernorm_bwd_dx_fp8(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x, long x_stride,
+                                const float* stats, const float* gamma, const float* dres, long dres_stride, int rows, int H,
+                                float* out_f32, long out_stride, void* out_bf16, void* out_fp8, float* out_scale,
+                                hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  fused dual Pfeiffer adapter (the DAT module), src/modeling/models/adapter.py:124-163.

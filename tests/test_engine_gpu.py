@@ -253,11 +253,11 @@ def test_composite_layer_calls_equal_the_op_by_op_sequence(eng_mod):
 
 
 def test_fp8_forward_config4_stated_tolerances(eng_mod):
-    """BASELINE.json configs[4]: e4m3 MFMA for the QKV / FFN1 products of the frozen backbone's forward (per-row activation
-    scales, per-channel weight scales), bf16 adapters.  e4m3 has 3 mantissa bits: the stated tolerances are LOOSER than the
+    """BASELINE.json configs[4]: e4m3 MFMA for the forward QKV / FFN1 products and the dX products FFN2^T / attention-output^T
+    of the frozen backbone (per-row activation / gradient scales, per-channel weight scales), bf16 adapters.  e4m3 has 3 mantissa bits: the stated tolerances are LOOSER than the
     bf16 path's -- logits within 0.1 abs of the fp32 oracle (bf16 path: 3e-2; measured 0.043 vs 0.003), losses within 1 %
     (bf16: 0.2 %), and the adapter updates are compared with the bf16 engine's: mean |ddW| <= 0.3 mean |dW| and cosine > 0.9
-    per tensor (measured 0.134 / 0.954)."""
+    per tensor (measured 0.162 / 0.939)."""
     d = O.ViltDims(layers=4)
     B, res = 8, 384                                        # 2R = 2960 rows: the fp8 products are really taken
     P = O.make_params(d, ["art"], bias_std=0.02)

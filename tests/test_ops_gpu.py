@@ -795,7 +795,35 @@ def test_layernorm_fwd_fp8(L):
         (_fp8_deq(y8, sc) - ref).abs().max() < 0.07 * ref.abs().max()
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(11840, 2304, 768, 0), (11840, 3072, 768, 2), (5920, 3072, 768, 2), (1200, 192, 256, 0)])
+def test_layernorm_bwd_dx_fp8(L):
+    """The LayerNorm backward that also leaves its result as e4m3 rows + per-row scale: fp32 / bf16 outputs identical to the
+    plain entry point, the fp8 copy = torch's round-to-nearest e4m3 of out / (amax / 448)."""
+    rows, H = 1003, 768
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, H, generator=g).to(DEV)
+    dy = (torch.randn(rows, H, generator=g) * 1e-4).to(torch.bfloat16).to(DEV)
+    dres = (torch.randn(rows, H, generator=g) * 1e-4).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    st = torch.empty(rows, 2, device=DEV)
+    y = torch.empty(rows, H, dtype=torch.bfloat16, device=DEV)
+    L.layernorm_fwd(x, gamma, torch.zeros(H, device=DEV), 1e-12, rows, H, y_bf16=y, stats=st)
+    o_a, o_b = torch.empty(rows, H, device=DEV), torch.empty(rows, H, device=DEV)
+    L.layernorm_bwd_dx(x, st, gamma, rows, H, dy_bf16=dy, dres=dres, out_f32=o_a)
+    o8 = torch.empty(rows, H, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(rows, device=DEV)
+    L.layernorm_bwd_dx_fp8(x, st, gamma, rows, H, o8, sc, dy_bf16=dy, dres=dres, out_f32=o_b)
+    assert torch.equal(o_a, o_b)
+    amax = o_a.abs().amax(1)
+    assert torch.allclose(sc, amax / 448.0, rtol=1e-6)
+    # the kernel multiplies by 1 / scale, torch divides: codes may differ by one step at a rounding tie -> compare dequantised
+    deq = o8.view(torch.float8_e4m3fn).float() * sc[:, None]
+    assert bool(((deq - o_a).abs() <= amax[:, None] * (2.0 ** -4) + 1e-12).all())          # half a step of e4m3's 3-bit mantissa
+    same = (o8.view(torch.float8_e4m3fn).float() == (o_a / sc[:, None]).to(torch.float8_e4m3fn).float()).float().mean()
+    assert float(same) > 0.99
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(11840, 2304, 768, 0), (11840, 3072, 768, 2), (5920, 3072, 768, 2), (1200, 192, 256, 0),
+                                       (11840, 3072, 768, 3), (11849, 768, 768, 0), (1200, 384, 128, 3)])
 def test_gemm_fp8_vs_fp32_on_the_dequantised_operands(L, M, N, K, epi):
     """The kernel's own arithmetic: e4m3 x e4m3 products are exact in fp32, so against an fp32 product of the dequantised
     operands only the accumulation order and the bf16 output rounding differ."""
@@ -812,6 +840,12 @@ def test_gemm_fp8_vs_fp32_on_the_dequantised_operands(L, M, N, K, epi):
     if epi == 0:
         L.gemm_fp8_nt(A8, sa, W8, sw, L.EPI_BF16, bias=bias, out_bf16=out)
         assert rel_err(out, ref) < 1e-2
+    elif epi == 3:      # the dX product of FFN2: (dY W2) . gelu'(u), A8 = e4m3 gradient rows, no bias
+        aux = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+        L.gemm_fp8_nt(A8, sa, W8, sw, L.EPI_MUL_DGELU, aux=aux, out_bf16=out)
+        a32 = aux.float().requires_grad_(True)
+        F.gelu(a32).sum().backward()
+        assert rel_err(out, (ref - bias) * a32.grad) < 1e-2
     else:
         u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         L.gemm_fp8_nt(A8, sa, W8, sw, L.EPI_GELU, bias=bias, out_bf16=out, out2_bf16=u)

@@ -60,12 +60,13 @@ def test_b64_12_layers_two_steps_vs_oracle(engine):
 
 def test_fp8_b64_12_layers_vs_oracle(engine):
     """configs[4] at its own size against the fp32 ORACLE.  Stated tolerances of the fp8 path (e4m3 operands, 3 mantissa
-    bits, for the QKV and FFN1 products of all 12 layers; everything else as the bf16 path):
+    bits, for the forward QKV / FFN1 products and the dX products FFN2^T / attention-output^T of all 12 layers; everything else as
+    the bf16 path):
         logits          max |diff| < 0.12              (measured 0.069; bf16 path at this size: < 3e-2)
         losses          within 1.5 % per step          (bf16: 0.2 %)
         adapter / head  per tensor, on the UPDATE dW:  max |ddW| < 1e-3 (measured 3.9e-4: the north-star bound on the
-        update          weights still holds over two steps), mean |ddW| <= 0.2 mean |dW_ref| (measured 0.073; bf16 path
-                        0.011 on the same batches), cosine(dW, dW_ref) > 0.9 (measured 0.958)
+        update          weights still holds over two steps), mean |ddW| <= 0.2 mean |dW_ref| (measured 0.086; bf16 path
+                        0.011 on the same batches), cosine(dW, dW_ref) > 0.9 (measured 0.954)
     i.e. the direction of every update is the reference's, its element-wise noise is ~7x the bf16 path's."""
     B, res = 64, 384
     d = O.ViltDims(layers=12)
