@@ -644,15 +644,18 @@ __device__ __forceinline__ void ws_ztile_dma(const float* __restrict__ zs, int n
 }
 
 // Backward, z saved by the forward.  Register-resident: WuT (down-type: g = Wu^T dy) and WdT (up-type: dx = dy + Wd^T dz).
-template <int NA>
+// Q8 (configs[4] only, its own instantiation so that the default kernel's register plan is untouched): dx also as e4m3 rows.
+template <int NA, bool Q8>
 __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float* __restrict__ dx, bf16* __restrict__ dx16,
                                             float* __restrict__ z_out, float* __restrict__ dz_out,
                                             const feddat_adapter_seg& sg, int t0, int tstep, int ntiles, float* smem,
-                                            const float* __restrict__ z_saved, const int dbg) {
+                                            const float* __restrict__ z_saved, const int dbg,
+                                            unsigned char* __restrict__ dx8, float* __restrict__ dx8_scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15;
     float* kspl = smem + 2 * TILE_F;
     float* ztile = kspl + KSPL_F;              // [2][ZT_F]
+    float* amred = ztile + 2 * ZT_F;           // [4 waves][16 rows]: row maxima of |dx| (fp8 copy only)
     if (t0 >= ntiles) return;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -753,6 +756,31 @@ __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float*
                 v[j] = *reinterpret_cast<const f32x4*>(srow + r * ROWT + c * 4);
             }
         }
+        // configs[4]: dx also leaves as e4m3 rows + per-row scale amax / 448 (the A operand of the fp8 FFN2^T product): row
+        // maxima over this wave's 192 columns (16 lanes per row: four shuffles), over the four waves through LDS
+        float sc8[4] = {1.f, 1.f, 1.f, 1.f};
+        if (Q8 && dx && dx8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float am = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(v[3 * q + jj][e]));
+                am = fmaxf(am, __shfl_xor(am, 1, 64));
+                am = fmaxf(am, __shfl_xor(am, 2, 64));
+                am = fmaxf(am, __shfl_xor(am, 4, 64));
+                am = fmaxf(am, __shfl_xor(am, 8, 64));
+                if (i16 == 0) amred[wave * 16 + 4 * q + g] = am;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * q + g;
+                const float am = fmaxf(fmaxf(amred[r], amred[16 + r]), fmaxf(amred[32 + r], amred[48 + r]));
+                sc8[q] = am > 0.f ? am * (1.0f / 448.0f) : 1.0f;
+            }
+        }
         FD_WAIT_VM0();                         // next tile's DMA has landed; no store is issued before this point
         const bool st_on = !(dbg & 1);
         auto emit = [&](auto full_tag) {        // full tiles: no per-access predicates (see ws_fwd_body)
@@ -776,6 +804,22 @@ __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float*
                         if (FULL || r < nvalid) *reinterpret_cast<bf16x4*>(brow + (size_t)r * H + c * 4) = cvt4(v[j]);
                     }
                 }
+                if (Q8 && dx8) {
+                    unsigned char* qrow = dx8 + (size_t)row0 * H + wave * WCOLS;
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) {
+                        const int r = 4 * (j / 3) + g, c = 16 * (j % 3) + i16;
+                        const float inv = 1.0f / sc8[j / 3];
+                        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[j][0] * inv, v[j][1] * inv, 0, false);
+                        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[j][2] * inv, v[j][3] * inv, pk, true);
+                        if (FULL || r < nvalid) *reinterpret_cast<int*>(qrow + (size_t)r * H + c * 4) = pk;
+                    }
+                    if (wave == 0 && i16 == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (FULL || 4 * q + g < nvalid) dx8_scale[row0 + 4 * q + g] = sc8[q];
+                    }
+                }
             }
         };
         if (st_on) {
@@ -792,18 +836,21 @@ __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float*
     }
 }
 
-constexpr int WS_BWD_LDS = (2 * TILE_F + KSPL_F + 2 * ZT_F) * 4;
+constexpr int WS_BWD_LDS = (2 * TILE_F + KSPL_F + 2 * ZT_F + 64) * 4;
 
+template <bool Q8>
 __global__ __launch_bounds__(256, 1) void adapter_bwd_ws_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                 bf16* __restrict__ dx16, float* __restrict__ z_out,
                                                                 float* __restrict__ dz_out, WsLaunch L,
-                                                                const float* __restrict__ z_saved) {
+                                                                const float* __restrict__ z_saved,
+                                                                unsigned char* __restrict__ dx8, float* __restrict__ dx8_scale) {
     extern __shared__ __attribute__((aligned(16))) float ws_smem[];
     int s, t0, tstep, ntiles;
     ws_walk(L, s, t0, tstep, ntiles);
     const feddat_adapter_seg& sg = L.a.seg[s];
-    if (sg.n_adapters == 2) ws_bwd_body<2>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg);
-    else ws_bwd_body<1>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg);
+    if (sg.n_adapters == 2) ws_bwd_body<2, Q8>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg, dx8,
+                                               dx8_scale);
+    else ws_bwd_body<1, Q8>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg, dx8, dx8_scale);
 }
 
 // host: blocks per segment, proportional to the tiles (at least one block per non-empty segment, one block per CU in all)
@@ -931,11 +978,12 @@ extern "C" int feddat_adapter_fwd_ln(const float* x, float* out, int T, int Hd, 
     return ws_launch_fwd(x, out, L, tiles, LnFuse{ln_gamma, ln_beta, (bf16*)y_bf16, stats, eps}, z_save, stream);
 }
 
-extern "C" int feddat_adapter_bwd(const float* x, const float* z_saved, const float* dy, float* dx, void* dx_bf16,
-                                  float* z_out, float* dz_out, int T, int Hd, int r, const feddat_adapter_seg* segs,
-                                  int nseg, hipStream_t stream) {
+static int adapter_bwd_launch(const float* x, const float* z_saved, const float* dy, float* dx, void* dx_bf16, void* dx_fp8,
+                              float* dx_scale, float* z_out, float* dz_out, int T, int Hd, int r,
+                              const feddat_adapter_seg* segs, int nseg, hipStream_t stream) {
     FD_CHECK_ARG((x || z_saved) && dy && (dx || z_out) && T > 0 && Hd == H && r == R);
     FD_CHECK_ARG((z_out == nullptr) == (dz_out == nullptr));
+    FD_CHECK_ARG((dx_fp8 == nullptr) == (dx_scale == nullptr) && (!dx_fp8 || (z_saved && dx)));
     AdapterLaunch L;
     int tiles;
     const int rc = prep_launch(segs, nseg, T, L, tiles, true);
@@ -946,15 +994,35 @@ extern "C" int feddat_adapter_bwd(const float* x, const float* z_saved, const fl
         int grid;
         const int rc2 = ws_plan(L, tiles, W, grid);
         if (rc2) return rc2;
-        const int rc3 = fd_set_max_lds((const void*)adapter_bwd_ws_kernel, WS_BWD_LDS);
-        if (rc3) return rc3;
-        hipLaunchKernelGGL(adapter_bwd_ws_kernel, dim3(grid), dim3(256), WS_BWD_LDS, stream, dy, dx, (bf16*)dx_bf16,
-                           z_out, dz_out, W, z_saved);
+        if (dx_fp8) {
+            const int rc3 = fd_set_max_lds((const void*)adapter_bwd_ws_kernel<true>, WS_BWD_LDS);
+            if (rc3) return rc3;
+            hipLaunchKernelGGL(adapter_bwd_ws_kernel<true>, dim3(grid), dim3(256), WS_BWD_LDS, stream, dy, dx, (bf16*)dx_bf16,
+                               z_out, dz_out, W, z_saved, (unsigned char*)dx_fp8, dx_scale);
+        } else {
+            const int rc3 = fd_set_max_lds((const void*)adapter_bwd_ws_kernel<false>, WS_BWD_LDS);
+            if (rc3) return rc3;
+            hipLaunchKernelGGL(adapter_bwd_ws_kernel<false>, dim3(grid), dim3(256), WS_BWD_LDS, stream, dy, dx, (bf16*)dx_bf16,
+                               z_out, dz_out, W, z_saved, (unsigned char*)nullptr, (float*)nullptr);
+        }
     } else {
         hipLaunchKernelGGL(adapter_bwd_kernel<false>, dim3(tiles), dim3(256), dbg_extra_lds(), stream, x, dy, dx,
                            (bf16*)dx_bf16, z_out, dz_out, L, z_saved);
     }
     FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adapter_bwd(const float* x, const float* z_saved, const float* dy, float* dx, void* dx_bf16,
+                                  float* z_out, float* dz_out, int T, int Hd, int r, const feddat_adapter_seg* segs,
+                                  int nseg, hipStream_t stream) {
+    return adapter_bwd_launch(x, z_saved, dy, dx, dx_bf16, nullptr, nullptr, z_out, dz_out, T, Hd, r, segs, nseg, stream);
+}
+
+extern "C" int feddat_adapter_bwd_fp8(const float* z_saved, const float* dy, float* dx, void* dx_fp8, float* dx_scale,
+                                      float* z_out, float* dz_out, int T, int Hd, int r, const feddat_adapter_seg* segs,
+                                      int nseg, hipStream_t stream) {
+    FD_CHECK_ARG(z_saved && dx && dx_fp8 && dx_scale);
+    return adapter_bwd_launch(nullptr, z_saved, dy, dx, nullptr, dx_fp8, dx_scale, z_out, dz_out, T, Hd, r, segs, nseg, stream);
 }
 
 extern "C" int feddat_adapter_pack(const float* wd, const float* wu, void* wd_bf16, void* wdT_bf16, void* wu_bf16,

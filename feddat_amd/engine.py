@@ -553,9 +553,8 @@ class ViltDatEngine:
             # FFN1^T, LN2 backward (+ residual), attention-out^T, attention backward, QKV^T, LN1 backward (+ residual)
             if self._fp8_rows(R2):      # configs[4]: FFN2^T and attention-output^T on the fp8 MFMA, e4m3 gradient rows
                 a, W = self.act[i], self.layers[i]
-                L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, z_out=self.z, dz_out=self.dz,
-                              z_saved=self.zsave[i])
-                L.quant_rows_fp8(oth, self.g8, self.gsc)
+                L.adapter_bwd_fp8(cur, oth, self.g8, self.gsc, self._segs(i, False, True), R2, z_saved=self.zsave[i],
+                                  z_out=self.z, dz_out=self.dz)
                 self._adapter_wgrads(i, a["h3"], 0, cur)
                 L.gemm_fp8_nt(self.g8, self.gsc, W["w2T8"], W["s2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
                 L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)

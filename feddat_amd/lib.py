@@ -88,6 +88,7 @@ _SIGS = {
     "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp],
     "feddat_adapter_fwd_ln": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp, f32, vp, vp, vp, vp],
     "feddat_adapter_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
+    "feddat_adapter_bwd_fp8": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp],
     "feddat_adapter_pack": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "feddat_adapter_pack_strided": [vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "feddat_adapter_wgrad_workspace_elems": [i32],
@@ -410,6 +411,13 @@ def adapter_bwd(x, dy, dx, segs_arr, T, *, dx_bf16=None, z_out=None, dz_out=None
         raise FeddatHipError("adapter_bwd needs x or z_saved")
     _chk(load().feddat_adapter_bwd(_p(x), _p(z_saved), _p(dy), _p(dx), _p(dx_bf16), _p(z_out), _p(dz_out), T, H, r,
                                    segs_arr, len(segs_arr), _stream()), "feddat_adapter_bwd")
+
+
+def adapter_bwd_fp8(dy, dx, dx_fp8, dx_scale, segs_arr, T, *, z_saved, z_out=None, dz_out=None, H=768, r=48):
+    """adapter_bwd (saved-z form) whose dx also leaves as e4m3 rows + per-row scale."""
+    _dev(dy, dx, dx_fp8, dx_scale, z_saved)
+    _chk(load().feddat_adapter_bwd_fp8(_p(z_saved), _p(dy), _p(dx), _p(dx_fp8), _p(dx_scale), _p(z_out), _p(dz_out), T, H, r,
+                                       segs_arr, len(segs_arr), _stream()), "feddat_adapter_bwd_fp8")
 
 
 def make_wgrad_segs(segs: Sequence[dict]):

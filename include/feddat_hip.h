@@ -202,6 +202,10 @@ int feddat_adapter_fwd_ln(const float* x, float* out, int T, int H, int r, const
  * db_up = scale * sum_t dy, dW_down = dz^T x, db_down = sum_t dz. */
 int feddat_adapter_bwd(const float* x, const float* z_saved, const float* dy, float* dx, void* dx_bf16, float* z_out,
                        float* dz_out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg, hipStream_t stream);
+/* configs[4]: the same backward (saved-z form) whose dx also leaves as e4m3 rows + per-row scale (amax / 448): the A operand
+ * of the fp8 FFN2^T product, quantised in the kernel that produces it (no extra pass over dx). */
+int feddat_adapter_bwd_fp8(const float* z_saved, const float* dy, float* dx, void* dx_fp8, float* dx_scale, float* z_out,
+                           float* dz_out, int T, int H, int r, const feddat_adapter_seg* segs, int nseg, hipStream_t stream);
 /* Weight gradients of the trainable adapter of up to two row segments, from the z/dz written by
  * feddat_adapter_bwd: grad = flat fp32 [wd (r x H) | bd (r) | wu (H x r) | bu (H)] (the state-dict order of one
  * layer's adapter), fully overwritten.  x, dy: fp32 [rows, H] (row stride H); z, dz: fp32 [rows, r].

@@ -352,6 +352,18 @@ def test_adapter_full_size_and_ragged_rows(L):
     assert torch.equal(dx2, dx) and torch.equal(z2, z) and torch.equal(dz2, dz)
     assert torch.equal(zs[:h, 0], z[:h]) and torch.equal(zs[h:, 0], z[h:]) and not torch.isnan(zs[:h, 1]).any()
     assert torch.equal(dx16a, dx2.to(torch.bfloat16))
+    # configs[4]: the same backward with dx also as e4m3 rows + per-row scale (quantised in the kernel): identical fp32
+    # outputs, scale = row amax / 448, codes = round-to-nearest e4m3 of dx / scale (ragged tails included)
+    dx3, z3, dz3 = torch.empty_like(x), torch.empty(T, 48, device=DEV), torch.empty(T, 48, device=DEV)
+    d8 = torch.zeros(T, 768, dtype=torch.uint8, device=DEV)
+    dsc = torch.zeros(T, device=DEV)
+    L.adapter_bwd_fp8(dy, dx3, d8, dsc, segs_b, T, z_saved=zs, z_out=z3, dz_out=dz3)
+    assert torch.equal(dx3, dx) and torch.equal(z3, z) and torch.equal(dz3, dz)
+    amax = dx.abs().amax(1)
+    assert torch.allclose(dsc, amax / 448.0, rtol=1e-6)
+    deq = d8.view(torch.float8_e4m3fn).float() * dsc[:, None]
+    assert bool(((deq - dx).abs() <= amax[:, None] * (2.0 ** -4) + 1e-12).all())
+    assert float((d8.view(torch.float8_e4m3fn).float() == (dx / dsc[:, None]).to(torch.float8_e4m3fn).float()).float().mean()) > 0.99
     with pytest.raises(L.FeddatHipError):
         L.adapter_bwd(None, dy, dx2, segs_b, T)
     n = 48 * 768 + 48 + 768 * 48 + 768
