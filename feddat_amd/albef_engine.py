@@ -271,7 +271,13 @@ class AlbefDatEngine:
     # ------------------------------------------------------------------------------------------ inputs
     def set_batch(self, batch: Dict):
         """Reference batch after tokenisation: image [B,3,R,R] f32; question_ids / question_mask [B,Lq]; answer_ids /
-        answer_mask [N,La]; weights [N]; k = answers per question (host list, sum = N)."""
+        answer_mask [N,La]; weights [N]; k = answers per question (host list, sum = N).
+        Shapes are the engine's (static buffers, one captured graph): the caller pads questions to Lq and answers to La with
+        [PAD] + mask 0 and keeps N answers per batch.  Padded KEYS are masked out exactly; padded answer POSITIONS are not
+        free, as in the reference: its MKD term runs over every row of logits[:, :-1] (task_trainer.py:506-516, batchmean over
+        the answers), pad positions included, so a batch padded to a longer La than the reference's `padding='longest'`
+        (albef.py:56-57) carries extra KL rows.  For a bit-for-bit comparable recipe tokenise with padding to the engine's
+        fixed lengths on both sides (what the parity fixtures do)."""
         for k in ("image", "question_ids", "question_mask", "answer_ids", "answer_mask", "weights"):
             src = batch[k]
             if tuple(src.shape) != tuple(self.inp[k].shape):

@@ -322,7 +322,10 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
                                                                      const bf16* __restrict__ ctx,
                                                                      const float* __restrict__ lse,
                                                                      const bf16* __restrict__ dctx,
-                                                                     bf16* __restrict__ dqkv, int S, int heads) {
+                                                                     bf16* __restrict__ dqkv, int S, int heads,
+                                                                     const int dbg) {
+    // dbg (tools/attn_ablate.py, debug flags bits 20..22; 0 in production; timing only): 1 no global stores, 2 no phase-A
+    // arithmetic, 4 no phase B
     constexpr int S_pad = NKS * 32, NT = NKS * 2, NTHR = NKS * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
         if (kt * 16 < S) {
 #pragma unroll
             for (int qs = 0; qs < NKS; ++qs) {
-                if (qs * 32 >= S) break;
+                if (qs * 32 >= S || (dbg & 2)) break;
                 f32x4 p[2], ds[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
                     dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
                 }
             }
-            if (key < S) {
+            if (key < S && !(dbg & 1)) {
                 bf16* ok = dq_base + (size_t)key * ld + H;
                 bf16* ov = dq_base + (size_t)key * ld + 2 * H;
 #pragma unroll
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
     // ---------------- phase B: this wave's query tile ----------------
     {
         const int qt = wave;
-        if (qt * 16 >= S) return;
+        if (qt * 16 >= S || (dbg & 4)) return;
         const char* panel = Pn + qt * S_pad * 32;
         f32x4 dq[4];
 #pragma unroll
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
             for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
         }
         const int q = qt * 16 + i16;
-        if (q < S) {
+        if (q < S && !(dbg & 1)) {
             bf16* oq = dq_base + (size_t)q * ld;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -528,7 +531,8 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
         if (set_lds(attn_bwd_fused_kernel<N>, 3 * (N) * 32 * ROWB + (N) * 32 * (N) * 32 * 2 + 3 * (N) * 32 * 4))  \
             return FEDDAT_ELAUNCH;                                                                             \
         hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(B * heads), dim3((N) * 128), ldsf, stream,           \
-                           (const bf16*)qkv, key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads); \
+                           (const bf16*)qkv, key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads, \
+                           (fd_debug_flags() >> 20) & 7);                                                      \
         break;
         switch (nks) {
             ATTN_BWD_F(1) ATTN_BWD_F(2) ATTN_BWD_F(3) ATTN_BWD_F(4) ATTN_BWD_F(5) ATTN_BWD_F(6)
