@@ -195,19 +195,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
 }
 
 // grad layer layout: [wd (R x H) | bd (R) | wu (H x R) | bu (H)]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradLaunch L) {
-    const int seg = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= PSTRIDE) return;
-    const float* Pd = L.partials + (size_t)(2 * seg) * NBLK * PSTRIDE;       // dW_down problem
-    const float* Pu = L.partials + (size_t)(2 * seg + 1) * NBLK * PSTRIDE;   // dW_up^T problem
+__device__ __forceinline__ void wgrad_reduce_one(const float* __restrict__ partials, float* __restrict__ gl, int seg, int i) {
+    const float* Pd = partials + (size_t)(2 * seg) * NBLK * PSTRIDE;       // dW_down problem
+    const float* Pu = partials + (size_t)(2 * seg + 1) * NBLK * PSTRIDE;   // dW_up^T problem
     float sd = 0.f, su = 0.f;
 #pragma unroll 4
     for (int b = 0; b < NBLK; ++b) {
         sd += Pd[(size_t)b * PSTRIDE + i];
         su += Pu[(size_t)b * PSTRIDE + i];
     }
-    float* gl = L.seg[seg].grad;
     if (i < R * H) {
         gl[i] = sd;                                   // wd[r][c]
         const int r = i / H, c = i - r * H;
@@ -219,12 +215,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradLaunch L) {
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradLaunch L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < PSTRIDE) wgrad_reduce_one(L.partials, L.seg[blockIdx.y].grad, blockIdx.y, i);
+}
+
+// the reductions of several launches (one per layer) in ONE: blockIdx.z = launch, its partials at + z * stride
+struct WgradReduceBatch {
+    float* const* grads;      // device array [n][nseg] of gradient pointers
+    const float* partials;
+    long stride;
+    int nseg;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WgradReduceBatch B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < PSTRIDE)
+        wgrad_reduce_one(B.partials + (size_t)blockIdx.z * B.stride, B.grads[blockIdx.z * B.nseg + blockIdx.y], blockIdx.y, i);
+}
+
 }  // namespace
 
 extern "C" long feddat_adapter_wgrad_workspace_elems(int nseg) { return (long)nseg * 2 * NBLK * PSTRIDE; }
 
-extern "C" int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems,
-                                    int Hd, int r, hipStream_t stream) {
+static int wgrad_launch(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int Hd, int r,
+                        bool reduce_now, hipStream_t stream) {
     FD_CHECK_ARG(segs && nseg >= 1 && nseg <= 2 && partials && Hd == H && r == R);
     FD_CHECK_ARG(partials_elems >= (long)nseg * 2 * NBLK * PSTRIDE);
     WgradLaunch L;
@@ -236,6 +250,25 @@ extern "C" int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, floa
     }
     if (nseg == 1) L.seg[1] = L.seg[0];
     hipLaunchKernelGGL(wgrad_kernel, dim3(NBLK, NCH, 2 * nseg), dim3(256), 0, stream, L);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((PSTRIDE + 255) / 256, nseg), dim3(256), 0, stream, L);
+    if (reduce_now) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((PSTRIDE + 255) / 256, nseg), dim3(256), 0, stream, L);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems,
+                                    int Hd, int r, hipStream_t stream) {
+    return wgrad_launch(segs, nseg, partials, partials_elems, Hd, r, true, stream);
+}
+
+extern "C" int feddat_adapter_wgrad_partial(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems,
+                                            int Hd, int r, hipStream_t stream) {
+    return wgrad_launch(segs, nseg, partials, partials_elems, Hd, r, false, stream);
+}
+
+extern "C" int feddat_adapter_wgrad_reduce(float* const* grads_dev, int n, int nseg, const float* partials,
+                                           long partials_stride, hipStream_t stream) {
+    FD_CHECK_ARG(grads_dev && partials && n > 0 && n <= 65535 && nseg >= 1 && nseg <= 2);
+    FD_CHECK_ARG(partials_stride >= (long)nseg * 2 * NBLK * PSTRIDE);
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((PSTRIDE + 255) / 256, nseg, n), dim3(256), 0, stream,
+                       WgradReduceBatch{grads_dev, partials, partials_stride, nseg});
     FD_LAUNCH_RET();
 }

@@ -58,7 +58,8 @@ extern "C" int feddat_vilt_layer_fwd(feddat_ctx* ctx, const feddat_vilt_layer_we
 extern "C" int feddat_vilt_layer_bwd(feddat_ctx* ctx, const feddat_vilt_layer_weights* W, const feddat_vilt_layer_acts* A,
                                      const feddat_vilt_layer_grads* G, int nb, int S, int heads, const uint8_t* key_mask,
                                      const feddat_adapter_seg* segs, int nseg, const feddat_wgrad_seg* wsegs, int nwseg,
-                                     float* wgrad_partials, long wgrad_partials_elems, hipStream_t stream) {
+                                     float* wgrad_partials, long wgrad_partials_elems, int wgrad_reduce_now,
+                                     hipStream_t stream) {
     FD_CHECK_ARG(ctx && W && A && G && nb > 0 && S > 0 && heads > 0 && segs);
     FD_CHECK_ARG(G->dh_out && G->dh_in && G->dh3 && G->dh16 && G->dU && G->dx16 && G->dctx && G->dqkv && G->z && G->dz);
     int rc = check_ctx_and_shape(ctx, heads);
@@ -69,8 +70,10 @@ extern "C" int feddat_vilt_layer_bwd(feddat_ctx* ctx, const feddat_vilt_layer_we
     // adapter: d h3 (fp32 + bf16 copy), z / dz for the weight gradients of the trainable adapter(s)
     FD_TRY(feddat_adapter_bwd(A->z_save ? nullptr : A->h3, A->z_save, G->dh_out, G->dh3, G->dh16, G->z, G->dz, rows, H, 48,
                               segs, nseg, stream));
-    if (wsegs && nwseg > 0)
-        FD_TRY(feddat_adapter_wgrad(wsegs, nwseg, wgrad_partials, wgrad_partials_elems, H, 48, stream));
+    if (wsegs && nwseg > 0) {      // wgrad_reduce_now = 0: the caller folds all layers' partials with one feddat_adapter_wgrad_reduce
+        if (wgrad_reduce_now) FD_TRY(feddat_adapter_wgrad(wsegs, nwseg, wgrad_partials, wgrad_partials_elems, H, 48, stream));
+        else FD_TRY(feddat_adapter_wgrad_partial(wsegs, nwseg, wgrad_partials, wgrad_partials_elems, H, 48, stream));
+    }
     // FFN2^T (. gelu'), FFN1^T, LN2 backward (+ residual)
     FD_TRY(feddat_gemm_bf16_nt(G->dh16, H, W->w2T, H, rows, I, H, FEDDAT_EPI_MUL_DGELU, nullptr, nullptr, 0, A->u, I, nullptr,
                                0, G->dU, I, nullptr, 0, stream));

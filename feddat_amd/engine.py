@@ -178,7 +178,8 @@ class ViltDatEngine:
 
         def b16(*s):
             return torch.empty(*s, dtype=torch.bfloat16, device=dev)
-        self.inp = dict(pixel_values=f32(B, 3, self.res[0], self.res[1]), input_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
+        self._px_shape = (B, 3, self.res[0], self.res[1])
+        self.inp = dict(input_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
                         token_type_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
                         target=f32(B, num_labels),
                         attention_mask=torch.ones(B, text_len, dtype=torch.int64, device=dev),
@@ -239,7 +240,11 @@ class ViltDatEngine:
         # relu(W_down h3 + b_down) of every adapter slot, saved by the adapter forward of each layer for its backward
         # (fp32 [rows, 2, 48]: 384 B per token instead of re-reading the 3 KB row and repeating the down-projection)
         self.zsave = [f32(R2, 2, self.r) for _ in range(layers - 1)] + [f32(nb2 if layers > 1 else R2, 2, self.r)]
-        self.wpart = f32(L.adapter_wgrad_workspace_elems(2))
+        # token-split partial sums of the adapter weight gradients: one slot per layer, folded into the flat gradient
+        # buffers by ONE reduction at the end of the backward (feddat_adapter_wgrad_reduce) instead of one per layer
+        self.wpart_stride = L.adapter_wgrad_workspace_elems(2)
+        self.wpart_all = f32(layers * self.wpart_stride)
+        self.wpart = self.wpart_all[:self.wpart_stride]
         self._segs_cache: Dict = {}
         self.graph = None
         self.ctx = L.Context(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
@@ -309,10 +314,14 @@ class ViltDatEngine:
     def set_batch(self, batch: Dict[str, torch.Tensor]):
         """Copy one batch (reference schema: HF ViLT encodings + target_scores) into the static input buffers."""
         px = batch["pixel_values"]
-        if tuple(px.shape) != tuple(self.inp["pixel_values"].shape):
-            raise L.FeddatHipError(f"engine built for pixel_values {tuple(self.inp['pixel_values'].shape)}, got "
-                                   f"{tuple(px.shape)}")
-        self.inp["pixel_values"].copy_(px, non_blocking=True)
+        if tuple(px.shape) != self._px_shape:
+            raise L.FeddatHipError(f"engine built for pixel_values {self._px_shape}, got {tuple(px.shape)}")
+        # the pixels are consumed right here, from the caller's tensor: patch extraction (im2col + bf16) is the only reader of
+        # pixel_values, so it runs ahead of the captured step instead of a 57 MB device-to-device copy into a static buffer
+        # followed by the same read inside the graph (stream-ordered with the replay that follows)
+        if not px.is_cuda:
+            px = px.to(self.dev, non_blocking=True)
+        L.im2col_patches(px.to(torch.float32).contiguous(), self.patches, self.B, 3, self.res[0], self.res[1], self.P)
         self.inp["input_ids"].copy_(batch["input_ids"], non_blocking=True)
         self.inp["token_type_ids"].copy_(batch["token_type_ids"], non_blocking=True)
         if "target_scores" in batch:
@@ -334,7 +343,7 @@ class ViltDatEngine:
                      e["text_embeddings.position_embeddings.weight"], e["text_embeddings.token_type_embeddings.weight"],
                      e["text_embeddings.LayerNorm.weight"], e["text_embeddings.LayerNorm.bias"], self.ln_eps,
                      self.mod0, self.h0, B, Lt, S, H)
-        L.im2col_patches(self.inp["pixel_values"], self.patches, B, 3, self.res[0], self.res[1], self.P)
+        # (self.patches was filled by set_batch: im2col of the caller's pixel_values)
         L.gemm_bf16_nt(self.patches, self.w_patch, L.EPI_F32, bias=e["patch_embeddings.projection.bias"],
                        out_f32=self.proj)
         L.vilt_key_mask(self.inp["attention_mask"], self.inp["patch_mask"], self.key_mask2, B, Lt, self.gh, self.gw, 1,
@@ -584,12 +593,14 @@ class ViltDatEngine:
             W, A, _ = self._layer_struct(i)
             G = self._grad_struct(cur, oth)
             L.vilt_layer_bwd(self.ctx, W, A, G, nb, self.S, self.heads, self._segs(i, False, True),
-                             self._wgrad_segs(i, self.act[i]["h3"], 0, cur), self.wpart, key_mask=m2)
+                             self._wgrad_segs(i, self.act[i]["h3"], 0, cur), self._wpart(i), key_mask=m2,
+                             wgrad_reduce_now=False)
             cur, oth = oth, cur
         # layer 0: weight gradients only (nothing trainable below)
         L.adapter_bwd(None, cur, None, self._segs(0, True, True), R2, z_out=self.z, dz_out=self.dz,
                       z_saved=self.zsave[0])
         self._adapter_wgrads(0, self.l0["h3"], -R, cur)
+        self._wgrad_reduce_all()
 
     def _top_layer_bwd(self, cur, oth, mask):
         """Backward of the last layer: the incoming gradient is non-zero only on the 2B token-0 rows, so the adapter,
@@ -607,7 +618,7 @@ class ViltDatEngine:
                     for ad, r0, sc in ((0, 0, 0.5), (1, B, 1.0)) if ad in self.opt_adapters]
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
         if self._segs_cache[key] is not None:
-            L.adapter_wgrad(self._segs_cache[key], self.wpart)
+            L.adapter_wgrad_partial(self._segs_cache[key], self._wpart(i))
         ws = self._skinny_ws()
         L.gemm_bf16_nt(t["dh316"], W["w2T"], L.EPI_MUL_DGELU, aux=t["u"], out_bf16=t["dU"], skinny_workspace=ws)
         L.gemm_bf16_nt(t["dU"], W["w1T"], L.EPI_BF16, out_bf16=t["dx2"], skinny_workspace=ws)
@@ -656,13 +667,28 @@ class ViltDatEngine:
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
         return self._segs_cache[key]
 
+    def _wpart(self, layer: int):
+        return self.wpart_all[layer * self.wpart_stride:(layer + 1) * self.wpart_stride]
+
+    def _wgrad_reduce_all(self):
+        """Fold every layer's partial sums into the adapters' flat gradient buffers (one launch)."""
+        ads = [a for a in (0, 1) if a in self.opt_adapters]
+        if not ads:
+            return
+        key = ("wg-reduce", self.opt_adapters)
+        if key not in self._segs_cache:
+            n = self.ad_layer_numel
+            ptrs = [self.ad[a].g[i * n:(i + 1) * n].data_ptr() for i in range(self.nl) for a in ads]
+            self._segs_cache[key] = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
+        L.adapter_wgrad_reduce(self._segs_cache[key], self.nl, len(ads), self.wpart_all, self.wpart_stride)
+
     def _adapter_wgrads(self, layer: int, x, x_delta_s: int, dy):
         """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146)
         for adapter_0 (rows [0,R)) and adapter_1 (rows [R,2R)): exact fp32 MFMA, split over tokens, deterministic
         reduction straight into the flat gradient buffers."""
         segs = self._wgrad_segs(layer, x, x_delta_s, dy)
         if segs is not None:
-            L.adapter_wgrad(segs, self.wpart)
+            L.adapter_wgrad_partial(segs, self._wpart(layer))
 
     # ------------------------------------------------------------------------------------------ train step
     def begin_local_update(self, task: str, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,

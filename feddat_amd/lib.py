@@ -93,10 +93,12 @@ _SIGS = {
     "feddat_adapter_pack_strided": [vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "feddat_adapter_wgrad_workspace_elems": [i32],
     "feddat_adapter_wgrad": [C.POINTER(WgradSeg), i32, vp, i64, i32, i32, vp],
+    "feddat_adapter_wgrad_partial": [C.POINTER(WgradSeg), i32, vp, i64, i32, i32, vp],
+    "feddat_adapter_wgrad_reduce": [vp, i32, i32, vp, i64, vp],
     "feddat_vilt_layer_fwd": [vp, C.POINTER(ViltLayerWeights), C.POINTER(ViltLayerActs), i32, i32, i32, vp, i32,
                               C.POINTER(AdapterSeg), i32, vp, vp, vp],
     "feddat_vilt_layer_bwd": [vp, C.POINTER(ViltLayerWeights), C.POINTER(ViltLayerActs), C.POINTER(ViltLayerGrads), i32, i32,
-                              i32, vp, C.POINTER(AdapterSeg), i32, C.POINTER(WgradSeg), i32, vp, i64, vp],
+                              i32, vp, C.POINTER(AdapterSeg), i32, C.POINTER(WgradSeg), i32, vp, i64, i32, vp],
     "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
@@ -432,6 +434,19 @@ def adapter_wgrad_workspace_elems(nseg: int) -> int:
     return int(load().feddat_adapter_wgrad_workspace_elems(nseg))
 
 
+def adapter_wgrad_partial(segs_arr, partials, H=768, r=48):
+    _dev(partials)
+    _chk(load().feddat_adapter_wgrad_partial(segs_arr, len(segs_arr), _p(partials), partials.numel(), H, r, _stream()),
+         "feddat_adapter_wgrad_partial")
+
+
+def adapter_wgrad_reduce(grads_dev, n, nseg, partials, stride):
+    """grads_dev: int64 device tensor [n * nseg] of gradient-buffer addresses; launch l's partials at partials[l * stride:]."""
+    _dev(grads_dev, partials)
+    _chk(load().feddat_adapter_wgrad_reduce(_p(grads_dev), n, nseg, _p(partials), stride, _stream()),
+         "feddat_adapter_wgrad_reduce")
+
+
 def adapter_wgrad(segs_arr, partials, H=768, r=48):
     _dev(partials)
     _chk(load().feddat_adapter_wgrad(segs_arr, len(segs_arr), _p(partials), partials.numel(), H, r, _stream()),
@@ -457,10 +472,12 @@ def vilt_layer_fwd(ctx: "Context", W, A, nb, S, heads, segs_arr, *, key_mask=Non
                                       len(segs_arr), _p(next_ln_g), _p(next_ln_b), _stream()), "feddat_vilt_layer_fwd")
 
 
-def vilt_layer_bwd(ctx: "Context", W, A, G, nb, S, heads, segs_arr, wsegs_arr, partials, *, key_mask=None):
+def vilt_layer_bwd(ctx: "Context", W, A, G, nb, S, heads, segs_arr, wsegs_arr, partials, *, key_mask=None,
+                   wgrad_reduce_now=True):
     _chk(load().feddat_vilt_layer_bwd(ctx._h, C.byref(W), C.byref(A), C.byref(G), nb, S, heads, _p(key_mask), segs_arr,
                                       len(segs_arr), wsegs_arr, 0 if wsegs_arr is None else len(wsegs_arr), _p(partials),
-                                      0 if partials is None else partials.numel(), _stream()), "feddat_vilt_layer_bwd")
+                                      0 if partials is None else partials.numel(), int(wgrad_reduce_now), _stream()),
+         "feddat_vilt_layer_bwd")
 
 
 def sgemm_f32(A, sa_i, sa_k, B, sb_k, sb_j, I, J, K, out, *, ldo=None, ksplit=1, alpha=1.0, bias_j=None,

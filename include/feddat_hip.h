@@ -222,6 +222,15 @@ typedef struct {
 long feddat_adapter_wgrad_workspace_elems(int nseg);
 int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int H, int r,
                          hipStream_t stream);
+/* The same in two steps, for callers that run several of these per backward pass (one per layer): _partial leaves the
+ * token-split partial sums of ONE launch in `partials` (no reduction); _reduce folds the partials of n such launches --
+ * launch l's at partials + l * partials_stride floats -- into their gradient buffers in one kernel (same fixed summation
+ * order as feddat_adapter_wgrad: bit-identical results).  grads_dev: DEVICE array of n * nseg gradient pointers
+ * ([launch][segment]), every launch with the same nseg. */
+int feddat_adapter_wgrad_partial(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int H, int r,
+                                 hipStream_t stream);
+int feddat_adapter_wgrad_reduce(float* const* grads_dev, int n, int nseg, const float* partials, long partials_stride,
+                                hipStream_t stream);
 /* fp32 masters -> bf16 MFMA operand copies (r*H elements each).  All four are stored FRAGMENT-MAJOR -- the 64 lanes of
  * a wave read 64 consecutive 16-byte pieces, i.e. one contiguous 1 KiB burst per weight load -- with the contraction
  * slots of wd / wuT permuted along H (feature c at 32*(c/32) + 8*((c%16)/4) + 4*((c%32)/16) + c%4) so that they coincide
@@ -288,7 +297,7 @@ int feddat_vilt_layer_fwd(feddat_ctx* ctx, const feddat_vilt_layer_weights* W, c
 int feddat_vilt_layer_bwd(feddat_ctx* ctx, const feddat_vilt_layer_weights* W, const feddat_vilt_layer_acts* A,
                           const feddat_vilt_layer_grads* G, int nb, int S, int heads, const uint8_t* key_mask,
                           const feddat_adapter_seg* segs, int nseg, const feddat_wgrad_seg* wsegs, int nwseg,
-                          float* wgrad_partials, long wgrad_partials_elems, hipStream_t stream);
+                          float* wgrad_partials, long wgrad_partials_elems, int wgrad_reduce_now, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 with arbitrary strides and split-K partial sums:
