@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
                                                                      const float* __restrict__ lse,
                                                                      const bf16* __restrict__ dctx,
                                                                      bf16* __restrict__ dqkv, int S, int heads,
-                                                                     const int dbg) {
+                                                                     const int npairs, const int dbg) {
     // dbg (tools/attn_ablate.py, debug flags bits 20..22; 0 in production; timing only): 1 no global stores, 2 no phase-A
     // arithmetic, 4 no phase B
     constexpr int S_pad = NKS * 32, NT = NKS * 2, NTHR = NKS * 128;
@@ -337,52 +337,97 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
     float* kvalid = Ls + S_pad;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const int H = heads * D;
     const long ld = 3L * H;
-    const bf16* base = qkv + (size_t)b * S * ld + h * D;
-    const bf16* gO = ctx + (size_t)b * S * H + h * D;
-    const bf16* gG = dctx + (size_t)b * S * H + h * D;
-    bf16* dq_base = dqkv + (size_t)b * S * ld + h * D;
     const int g = lane >> 4, i16 = lane & 15;
-    for (int k = tid; k < S_pad; k += NTHR) {
-        Ls[k] = k < S ? lse[((size_t)b * heads + h) * S + k] * LOG2E : 0.f;
-        kvalid[k] = (k < S && (!kmask || kmask[(size_t)b * S + k])) ? 1.f : 0.f;
-    }
-    for (int idx = tid; idx < S_pad * 8; idx += NTHR) {             // Q, K -> LDS
-        const int row = idx >> 3, chunk = idx & 7;
-        bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, kv = qv;
-        if (row < S) {
-            qv = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + chunk * 8);
-            kv = *reinterpret_cast<const bf16x8*>(base + H + (size_t)row * ld + chunk * 8);
-        }
-        *reinterpret_cast<bf16x8*>(Qs + sw_off(row, chunk)) = qv;
-        *reinterpret_cast<bf16x8*>(Ks + sw_off(row, chunk)) = kv;
-    }
-    for (int idx = tid; idx < S_pad * 8; idx += NTHR) {             // dO -> LDS, D[q] = sum_d dO[q][d] O[q][d]
-        const int row = idx >> 3, chunk = idx & 7;
-        bf16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
-        float part = 0.f;
-        if (row < S) {
-            gv = *reinterpret_cast<const bf16x8*>(gG + (size_t)row * H + chunk * 8);
-            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(gO + (size_t)row * H + chunk * 8);
+    constexpr int NIT = S_pad * 8 / NTHR;          // 16-byte chunks of one [S_pad][64] operand per thread (2)
+    static_assert(S_pad * 8 % NTHR == 0, "operand chunks divide over the block");
+    // PERSISTENT over (sample, head) pairs: blockIdx.x, + gridDim.x, ...  Everything the next pair needs from HBM is
+    // requested into REGISTERS while the current pair computes (LDS is full), in two instalments so that the register
+    // file (168 per thread at 12 waves per CU) holds: K chunks, this wave's two V row fragments, LSE and key mask (18
+    // registers) before phase A; Q, dO and O chunks (24) before phase B, whose own footprint is small.  The loads fly
+    // during the phases and the load phase of every pair but a block's first disappears (r03 ablation: loads 17 us of
+    // the 50 us launch, serial with compute).  Nothing inside the phases consumes a prefetched register, so nothing
+    // there waits on vmcnt.
+    struct Pre {
+        bf16x8 q[NIT], k[NIT], gd[NIT], o[NIT], vf0, vf1;
+        float ls, kv;
+    } P;
+    auto prefetch1 = [&](int pair) {
+        const int b = pair / heads, h = pair - b * heads;
+        const bf16* base = qkv + (size_t)b * S * ld + h * D;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part += (float)gv[e] * (float)ov[e];
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NTHR, row = idx >> 3, chunk = idx & 7;
+            P.k[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < S) P.k[it] = *reinterpret_cast<const bf16x8*>(base + H + (size_t)row * ld + chunk * 8);
         }
-        *reinterpret_cast<bf16x8*>(Gs + sw_off(row, chunk)) = gv;
+        const int key = wave * 16 + i16;
+        P.vf0 = gload_frag(base + 2 * H, ld, key, S, g);
+        P.vf1 = gload_frag(base + 2 * H, ld, key, S, 4 + g);
+        P.ls = 0.f;
+        P.kv = 0.f;
+        if (tid < S_pad && tid < S) {
+            P.ls = lse[((size_t)b * heads + h) * S + tid] * LOG2E;
+            P.kv = (!kmask || kmask[(size_t)b * S + tid]) ? 1.f : 0.f;
+        }
+    };
+    auto prefetch2 = [&](int pair) {
+        const int b = pair / heads, h = pair - b * heads;
+        const bf16* base = qkv + (size_t)b * S * ld + h * D;
+        const bf16* gO = ctx + (size_t)b * S * H + h * D;
+        const bf16* gG = dctx + (size_t)b * S * H + h * D;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NTHR, row = idx >> 3, chunk = idx & 7;
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            P.q[it] = P.gd[it] = P.o[it] = z8;
+            if (row < S) {
+                P.q[it] = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + chunk * 8);
+                P.gd[it] = *reinterpret_cast<const bf16x8*>(gG + (size_t)row * H + chunk * 8);
+                P.o[it] = *reinterpret_cast<const bf16x8*>(gO + (size_t)row * H + chunk * 8);
+            }
+        }
+    };
+    prefetch1(blockIdx.x);
+    prefetch2(blockIdx.x);
+  for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    // the lane-derived LDS offsets below are loop invariant; hoisted out of the loop they would all be live across both
+    // phases (hipcc did exactly that: 54 spilled registers).  Re-deriving them from a laundered thread id keeps them local.
+    int tid_l = threadIdx.x;
+    asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int b = pair / heads, h = pair - b * heads;
+    bf16* dq_base = dqkv + (size_t)b * S * ld + h * D;
+    // hand the prefetched operands to LDS; D[q] = sum_d dO[q][d] O[q][d]
+    if (tid < S_pad) {
+        Ls[tid] = P.ls;
+        kvalid[tid] = P.kv;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTHR, row = idx >> 3, chunk = idx & 7;
+        *reinterpret_cast<bf16x8*>(Qs + sw_off(row, chunk)) = P.q[it];
+        *reinterpret_cast<bf16x8*>(Ks + sw_off(row, chunk)) = P.k[it];
+        *reinterpret_cast<bf16x8*>(Gs + sw_off(row, chunk)) = P.gd[it];
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)P.gd[it][e] * (float)P.o[it][e];
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
         part += __shfl_xor(part, 4, 64);
         if (chunk == 0) Dv[row] = part;
     }
+    const bf16x8 vf0 = P.vf0, vf1 = P.vf1;
     __syncthreads();
+    const bool more = pair + (int)gridDim.x < npairs;
+    if (more) prefetch1(pair + gridDim.x);
 
     // ---------------- phase A: this wave's key tile ----------------
     {
         const int kt = wave;
         const int key = kt * 16 + i16;
         const bf16x8 kf0 = row_frag(Ks, key, g), kf1 = row_frag(Ks, key, 4 + g);
-        const bf16x8 vf0 = gload_frag(base + 2 * H, ld, key, S, g), vf1 = gload_frag(base + 2 * H, ld, key, S, 4 + g);
         const float kv = kvalid[key];
         f32x4 dv[4], dk[4];
 #pragma unroll
@@ -442,11 +487,12 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
         }
     }
     __syncthreads();
+    if (more) prefetch2(pair + gridDim.x);
 
     // ---------------- phase B: this wave's query tile ----------------
     {
         const int qt = wave;
-        if (qt * 16 >= S || (dbg & 4)) return;
+        if (qt * 16 < S && !(dbg & 4)) {
         const char* panel = Pn + qt * S_pad * 32;
         f32x4 dq[4];
 #pragma unroll
@@ -475,7 +521,10 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
             for (int dt = 0; dt < 4; ++dt)
                 *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
         }
+        }
     }
+    __syncthreads();        // every wave is done with this pair's LDS before the next pair's operands land in it
+  }
 }
 
 template <typename K>
@@ -526,13 +575,18 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
     if (nks <= 6 && !(fd_debug_flags() & 2)) {        // one block per (sample, head): operands and probabilities once
         const int sp = nks * 32;
         const int ldsf = 3 * sp * ROWB + sp * sp * 2 + 3 * sp * 4;
+        // one block per CU (the LDS footprint allows no more), each walking (sample, head) pairs with the next pair's
+        // operands prefetched into registers; debug bit 23: one block per pair (the r02 launch, nothing to prefetch)
+        int n_cu = 0;
+        if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+        const int grid = (fd_debug_flags() & (1 << 23)) || B * heads < n_cu ? B * heads : n_cu;
 #define ATTN_BWD_F(N)                                                                                          \
     case N:                                                                                                    \
         if (set_lds(attn_bwd_fused_kernel<N>, 3 * (N) * 32 * ROWB + (N) * 32 * (N) * 32 * 2 + 3 * (N) * 32 * 4))  \
             return FEDDAT_ELAUNCH;                                                                             \
-        hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(B * heads), dim3((N) * 128), ldsf, stream,           \
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(grid), dim3((N) * 128), ldsf, stream,                \
                            (const bf16*)qkv, key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads, \
-                           (fd_debug_flags() >> 20) & 7);                                                      \
+                           B * heads, (fd_debug_flags() >> 20) & 7);                                           \
         break;
         switch (nks) {
             ATTN_BWD_F(1) ATTN_BWD_F(2) ATTN_BWD_F(3) ATTN_BWD_F(4) ATTN_BWD_F(5) ATTN_BWD_F(6)

@@ -143,6 +143,24 @@ __device__ __forceinline__ f32x4 gelu_grad4_pk(f32x4 u) {
     return f32x4{a[0], a[1], b[0], b[1]};
 }
 
+// 8-bit gelu'(u) codes (FEDDAT_EPI_GELU_G8 / FEDDAT_EPI_MUL_G8, include/feddat_hip.h): gelu' lives in [-0.1290, 1.1290];
+// code = round((g' - FEDDAT_G8_LO) / FEDDAT_G8_STEP) in 0..255 covers [-0.135, 1.14] with |error| <= STEP / 2 = 2.5e-3
+// (the bf16 u it replaces carried |u| 2^-9 gelu''(u) <= 2e-3 at |u| ~ 1).  Encode: one fma onto 2^23 + offset puts the
+// round-to-nearest-even code into the low byte of the float's bits (LO / STEP is an integer, so the offset is exact).
+__device__ __forceinline__ unsigned fd_g8_encode4(const f32x4 gp) {
+    constexpr float INV = 1.0f / FEDDAT_G8_STEP, OFF = 8388608.0f - FEDDAT_G8_LO / FEDDAT_G8_STEP;
+    const f32x4 t = gp * f32x4{INV, INV, INV, INV} + f32x4{OFF, OFF, OFF, OFF};
+    // (__float_as_uint, not __builtin_bit_cast: applied to a vector ELEMENT hipcc's bit_cast reads element 0 every time)
+    const unsigned b0 = __float_as_uint(t[0]), b1 = __float_as_uint(t[1]), b2 = __float_as_uint(t[2]), b3 = __float_as_uint(t[3]);
+    // v_perm_b32 D = perm(S0, S1, sel): selector 0..3 = byte of S1, 4..7 = byte of S0, 0x0c = zero
+    return __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
+}
+__device__ __forceinline__ f32x4 fd_g8_decode4(const unsigned w) {
+    const f32x4 c = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24)};
+    return c * f32x4{FEDDAT_G8_STEP, FEDDAT_G8_STEP, FEDDAT_G8_STEP, FEDDAT_G8_STEP} +
+           f32x4{FEDDAT_G8_LO, FEDDAT_G8_LO, FEDDAT_G8_LO, FEDDAT_G8_LO};
+}
+
 __device__ __forceinline__ bf16x8 cvt8(const f32x4 a, const f32x4 b) {
     bf16x8 r;
     r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];

@@ -378,6 +378,7 @@ __device__ __forceinline__ void v2_piece_ptrs(const GemmArgs& g, int m0, int m_l
 // instead of 6 x dwordx2 (the 8-byte form was store-issue-bound at ~9 B/clk/CU: 9.5 us of every 27 us FFN1 tile).
 // The aux operand of MUL_DGELU takes the opposite way: 16-byte row-contiguous loads -> LDS -> accumulator layout.
 constexpr int V2_EPI_LD16 = 208;              // bytes per staged bf16 row (96 x 2 + 16 pad)
+constexpr int V2_EPI_LD8 = 112;               // bytes per staged row of 8-bit gelu' codes (96 + 16 pad); 22 rows are addressable
 // SINK (v3: one wave per SIMD, nothing else to hide a stall): stores of rows outside the tile go to a dummy line
 // instead of being predicated, so the whole epilogue is one basic block the scheduler can interleave.
 __device__ uint4 fd_epi_sink[64];
@@ -386,10 +387,24 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
                                                  int m_end, int lane) {
     asm volatile("" : "+v"(lane));
     const int frow = lane & 15, fg = lane >> 4;
-    f32x4 bias4[6];
+    constexpr bool G8OUT_ = EPI == FEDDAT_EPI_GELU_G8 || EPI == FEDDAT_EPI_MUL_G8;      // column constants in LDS
+    // GELU_G8 (two polynomials per element) / MUL_G8 (its codes in flight) have no registers for per-column constants at
+    // 256-row tiles (57 / 26 spilled, and scratch traffic in the k-loop breaks its counted vmcnt waits): their bias / fp8
+    // channel scales wait in the wave's staging buffer behind the slab and are re-read per row group
+    constexpr int COLC_OFF = 16 * V2_EPI_LD16;
+    static_assert(COLC_OFF + 2 * 384 <= V2_EPI_WAVE, "column constants fit behind the staged slab");
+    f32x4 bias4[G8OUT_ ? 1 : 6];
+    if (G8OUT_) {
+        if (lane < 24) {
+            *reinterpret_cast<f32x4*>(stg + COLC_OFF + lane * 16) =
+                g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nbase + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g.sw) *reinterpret_cast<f32x4*>(stg + COLC_OFF + 384 + lane * 16) = *reinterpret_cast<const f32x4*>(g.sw + nbase + lane * 4);
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-        bias4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nbase + j * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 6; ++j)
+            bias4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nbase + j * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     int srow[3], sc8[3];                       // row-contiguous slots of this lane: (row, 8-column group) = divmod(64 p + lane, 12)
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -397,7 +412,30 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
         srow[p] = idx / 12;
         sc8[p] = idx - srow[p] * 12;
     }
-    bf16x8 ux[WM][3];
+    // 8-bit gelu' codes (GELU_G8 / MUL_G8): a slab is [16 rows][96 bytes] = 96 x 16-byte chunks, one per lane + 32
+    constexpr bool G8OUT = EPI == FEDDAT_EPI_GELU_G8, G8IN = EPI == FEDDAT_EPI_MUL_G8;
+    int r8[2], c8[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int idx = p * 64 + lane;          // idx >= 96 (p = 1, lanes 32..63): staged beyond the slab, never used
+        r8[p] = idx / 6;
+        c8[p] = idx - r8[p] * 6;
+    }
+    char* wr8 = stg + frow * V2_EPI_LD8 + fg * 4;           // accumulator-layout position of 4 codes: row frow, cols 16 j + 4 fg
+    u32x4 ux8[G8IN ? WM : 1][2];
+    auto aux8_load = [&](int i) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned mc = (unsigned)min(mbase + i * 16 + r8[p], m_end - 1);
+            const unsigned off = mc * (unsigned)g.ldaux + (unsigned)(nbase + c8[p] * 16);
+            ux8[i][p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g.aux) + off);
+        }
+    };
+    if (G8IN) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) aux8_load(i);
+    }
+    bf16x8 ux[G8IN ? 1 : WM][3];
     auto aux_load = [&](int i) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -429,21 +467,23 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
             }
         }
     };
-    f32x4 sw4[6];
-    if (g.sw) {
+    f32x4 sw4[G8OUT_ ? 1 : 6];
+    if (g.sw && !G8OUT_) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) sw4[j] = *reinterpret_cast<const f32x4*>(g.sw + nbase + j * 16 + fg * 4);
     }
+    auto colc = [&](int which, int j) { return *reinterpret_cast<const f32x4*>(stg + COLC_OFF + which * 384 + j * 64 + fg * 16); };
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         f32x4 val[6];
         if (g.sw) {          // fp8 operands: dequantise the accumulators (per-row scale of A x per-channel scale of B)
             const float sa = g.sa[min(mbase + i * 16 + frow, m_end - 1)];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) val[j] = acc[i][j] * (sw4[j] * f32x4{sa, sa, sa, sa}) + bias4[j];
+            for (int j = 0; j < 6; ++j)
+                val[j] = acc[i][j] * ((G8OUT_ ? colc(1, j) : sw4[j]) * f32x4{sa, sa, sa, sa}) + (G8OUT_ ? colc(0, j) : bias4[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) val[j] = acc[i][j] + bias4[j];
+            for (int j = 0; j < 6; ++j) val[j] = acc[i][j] + (G8OUT_ ? colc(0, j) : bias4[j]);
         }
         if (EPI == FEDDAT_EPI_MUL_DGELU) {
 #pragma unroll
@@ -461,6 +501,33 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 if (!(g.nostore & 2)) val[j] = gelu4_pk(val[j]);
+        }
+        if (G8IN) {          // codes: row-contiguous 16-byte chunks -> LDS -> one dword (4 codes) per accumulator
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(stg + r8[p] * V2_EPI_LD8 + c8[p] * 16) = ux8[i][p];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) val[j] = val[j] * fd_g8_decode4(*reinterpret_cast<const unsigned*>(wr8 + j * 16));
+        }
+        if (G8OUT) {         // gelu'(u) from the fp32 u, as codes; then gelu(u) like the plain GELU epilogue
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                *reinterpret_cast<unsigned*>(wr8 + j * 16) = fd_g8_encode4(gelu_grad4_pk(val[j]));
+                // one column group at a time: left to itself the scheduler interleaves all six polynomial pairs and the
+                // 256-row instantiation spills 57 registers
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            u32x4 cv[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) cv[p] = *reinterpret_cast<const u32x4*>(stg + r8[p] * V2_EPI_LD8 + c8[p] * 16);
+            uint8_t* o8 = reinterpret_cast<uint8_t*>(g.out2_bf16);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int m = mbase + i * 16 + r8[p];
+                if (m < m_end && (p == 0 || lane < 32) && !(g.nostore & 1))
+                    *reinterpret_cast<u32x4*>(o8 + (size_t)m * g.ldo2 + nbase + c8[p] * 16) = cv[p];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) val[j] = gelu4_pk(val[j]);
         }
         put(g.out_bf16, g.ldo16, i, val);
     }
@@ -640,7 +707,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     auto run_epilogue = [&](int em0, int en0, int eml) {
         const int mb = em0 + wm * (16 * WM), nb = en0 + wn * 96, me = eml + 1;
         if (!(a.dbg & 8)) {
-            if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU)
+            if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU || EPI == FEDDAT_EPI_GELU_G8 ||
+                EPI == FEDDAT_EPI_MUL_G8)
                 v2_epilogue_bf16<EPI, WM>(g, acc, stg, mb, nb, me, lane);
             else
                 v2_epilogue<EPI, WM>(g, acc, stg, mb, nb, me, lane);
@@ -1122,14 +1190,16 @@ namespace {
 }  // namespace
 
 using V2Kernel = void (*)(GemmArgsV2);
-static const V2Kernel (*v2_kernel_table())[5] {
-    static const V2Kernel kernels[2][5] = {
+static const V2Kernel (*v2_kernel_table())[7] {
+    static const V2Kernel kernels[2][7] = {
         {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 3>,
          gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3>,
-         gemm_nt_v2_kernel<FEDDAT_EPI_F32, 3>},
+         gemm_nt_v2_kernel<FEDDAT_EPI_F32, 3>, gemm_nt_v2_kernel<FEDDAT_EPI_GELU_G8, 3>,
+         gemm_nt_v2_kernel<FEDDAT_EPI_MUL_G8, 3>},
         {gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 4>,
          gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 4>,
-         gemm_nt_v2_kernel<FEDDAT_EPI_F32, 4>}};
+         gemm_nt_v2_kernel<FEDDAT_EPI_F32, 4>, gemm_nt_v2_kernel<FEDDAT_EPI_GELU_G8, 4>,
+         gemm_nt_v2_kernel<FEDDAT_EPI_MUL_G8, 4>}};
     return kernels;
 }
 
@@ -1148,7 +1218,7 @@ int fd_prepare_gemm_kernels() {
             if (fd_set_max_lds((const void*)v3_kernel_table()[w][e], w ? V3Cfg<8>::LDS : V3Cfg<6>::LDS) != FEDDAT_OK)
                 return FEDDAT_ELAUNCH;
     for (int w = 0; w < 2; ++w)
-        for (int e = 0; e < 5; ++e)
+        for (int e = 0; e < 7; ++e)
             if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
                 return FEDDAT_ELAUNCH;
     if (fd_set_max_lds((const void*)gemm_nt_mid_kernel, MID_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
@@ -1163,9 +1233,13 @@ extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale,
                                   const float* b_scale, int M, int N, int K, int epi, const float* bias, const void* aux,
                                   int ldaux, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream) {
     FD_CHECK_ARG(A8 && B8 && a_scale && b_scale && out_bf16 && M >= 1024 && N > 0 && N % V2_BN == 0 && K > 0 && K % 128 == 0);
-    FD_CHECK_ARG(epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU);
+    FD_CHECK_ARG(epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU || epi == FEDDAT_EPI_GELU_G8 ||
+                 epi == FEDDAT_EPI_MUL_G8);
     FD_CHECK_ARG(epi != FEDDAT_EPI_MUL_DGELU || (aux && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0 &&
                                                 (size_t)M * ldaux * 2 < (1ull << 32)));
+    FD_CHECK_ARG(epi != FEDDAT_EPI_MUL_G8 || (aux && ldaux % 16 == 0 && ldaux >= N && ((uintptr_t)aux & 15) == 0 &&
+                                             (size_t)M * ldaux < (1ull << 32)));
+    FD_CHECK_ARG(epi != FEDDAT_EPI_GELU_G8 || (out2_bf16 && ldo2 % 16 == 0 && ldo2 >= N));
     FD_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
     FD_CHECK_ARG(!out2_bf16 || (ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0));
     GemmArgsV2 a2;
@@ -1195,12 +1269,16 @@ extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale,
     };
     GemmArgsV2 a3 = a2, a4 = a2;
     const int rounds3 = plan(192, a3), rounds4 = plan(256, a4);
-    const bool wm4 = rounds4 * 12 < rounds3 * 10 && epi != FEDDAT_EPI_MUL_DGELU;      // . gelu' stays on 192-row tiles (spills)
+    const bool wm4 = rounds4 * 12 < rounds3 * 10 && epi != FEDDAT_EPI_MUL_DGELU;      // . gelu'(bf16 u) stays on 192-row tiles (spills)
     a2 = wm4 ? a4 : a3;
     using KernelFn = void (*)(GemmArgsV2);
     KernelFn kern;
     if (epi == FEDDAT_EPI_MUL_DGELU) {
         kern = gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3, true>;
+    } else if (epi == FEDDAT_EPI_MUL_G8) {
+        kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_MUL_G8, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_MUL_G8, 3, true>;
+    } else if (epi == FEDDAT_EPI_GELU_G8) {
+        kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU_G8, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU_G8, 3, true>;
     } else if (fd_debug_flags() & 256) {      // tools/ A/B only: the CDNA3-style K = 32 fp8 instruction (bf16 issue rate)
         if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, true>;
         else kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true, true>;
@@ -1231,10 +1309,18 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             FD_CHECK_ARG(out_bf16 && aux && ldaux % 4 == 0 && ldo16 % 4 == 0 && (size_t)M * ldaux * 2 < (1ull << 32));
             break;
         case FEDDAT_EPI_F32: FD_CHECK_ARG(out_f32 && ldo32 % 4 == 0); break;
+        case FEDDAT_EPI_GELU_G8:
+            FD_CHECK_ARG(use_v2 && out_bf16 && out2_bf16 && ldo2 % 16 == 0 && ldo2 >= N && ((uintptr_t)out2_bf16 & 15) == 0);
+            break;
+        case FEDDAT_EPI_MUL_G8:
+            FD_CHECK_ARG(use_v2 && out_bf16 && aux && ldaux % 16 == 0 && ldaux >= N && ((uintptr_t)aux & 15) == 0 &&
+                         (size_t)M * ldaux < (1ull << 32));
+            break;
         default: return FEDDAT_EINVAL;
     }
+    const bool g8 = epi == FEDDAT_EPI_GELU_G8 || epi == FEDDAT_EPI_MUL_G8;
     if (use_v2) {      // 16-byte bf16 stores / aux loads of the persistent kernel's epilogue
-        if (epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU)
+        if (epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU || g8)
             FD_CHECK_ARG(ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
         if (epi == FEDDAT_EPI_GELU && out2_bf16) FD_CHECK_ARG(ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0);
         if (epi == FEDDAT_EPI_MUL_DGELU) FD_CHECK_ARG(ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0);
@@ -1285,7 +1371,8 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         // aux operand) -- in isolation v3 is level or ahead on those too (84 against 98 us for . gelu'), in the step, with
         // nothing cache-warm, it is behind (86 / 89 us against 82 / 81: tools/step_breakdown.py --detail); debug flag 1
         // keeps everything on v2, flag 2 forces v3
-        const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU;
+        const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU && !g8;
+        if (g8 && (dbg & (2 | 512))) return FEDDAT_EINVAL;      // the code epilogues exist on the two-group kernel only
         if (dbg & 512) {        // tools/gemm_defer_probe.py: the deferred-epilogue timing probe (RT = 6; wrong results)
             static const V2Kernel fk[5] = {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 6, 1>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 6, 1>,
                                            gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 6, 1>, gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 6, 1>,

@@ -43,8 +43,9 @@ extern "C" int feddat_vilt_layer_fwd(feddat_ctx* ctx, const feddat_vilt_layer_we
     FD_TRY(feddat_gemm_bf16_nt(A->ctx, H, W->wo, H, rows, H, H, FEDDAT_EPI_RESID_F32, W->bo, A->h_in, H, nullptr, 0, A->h2, H,
                                nullptr, 0, nullptr, 0, stream));
     FD_TRY(feddat_layernorm_fwd(A->h2, H, W->ln2_g, W->ln2_b, W->ln_eps, rows, H, A->x16, nullptr, A->st2, stream));
-    FD_TRY(feddat_gemm_bf16_nt(A->x16, H, W->w1, H, rows, I, H, FEDDAT_EPI_GELU, W->b1, nullptr, 0, nullptr, 0, nullptr, 0,
-                               A->f16, I, A->u, I, stream));
+    // A->u: what FFN2^T will need of the pre-GELU u -- 8-bit gelu'(u) codes where the persistent GEMM runs, else u in bf16
+    FD_TRY(feddat_gemm_bf16_nt(A->x16, H, W->w1, H, rows, I, H, rows >= 1024 ? FEDDAT_EPI_GELU_G8 : FEDDAT_EPI_GELU, W->b1,
+                               nullptr, 0, nullptr, 0, nullptr, 0, A->f16, I, A->u, I, stream));
     FD_TRY(feddat_gemm_bf16_nt(A->f16, I, W->w2, I, rows, H, I, FEDDAT_EPI_RESID_F32, W->b2, A->h2, H, nullptr, 0, A->h3, H,
                                nullptr, 0, nullptr, 0, stream));
     if (next_ln_g)
@@ -75,8 +76,8 @@ extern "C" int feddat_vilt_layer_bwd(feddat_ctx* ctx, const feddat_vilt_layer_we
         else FD_TRY(feddat_adapter_wgrad_partial(wsegs, nwseg, wgrad_partials, wgrad_partials_elems, H, 48, stream));
     }
     // FFN2^T (. gelu'), FFN1^T, LN2 backward (+ residual)
-    FD_TRY(feddat_gemm_bf16_nt(G->dh16, H, W->w2T, H, rows, I, H, FEDDAT_EPI_MUL_DGELU, nullptr, nullptr, 0, A->u, I, nullptr,
-                               0, G->dU, I, nullptr, 0, stream));
+    FD_TRY(feddat_gemm_bf16_nt(G->dh16, H, W->w2T, H, rows, I, H, rows >= 1024 ? FEDDAT_EPI_MUL_G8 : FEDDAT_EPI_MUL_DGELU, nullptr,
+                               nullptr, 0, A->u, I, nullptr, 0, G->dU, I, nullptr, 0, stream));
     FD_TRY(feddat_gemm_bf16_nt(G->dU, I, W->w1T, I, rows, H, I, FEDDAT_EPI_BF16, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
                                G->dx16, H, nullptr, 0, stream));
     FD_TRY(feddat_layernorm_bwd_dx(G->dx16, nullptr, H, A->h2, H, A->st2, W->ln2_g, G->dh3, H, rows, H, G->dh_out, H, G->dh16,

@@ -200,9 +200,15 @@ class ViltDatEngine:
         self.f16 = b16(R2, I)          # gelu(u), transient
         # layer 0 (shared body, R rows): only h3 is kept
         self.l0 = dict(qkv=b16(R, 3 * H), ctx=b16(R, H), lse=f32(B, self.heads, self.S), h2=f32(R, H), h3=f32(R, H))
+        # what FFN2^T needs of the pre-GELU u: 8-bit gelu'(u) codes where the persistent GEMM applies (FEDDAT_EPI_GELU_G8 /
+        # _MUL_G8, M >= 1024: 25 % fewer bytes through the two HBM-bound epilogues), else u itself in bf16
+        self.g8u = R2 >= 1024
+
+        def u_buf():
+            return torch.empty(R2, I, dtype=torch.uint8, device=dev) if self.g8u else b16(R2, I)
         self.act = [None] + [dict(h_in=f32(R2, H), st1=f32(R2, 2), qkv=b16(R2, 3 * H), ctx=b16(R2, H),
                                   lse=f32(2 * B, self.heads, self.S), h2=f32(R2, H), st2=f32(R2, 2),
-                                  u=b16(R2, I), h3=f32(R2, H)) for _ in range(1, layers)]
+                                  u=u_buf(), h3=f32(R2, H)) for _ in range(1, layers)]
         self.h_out = f32(R2, H)        # output of the last adapter (dense path: single-layer models only)
         # top layer: only token 0 of each sample feeds the pooler, so everything after its attention runs on 2B rows
         nb2 = 2 * B
@@ -359,6 +365,7 @@ class ViltDatEngine:
         Adaptered_ViltOutput dense+residual (adaptered_output.py:74-76); returns the adapter input in h3."""
         W, H = self.layers[i], self.H
         x16, f16 = self.x16[:rows], self.f16[:rows]
+        g8 = u is not None and u.dtype == torch.uint8
         if self._fp8_rows(rows):           # fp8 MFMA for the two products fed by a LayerNorm
             x8, xs = self.x8[:rows], self.xs[:rows]
             L.layernorm_fwd_fp8(h_in, W["ln1g"], W["ln1b"], self.ln_eps, rows, H, x8, xs, stats=st1)
@@ -366,7 +373,7 @@ class ViltDatEngine:
             L.attn_fwd(qkv, ctx, lse, nb, self.S, self.heads, key_mask=mask)
             L.gemm_bf16_nt(ctx, W["wo"], L.EPI_RESID_F32, bias=W["bo"], resid=h_in, out_f32=h2)
             L.layernorm_fwd_fp8(h2, W["ln2g"], W["ln2b"], self.ln_eps, rows, H, x8, xs, stats=st2)
-            L.gemm_fp8_nt(x8, xs, W["w18"], W["s1"], L.EPI_GELU, bias=W["b1"], out_bf16=f16,
+            L.gemm_fp8_nt(x8, xs, W["w18"], W["s1"], L.EPI_GELU_G8 if g8 else L.EPI_GELU, bias=W["b1"], out_bf16=f16,
                           out2_bf16=u if u is not None else self.dU[:rows])
             L.gemm_bf16_nt(f16, W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=h2, out_f32=h3)
             return
@@ -376,7 +383,7 @@ class ViltDatEngine:
         L.attn_fwd(qkv, ctx, lse, nb, self.S, self.heads, key_mask=mask)
         L.gemm_bf16_nt(ctx, W["wo"], L.EPI_RESID_F32, bias=W["bo"], resid=h_in, out_f32=h2)
         L.layernorm_fwd(h2, W["ln2g"], W["ln2b"], self.ln_eps, rows, H, y_bf16=x16, stats=st2)
-        L.gemm_bf16_nt(x16, W["w1"], L.EPI_GELU, bias=W["b1"], out_bf16=f16, out2_bf16=u)
+        L.gemm_bf16_nt(x16, W["w1"], L.EPI_GELU_G8 if g8 else L.EPI_GELU, bias=W["b1"], out_bf16=f16, out2_bf16=u)
         L.gemm_bf16_nt(f16, W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=h2, out_f32=h3)
 
     def _fp8_rows(self, rows: int) -> bool:
@@ -565,7 +572,8 @@ class ViltDatEngine:
                 L.adapter_bwd_fp8(cur, oth, self.g8, self.gsc, self._segs(i, False, True), R2, z_saved=self.zsave[i],
                                   z_out=self.z, dz_out=self.dz)
                 self._adapter_wgrads(i, a["h3"], 0, cur)
-                L.gemm_fp8_nt(self.g8, self.gsc, W["w2T8"], W["s2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
+                L.gemm_fp8_nt(self.g8, self.gsc, W["w2T8"], W["s2T"], L.EPI_MUL_G8 if self.g8u else L.EPI_MUL_DGELU, aux=a["u"],
+                              out_bf16=self.dU)
                 L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
                 L.layernorm_bwd_dx_fp8(a["h2"], a["st2"], W["ln2g"], R2, H, self.g8, self.gsc, dy_bf16=self.dx16, dres=oth,
                                        out_f32=cur)
@@ -580,7 +588,7 @@ class ViltDatEngine:
                 L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
                               dz_out=self.dz, z_saved=self.zsave[i])
                 self._adapter_wgrads(i, a["h3"], 0, cur)
-                L.gemm_bf16_nt(self.dh16, W["w2T"], L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
+                L.gemm_bf16_nt(self.dh16, W["w2T"], L.EPI_MUL_G8 if self.g8u else L.EPI_MUL_DGELU, aux=a["u"], out_bf16=self.dU)
                 L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
                 L.layernorm_bwd_dx(a["h2"], a["st2"], W["ln2g"], R2, H, dy_bf16=self.dx16, dres=oth, out_f32=cur,
                                    out_bf16=self.dh16)

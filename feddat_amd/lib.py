@@ -15,7 +15,8 @@ import torch  # imported first on purpose: libfeddat_hip.so must bind to the HIP
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfeddat_hip.so")
 
-EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32, EPI_GELU_G8, EPI_MUL_G8 = 0, 1, 2, 3, 4, 5, 6
+G8_LO, G8_STEP = -0.135, 0.005        # FEDDAT_G8_LO / FEDDAT_G8_STEP: gelu' ~ G8_LO + G8_STEP * code
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 
@@ -154,7 +155,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes", "_table_entries")) else i32
-    if lib.feddat_abi_version() != 4:
+    if lib.feddat_abi_version() != 5:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
     if os.environ.get("FEDDAT_GEMM_DEBUG"):       # tools/ ablations: the env var is read HERE, never by the library
         lib.feddat_set_debug_flags(int(os.environ["FEDDAT_GEMM_DEBUG"]))

@@ -29,7 +29,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_EINVAL 1
 #define FEDDAT_ELAUNCH 2
 
-#define FEDDAT_ABI_VERSION 4   /* 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
+#define FEDDAT_ABI_VERSION 5   /* 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -67,12 +67,23 @@ int feddat_set_debug_flags(int flags);
 #define FEDDAT_EPI_GELU 2       /* out2_bf16 = u = acc + bias (optional); out_bf16 = gelu(u) */
 #define FEDDAT_EPI_MUL_DGELU 3  /* out_bf16 = (acc) * gelu'(aux_bf16)                        */
 #define FEDDAT_EPI_F32 4        /* out_f32  = acc + bias                                    */
+/* The GELU pair with the saved tensor at 8 bits instead of 16 (the FFN pair of a ViLT layer moves 25 % fewer bytes in its
+ * HBM-bound epilogues).  gelu'(u) is computed from the fp32 u in the FFN1 epilogue and stored as a uint8 code:
+ *   code = round((gelu'(u) - FEDDAT_G8_LO) / FEDDAT_G8_STEP),  gelu'(u) ~ FEDDAT_G8_LO + FEDDAT_G8_STEP * code,
+ * |error| <= 2.5e-3 over gelu's whole range [-0.129, 1.129] (the bf16 u of FEDDAT_EPI_GELU carries |u| 2^-9 |gelu''(u)|, the
+ * same size at |u| ~ 1).  out2 / aux are uint8 [M, N] here (ldo2 / ldaux in BYTES, % 16 == 0, 16-byte aligned).  Persistent
+ * kernels only: M >= 1024 and N % 192 == 0 (FEDDAT_EINVAL otherwise). */
+#define FEDDAT_EPI_GELU_G8 5    /* out2 = uint8 codes of gelu'(acc + bias); out_bf16 = gelu(acc + bias) */
+#define FEDDAT_EPI_MUL_G8 6     /* out_bf16 = (acc) * (FEDDAT_G8_LO + FEDDAT_G8_STEP * aux_u8)        */
+#define FEDDAT_G8_LO (-0.135f)     /* = -27 steps */
+#define FEDDAT_G8_STEP 0.005f
 int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
                         const float* bias, const float* resid, int ldr, const void* aux, int ldaux, float* out_f32,
                         int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream);
 /* configs[4]: fp8 (OCP e4m3) MFMA for frozen linears.  A8 [M,K] and B8 [N,K] are e4m3 with per-row scales (a_scale [M],
- * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias; epilogue BF16, GELU or MUL_DGELU (aux_bf16 =
- * the saved pre-GELU u) as above -- the last one is the dX product of FFN2 with A8 = the e4m3 row-quantised gradient).
+ * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias; epilogue BF16, GELU / GELU_G8 or
+ * MUL_DGELU / MUL_G8 (aux = the saved pre-GELU u, or the gelu' codes) as above -- the last pair is the dX product of FFN2
+ * with A8 = the e4m3 row-quantised gradient).
  * Same persistent kernel and data movement as the bf16 form (128 fp8 per 128-byte LDS row); the MFMA is the CDNA4
  * block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the bf16 rate).
  * Requirements: M >= 1024, N % 192 == 0, K % 128 == 0, lda / ldb % 16 == 0, 16-byte aligned outputs.
@@ -271,7 +282,7 @@ typedef struct {
     float* lse;          /* fp32 [nb,heads,S] */
     float* h2;           /* fp32 [rows,768] */
     float* st2;          /* fp32 [rows,2] */
-    void* u;             /* bf16 [rows,3072] pre-GELU */
+    void* u;             /* rows >= 1024: uint8 [rows,3072] gelu'(u) codes (FEDDAT_EPI_GELU_G8); fewer rows: bf16 [rows,3072] pre-GELU u */
     float* h3;           /* fp32 [rows,768] adapter input */
     float* z_save;       /* fp32 [rows,2,48] or NULL (the backward then recomputes from h3) */
     float* h_out;        /* fp32 [rows,768] */

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/feddat_hip.h but not exported"
-    assert lib.feddat_abi_version() == 4
+    assert lib.feddat_abi_version() == 5
 
 
 def test_python_binding_covers_the_header():

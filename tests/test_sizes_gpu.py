@@ -184,3 +184,72 @@ def test_gemm_production_shapes_per_element(M, N, K):
     L.gemm_bf16_nt(Ah, Bh, L.EPI_F32, bias=bias, out_f32=o32)
     check(o32, ref + bias.double(), 2e-5, AT, "f32")
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,fp8", [(11840, 3072, 768, False), (5920, 3072, 768, False), (1030, 192, 64, False),
+                                       (11840, 3072, 768, True)])
+def test_gemm_gelu_code_epilogues(M, N, K, fp8):
+    """FEDDAT_EPI_GELU_G8 / FEDDAT_EPI_MUL_G8 (8-bit gelu' codes in place of the bf16 u).  Against the fp64 product:
+      codes   within 1 of round((gelu'(u) - LO) / STEP) everywhere, equal on > 97 % (the packed-polynomial gelu' is within
+              3.2e-4 = 0.064 steps of the exact derivative, so only values near a rounding boundary may differ);
+      gelu    the bf16 output as in the plain GELU epilogue;
+      . code  out = (A B^T) * (LO + STEP * code) per element to bf16 rounding -- i.e. exact in the code it was given;
+      end to end: (A B^T) * decode(encode(gelu'(u))) differs from (A B^T) * gelu'(u) by at most STEP / 2 + 3.2e-4 relative to
+              |A B^T| -- the stated 2.5e-3 bound of the header."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import lib as L
+    L.load()
+    g = torch.Generator(device="cpu").manual_seed(5 * M + N + K)
+    Af = torch.randn(M, K, generator=g)
+    Bf = torch.randn(N, K, generator=g) * (1.5 / K ** 0.5)
+    bias = torch.randn(N, generator=g).to(DEV)
+    if fp8:
+        A8, B8 = torch.empty(M, K, dtype=torch.uint8, device=DEV), torch.empty(N, K, dtype=torch.uint8, device=DEV)
+        sa, sb = torch.empty(M, device=DEV), torch.empty(N, device=DEV)
+        L.quant_rows_fp8(Af.to(DEV), A8, sa)
+        L.quant_rows_fp8(Bf.to(DEV), B8, sb)
+        Ad = A8.view(torch.float8_e4m3fn).double() * sa.double()[:, None]
+        Bd = B8.view(torch.float8_e4m3fn).double() * sb.double()[:, None]
+    else:
+        Ah, Bh = Af.to(torch.bfloat16).to(DEV), Bf.to(torch.bfloat16).to(DEV)
+        Ad, Bd = Ah.double(), Bh.double()
+    ref = Ad @ Bd.t()
+    u = (ref + bias.double()).requires_grad_(True)
+    F.gelu(u).sum().backward()
+    gp = u.grad
+    f16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    code = torch.empty(M, N, dtype=torch.uint8, device=DEV)
+    if fp8:
+        L.gemm_fp8_nt(A8, sa, B8, sb, L.EPI_GELU_G8, bias=bias, out_bf16=f16, out2_bf16=code)
+    else:
+        L.gemm_bf16_nt(Ah, Bh, L.EPI_GELU_G8, bias=bias, out_bf16=f16, out2_bf16=code)
+    want = torch.round((gp - L.G8_LO) / L.G8_STEP)
+    dc = (code.double() - want).abs()
+    assert float(dc.max()) <= 1, float(dc.max())
+    assert float((dc == 0).double().mean()) > 0.97
+    fg = F.gelu(u.detach())
+    assert bool(((f16.double() - fg).abs() <= 2e-4 + 2.0 ** -8 * fg.abs()).all())
+    dec = L.G8_LO + L.G8_STEP * code.double()
+    assert float((dec - gp).abs().max()) <= L.G8_STEP / 2 + 4e-4
+    # . code on a fresh product (the FFN2^T shape is the transpose role: same kernel, aux = codes)
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    if fp8:
+        L.gemm_fp8_nt(A8, sa, B8, sb, L.EPI_MUL_G8, aux=code, out_bf16=o16)
+    else:
+        L.gemm_bf16_nt(Ah, Bh, L.EPI_MUL_G8, aux=code, out_bf16=o16)
+    w = ref * dec
+    assert bool(((o16.double() - w).abs() <= 2e-4 + 2.0 ** -8 * w.abs()).all())
+    torch.cuda.synchronize()
+
+
+def test_gemm_gelu_code_epilogues_need_the_persistent_kernel():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import lib as L
+    L.load()
+    A = torch.zeros(512, 64, dtype=torch.bfloat16, device=DEV)
+    B = torch.zeros(192, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.FeddatHipError):
+        L.gemm_bf16_nt(A, B, L.EPI_GELU_G8, out_bf16=torch.empty(512, 192, dtype=torch.bfloat16, device=DEV),
+                       out2_bf16=torch.empty(512, 192, dtype=torch.uint8, device=DEV))

@@ -51,4 +51,6 @@ names = {0: "as built", 1: "no stores", 2: "no phase-A arithmetic", 4: "no phase
 for flag in (0, 1, 2, 4, 6, 7):
     L.set_debug_flags(flag << 20)
     print(f"{names[flag]:42s} warm {warm(bwd):6.1f} us   cold {cold(bwd):6.1f} us", flush=True)
+L.set_debug_flags(8 << 20)
+print(f"{'one block per pair (r02 launch, bit 23)':42s} warm {warm(bwd):6.1f} us   cold {cold(bwd):6.1f} us", flush=True)
 L.set_debug_flags(0)
