@@ -134,6 +134,27 @@ __device__ __forceinline__ f32x2 gelu_grad_pk(f32x2 u) {
                             -7.304086803e+02f, 5.886747112e+02f, -2.703110568e+02f, 5.369588787e+01f};
     return odd_poly9_pk(clamp_unit_pk(u), C) + f32x2{0.5f, 0.5f};
 }
+// gelu(u) AND gelu'(u) (the FFN1 epilogue that stores 8-bit gelu' codes): gelu' = 1/2 + erf(u / sqrt 2) / 2 + u phi(u) shares
+// the erf polynomial with gelu; u phi(u) = u exp2(-u^2 log2(e) / 2) / sqrt(2 pi) costs one v_exp_f32 (~5/3 of a VALU slot on
+// gfx950) + 5 packed ops per element pair instead of a second 9-coefficient polynomial (14 packed ops).  |error| of this
+// gelu' <= 2.7e-5 + the exp's ulp.
+__device__ __forceinline__ void gelu_and_grad_pk(f32x2 u, f32x2& f, f32x2& gp) {
+    constexpr float C[9] = {3.589798371e+00f, -1.207231863e+01f, 3.590728051e+01f, -8.046883329e+01f, 1.320808609e+02f,
+                            -1.519935397e+02f, 1.145676310e+02f, -5.029529085e+01f, 9.684438904e+00f};
+    const f32x2 e = odd_poly9_pk(clamp_unit_pk(u), C);
+    const f32x2 h = u * f32x2{0.5f, 0.5f};
+    f = h * e + h;
+    const f32x2 a = (u * u) * f32x2{-0.72134752044448170f, -0.72134752044448170f};
+    const f32x2 ux = u * f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    gp = ux * f32x2{0.39894228040143268f, 0.39894228040143268f} + (e * f32x2{0.5f, 0.5f} + f32x2{0.5f, 0.5f});
+}
+__device__ __forceinline__ void gelu_and_grad4_pk(f32x4 u, f32x4& f, f32x4& gp) {
+    f32x2 f0, f1, g0, g1;
+    gelu_and_grad_pk(f32x2{u[0], u[1]}, f0, g0);
+    gelu_and_grad_pk(f32x2{u[2], u[3]}, f1, g1);
+    f = f32x4{f0[0], f0[1], f1[0], f1[1]};
+    gp = f32x4{g0[0], g0[1], g1[0], g1[1]};
+}
 __device__ __forceinline__ f32x4 gelu4_pk(f32x4 u) {
     const f32x2 a = gelu_pk(f32x2{u[0], u[1]}), b = gelu_pk(f32x2{u[2], u[3]});
     return f32x4{a[0], a[1], b[0], b[1]};

@@ -508,13 +508,14 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
             for (int j = 0; j < 6; ++j) val[j] = val[j] * fd_g8_decode4(*reinterpret_cast<const unsigned*>(wr8 + j * 16));
         }
-        if (G8OUT) {         // gelu'(u) from the fp32 u, as codes; then gelu(u) like the plain GELU epilogue
+        if (G8OUT) {         // gelu'(u) from the fp32 u, as codes, and gelu(u): one pass, shared erf polynomial
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                *reinterpret_cast<unsigned*>(wr8 + j * 16) = fd_g8_encode4(gelu_grad4_pk(val[j]));
-                // one column group at a time: left to itself the scheduler interleaves all six polynomial pairs and the
-                // 256-row instantiation spills 57 registers
-                __builtin_amdgcn_sched_barrier(0);
+                f32x4 fj, gj;
+                gelu_and_grad4_pk(val[j], fj, gj);
+                // (debug flag 4, timing only: codes without the gelu' arithmetic)
+                *reinterpret_cast<unsigned*>(wr8 + j * 16) = fd_g8_encode4((g.nostore & 2) ? val[j] : gj);
+                val[j] = fj;
             }
             u32x4 cv[2];
 #pragma unroll
@@ -526,8 +527,6 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
                 if (m < m_end && (p == 0 || lane < 32) && !(g.nostore & 1))
                     *reinterpret_cast<u32x4*>(o8 + (size_t)m * g.ldo2 + nbase + c8[p] * 16) = cv[p];
             }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) val[j] = gelu4_pk(val[j]);
         }
         put(g.out_bf16, g.ldo16, i, val);
     }
