@@ -32,13 +32,13 @@ def flops_tables(B, S, layers=12, H=768, I=3072, heads=12, r=48, npatch=144):
     R = B * S
     lin = lambda M, N, K: 2.0 * M * N * K  # noqa: E731
     gemms = []  # (M, N, K, epi, count)
-    fwd_shapes = [(3 * H, H, 0), (H, H, 1), (I, H, 2), (H, I, 1)]
-    bwd_shapes = [(I, H, 3), (H, I, 0), (H, H, 0), (H, 3 * H, 0)]
+    fwd_shapes = [(3 * H, H, 0), (H, H, 1), (I, H, 2), (H, I, 1)]     # (FFN1 of the batched layers: epi 5, set below)
+    bwd_shapes = [(I, H, 6 if 2 * R >= 1024 else 3), (H, I, 0), (H, H, 0), (H, 3 * H, 0)]
     # layer 0: shared body on R rows; layers 1..L-2: both passes batched (2R rows); top layer: QKV (and its dX) on all
     # tokens, everything behind the attention only on the 2B token-0 rows (negligible, not listed)
     for N, K, epi in fwd_shapes:
         gemms.append((R, N, K, epi, 1))
-        gemms.append((2 * R, N, K, epi, layers - 1 if N == 3 * H else layers - 2))
+        gemms.append((2 * R, N, K, 5 if epi == 2 and 2 * R >= 1024 else epi, layers - 1 if N == 3 * H else layers - 2))
     for N, K, epi in bwd_shapes:
         gemms.append((2 * R, N, K, epi, layers - 1 if K == 3 * H else layers - 2))
     gemms.append((B * npatch, H, 3 * 32 * 32, 4, 1))
@@ -61,10 +61,14 @@ def measure_gemms(L, gemms, iters=10):
         Bw = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
         bias = torch.randn(N, device=dev)
         kw = {}
-        if epi in (0, 3):
+        if epi in (0, 3, 5, 6):
             kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         if epi == 3:
             kw["aux"] = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        if epi == 5:
+            kw["out2_bf16"] = torch.empty(M, N, dtype=torch.uint8, device=dev)
+        if epi == 6:
+            kw["aux"] = torch.randint(0, 255, (M, N), dtype=torch.uint8, device=dev)
         if epi == 2:
             kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             kw["out2_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
@@ -73,7 +77,7 @@ def measure_gemms(L, gemms, iters=10):
             kw["out_f32"] = torch.empty(M, N, device=dev)
         if epi == 4:
             kw["out_f32"] = torch.empty(M, N, device=dev)
-        if epi != 3:
+        if epi not in (3, 6):
             kw["bias"] = bias
         for _ in range(3):
             L.gemm_bf16_nt(A, Bw, epi, **kw)
@@ -97,7 +101,9 @@ def gemm_algorithmic_bytes(M, N, K, epi):
            1: 4 * M * N + 4 * M * N,  # fp32 residual in + fp32 out
            2: 2 * M * N + 2 * M * N,  # gelu(u) + u, both bf16
            3: 2 * M * N + 2 * M * N,  # u in (bf16) + bf16 out
-           4: 4 * M * N}[epi]
+           4: 4 * M * N,
+           5: 2 * M * N + M * N,      # gelu(u) bf16 + 8-bit gelu'(u) codes
+           6: M * N + 2 * M * N}[epi]  # codes in + bf16 out
     return 2 * M * K + 2 * N * K + out + 4 * N
 
 

@@ -179,10 +179,13 @@ class AlbefDatEngine:
 
         def vit_set():
             Mi = self.Mi
+
+            def u_img():     # what fc2^T needs of the pre-GELU u: 8-bit gelu' codes where FEDDAT_EPI_GELU_G8 applies, else bf16 u
+                return torch.empty(Mi, I, dtype=torch.uint8, device=dev) if Mi >= 1024 else b16(Mi, I)
             return dict(patches=b16(B * (self.Ni - 1), 3 * self.P * self.P), proj=f32(B * (self.Ni - 1), H),
                         h0=f32(Mi, H), st0=f32(Mi, 2), x16=b16(Mi, H), f16=b16(Mi, I),
                         blocks=[dict(h_in=f32(Mi, H) if i else None, st1=f32(Mi, 2), qkv=b16(Mi, 3 * H), ctx=b16(Mi, H),
-                                     lse=f32(self.B, self.heads, self.Ni), h2=f32(Mi, H), st2=f32(Mi, 2), u=b16(Mi, I),
+                                     lse=f32(self.B, self.heads, self.Ni), h2=f32(Mi, H), st2=f32(Mi, 2), u=u_img(),
                                      h3=f32(Mi, H), zs=f32(Mi, 2, self.r)) for i in range(self.vd)],
                         out=f32(Mi, H), stf=f32(Mi, 2), emb16=b16(Mi, H))
 
@@ -328,7 +331,8 @@ class AlbefDatEngine:
             L.attn2_fwd(q, k, v, A["ctx"], A["lse"], B, Ni, Ni, self.heads)
             L.gemm_bf16_nt(A["ctx"], W["proj"]["w"], L.EPI_RESID_F32, bias=W["proj"]["b"], resid=h, out_f32=A["h2"])
             L.layernorm_fwd(A["h2"], W["n2g"], W["n2b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=A["st2"])
-            L.gemm_bf16_nt(V["x16"], W["fc1"]["w"], L.EPI_GELU, bias=W["fc1"]["b"], out_bf16=V["f16"], out2_bf16=A["u"])
+            L.gemm_bf16_nt(V["x16"], W["fc1"]["w"], L.EPI_GELU_G8 if A["u"].dtype == torch.uint8 else L.EPI_GELU,
+                           bias=W["fc1"]["b"], out_bf16=V["f16"], out2_bf16=A["u"])
             L.gemm_bf16_nt(V["f16"], W["fc2"]["w"], L.EPI_RESID_F32, bias=W["fc2"]["b"], resid=A["h2"], out_f32=A["h3"])
             last = i == self.vd - 1
             nxt = V["out"] if last else V["blocks"][i + 1]["h_in"]
@@ -493,7 +497,8 @@ class AlbefDatEngine:
             L.adapter_bwd(None, cur, oth, self._segs(i, mode, Mi, True), Mi, dx_bf16=g["b1"][:Mi], z_out=g["z"],
                           dz_out=g["dz"], z_saved=A["zs"])
             self._wgrad(i, mode, A["h3"], cur, Mi)
-            L.gemm_bf16_nt(g["b1"][:Mi], W["fc2"]["wT"], L.EPI_MUL_DGELU, aux=A["u"], out_bf16=g["bI"][:Mi])
+            L.gemm_bf16_nt(g["b1"][:Mi], W["fc2"]["wT"], L.EPI_MUL_G8 if A["u"].dtype == torch.uint8 else L.EPI_MUL_DGELU,
+                           aux=A["u"], out_bf16=g["bI"][:Mi])
             L.gemm_bf16_nt(g["bI"][:Mi], W["fc1"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:Mi])
             L.layernorm_bwd_dx(A["h2"], A["st2"], W["n2g"], Mi, H, dy_bf16=g["b2"][:Mi], dres=oth, out_f32=cur,
                                out_bf16=g["b1"][:Mi])
