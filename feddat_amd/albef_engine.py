@@ -671,8 +671,9 @@ class AlbefDatEngine:
         """ALBEF.forward(train=False) -> rank_answer (albef_model.py:147-156,171-228; eval loop task_trainer.py:159-204):
         first-token shortlist of k candidates per question out of the answer list, re-ranked by sequence likelihood.
         The engine must have been built with n_answers = B * k and a_len = answer_ids.shape[1].
-        Returns (topk_ids [B,k] int64, topk_probs [B,k]).  The two decoder passes run on the HIP kernels; the top-k
-        selections and the k-way softmax over B x k scalars are index bookkeeping done with torch on the device."""
+        Returns (topk_ids [B,k] int64, topk_probs [B,k]).  The two decoder passes, the first-token softmax over the
+        vocabulary (feddat_softmax_gather_rows) and both top-k selections (feddat_topk_rows) run on the HIP kernels; what is left
+        to torch is index bookkeeping (index_select / gather of the shortlisted answers)."""
         B, N, La, V = self.B, self.N, self.La, self.V
         if N != B * k or answer_ids.shape[1] != La:
             raise L.FeddatHipError("rank_answer: engine must be built with n_answers = B * k and a_len = answer length")
@@ -687,9 +688,10 @@ class AlbefDatEngine:
             m0 = torch.zeros(N, La, dtype=torch.int64, device=self.dev)
             m0[:, 0] = 1
             self.set_batch(dict(batch, answer_ids=start, answer_mask=m0, weights=torch.ones(N, device=self.dev), k=[k] * B))
-            logits = self._forward(mode).view(N, La - 1, self.Vp)[::k, 0, :V]        # position 0 of one slot per question
-            prob_first = torch.softmax(logits, 1).index_select(1, answer_ids[:, 1])
-            topk_probs, topk_ids = prob_first.topk(k, 1)
+            lg = self._forward(mode)          # [N (La - 1), Vp] fp32; position 0 of one slot per question = row b k (La - 1)
+            prob_first = torch.empty(B, answer_ids.shape[0], device=self.dev)
+            L.softmax_gather_rows(lg, B, k * (La - 1) * lg.stride(0), V, answer_ids[:, 1], prob_first)
+            topk_probs, topk_ids = L.topk_rows(prob_first, k)
             # pass 2: the shortlisted answers, per-answer next-token loss
             ids = answer_ids.index_select(0, topk_ids.reshape(-1))
             atts = answer_mask.index_select(0, topk_ids.reshape(-1))
@@ -701,9 +703,8 @@ class AlbefDatEngine:
         finally:
             if mode != key:
                 del self.acts[mode]
-        log_probs = (topk_probs.reshape(-1).log() - answer_loss).view(B, k)
-        probs = torch.softmax(log_probs, -1)
-        probs, rerank = probs.topk(k, 1)
+        # softmax(log(topk_probs) - answer_loss) over the k candidates, sorted (albef_model.py:223-226)
+        probs, rerank = L.topk_rows(topk_probs, k, minus=answer_loss.view(B, k).contiguous(), log_first=True, softmax=True)
         return torch.gather(topk_ids, 1, rerank), probs
 
     def image_embeds(self, mode_key: str = "gating"):

@@ -159,7 +159,116 @@ __global__ void lm_loss_finish(const float* __restrict__ row_terms, int R, float
     }
 }
 
+// rank_answer, step 1 (albef_model.py:183-186): prob_first[b, j] = softmax(logits[b, :V])[first_ids[j]].  One block per
+// question: log-sum-exp of the row over the vocabulary, then the gather.
+__global__ __launch_bounds__(256) void softmax_gather_kernel(const float* __restrict__ logits, long row_stride, int V,
+                                                             const long* __restrict__ ids, long id_stride, int n,
+                                                             float* __restrict__ out) {
+    __shared__ float red[8];
+    const float* row = logits + (size_t)blockIdx.x * row_stride;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, row[c]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) sum += __expf(row[c] - m);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+    __syncthreads();
+    const float lse = m + __logf(red[4] + red[5] + red[6] + red[7]);
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const long id = ids[(size_t)j * id_stride];
+        out[(size_t)blockIdx.x * n + j] = id >= 0 && id < V ? __expf(row[id] - lse) : 0.f;
+    }
+}
+
+// rank_answer, steps 2 and 4 (albef_model.py:186,223-226): the k largest of a row of n values, sorted descending (equal
+// values: lower index first).  Optional transforms ahead of the sort: flag 1: v = log(v); minus: v -= minus[row, j];
+// flag 2: v = softmax over the row.  One block per row, bitonic sort of (value, index) pairs in LDS (n padded to a
+// power of two with -inf).
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ vals, long ld, const float* __restrict__ minus,
+                                                        int n, int n2, int k, int flags, float* __restrict__ out_vals,
+                                                        long* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* v = reinterpret_cast<float*>(smem);
+    int* ix = reinterpret_cast<int*>(smem + (size_t)n2 * 4);
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int j = tid; j < n2; j += 256) {
+        float x = -INFINITY;
+        if (j < n) {
+            x = vals[(size_t)row * ld + j];
+            if (flags & 1) x = __logf(x);
+            if (minus) x -= minus[(size_t)row * n + j];
+        }
+        v[j] = x;
+        ix[j] = j;
+        m = fmaxf(m, x);
+    }
+    if (flags & 2) {
+        m = wave_max(m);
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sum = 0.f;
+        for (int j = tid; j < n; j += 256) {
+            const float e = __expf(v[j] - m);
+            v[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+        __syncthreads();
+        const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+        for (int j = tid; j < n; j += 256) v[j] *= inv;
+    }
+    __syncthreads();
+    // "a before b": larger value first, ties by lower index
+    auto before = [](float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); };
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += 256) {
+                const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+                const bool desc = ((lo & size) == 0);        // this run sorts "before" first
+                const float va = v[lo], vb = v[hi];
+                const int ia = ix[lo], ib = ix[hi];
+                const bool swap = desc ? before(vb, ib, va, ia) : before(va, ia, vb, ib);
+                if (swap) {
+                    v[lo] = vb; v[hi] = va;
+                    ix[lo] = ib; ix[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += 256) {
+        out_vals[(size_t)row * k + j] = v[j];
+        out_idx[(size_t)row * k + j] = ix[j];
+    }
+}
+
 }  // namespace
+
+extern "C" int feddat_softmax_gather_rows(const float* logits, long row_stride, int rows, int V, const long* ids,
+                                          long id_stride, int n, float* out, hipStream_t stream) {
+    FD_CHECK_ARG(logits && ids && out && rows > 0 && V > 0 && n > 0 && row_stride >= V && id_stride >= 1);
+    hipLaunchKernelGGL(softmax_gather_kernel, dim3(rows), dim3(256), 0, stream, logits, row_stride, V, ids, id_stride, n, out);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_topk_rows(const float* vals, long ld, const float* minus, int rows, int n, int k, int flags,
+                                float* out_vals, long* out_idx, hipStream_t stream) {
+    FD_CHECK_ARG(vals && out_vals && out_idx && rows > 0 && n > 0 && k > 0 && k <= n && ld >= n && n <= 8192 && !(flags & ~3));
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    const int lds = n2 * 8;
+    if (lds > 48 * 1024 && fd_set_max_lds((const void*)topk_rows_kernel, lds) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), lds, stream, vals, ld, minus, n, n2, k, flags, out_vals, out_idx);
+    FD_LAUNCH_RET();
+}
 
 extern "C" int feddat_axpby3(const float* a, float alpha, const float* b, float beta, const float* c, float gamma,
                              float* out_f32, void* out_bf16, long n, hipStream_t stream) {

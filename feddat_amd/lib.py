@@ -105,6 +105,8 @@ _SIGS = {
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
     "feddat_lm_loss_fwd_bwd": [vp, vp, i64, vp, vp, i32, i32, f32, f32, vp, i64, vp, vp],
     "feddat_axpby3": [vp, f32, vp, f32, vp, f32, vp, vp, i64, vp],
+    "feddat_softmax_gather_rows": [vp, i64, i32, i32, vp, i64, i32, vp, vp],
+    "feddat_topk_rows": [vp, i64, vp, i32, i32, i32, i32, vp, vp, vp],
     "feddat_gather_rows": [vp, vp, vp, vp, i32, i32, vp],
     "feddat_segment_sum_rows": [vp, vp, vp, i32, i32, i32, vp],
     "feddat_adamw_flat": [vp, vp, vp, vp, i64, vp, vp, i32, vp, f32, i32, i32, f32, f32, f32, vp],
@@ -510,6 +512,28 @@ def lm_loss_fwd_bwd(logits, teacher, labels, row_weight, V, temp, kl_scale, dlog
     _chk(load().feddat_lm_loss_fwd_bwd(_p(logits), _p(teacher), logits.stride(0), _p(labels), _p(row_weight), R, V, temp,
                                        kl_scale, _p(dlogits_bf16), 0 if dlogits_bf16 is None else dlogits_bf16.stride(0),
                                        _p(scalars), _stream()), "feddat_lm_loss_fwd_bwd")
+
+
+def softmax_gather_rows(logits, rows, row_stride, V, ids, out):
+    """out[r, j] = softmax(logits.flatten()[r * row_stride : r * row_stride + V])[ids[j]]; ids int64 (any 1-D stride)."""
+    _dev(logits, ids, out)
+    assert logits.dtype == torch.float32 and ids.dtype == torch.int64 and out.dtype == torch.float32 and out.is_contiguous()
+    n = ids.shape[0]
+    assert out.shape == (rows, n)
+    _chk(load().feddat_softmax_gather_rows(_p(logits), row_stride, rows, V, _p(ids), ids.stride(0), n, _p(out), _stream()),
+         "feddat_softmax_gather_rows")
+
+
+def topk_rows(vals, k, *, minus=None, log_first=False, softmax=False):
+    """-> (values [rows, k] fp32, indices [rows, k] int64), descending; ties: lower index first."""
+    _dev(vals, minus)
+    rows, n = vals.shape
+    assert vals.dtype == torch.float32 and vals.stride(1) == 1 and (minus is None or (minus.is_contiguous() and minus.shape == vals.shape))
+    ov = torch.empty(rows, k, dtype=torch.float32, device=vals.device)
+    oi = torch.empty(rows, k, dtype=torch.int64, device=vals.device)
+    _chk(load().feddat_topk_rows(_p(vals), vals.stride(0), _p(minus), rows, n, k, (1 if log_first else 0) | (2 if softmax else 0),
+                                 _p(ov), _p(oi), _stream()), "feddat_topk_rows")
+    return ov, oi
 
 
 def dropout(x, drop, *, resid=None, out_f32=None, out_bf16=None):

@@ -345,6 +345,18 @@ int feddat_dat_loss_fwd_bwd(const float* logits, const float* teacher, const flo
 int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
                            const float* row_weight, int R, int V, float temp, float kl_scale, void* dlogits_bf16, long ldd,
                            float* scalars, hipStream_t stream);
+/* ALBEF.rank_answer's selections (src/modeling/models/albef_model.py:171-228; eval loop task_trainer.py:159-204).
+ * feddat_softmax_gather_rows: out[r, j] = softmax(logits[r * row_stride + 0 .. V))[ids[j * id_stride]]  -- the probability of
+ *   every candidate answer's first token after [BOS] (albef_model.py:183-186: F.softmax(logits, 1).index_select(1, answer_ids[:, 1])).
+ * feddat_topk_rows: the k largest of each row of n <= 8192 values, sorted descending (equal values: lower index first), as
+ *   (out_vals [rows, k] fp32, out_idx [rows, k] int64).  flags: 1 = take log(v) first; `minus` (fp32 [rows, n], may be NULL) is
+ *   subtracted; 2 = softmax over the row ahead of the sort.  rank_answer: topk(prob_first, k) (flags 0), then
+ *   topk(softmax(log(topk_probs) - answer_loss), k) (flags 3): albef_model.py:186,223-226. */
+int feddat_softmax_gather_rows(const float* logits, long row_stride, int rows, int V, const long* ids, long id_stride, int n,
+                               float* out, hipStream_t stream);
+int feddat_topk_rows(const float* vals, long ld, const float* minus, int rows, int n, int k, int flags, float* out_vals,
+                     long* out_idx, hipStream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * K6  fused multi-tensor AdamW over one flat fp32 parameter buffer (torch.optim.AdamW semantics,

@@ -147,6 +147,74 @@ def test_rank_answer_eval_vs_reference_golden(eng_mod, golden_dir):
         assert np.array_equal(np.sort(ids.cpu().numpy(), 1), np.sort(ref_ids, 1))      # same shortlist
 
 
+def test_rank_answer_selection_kernels_vs_torch():
+    """feddat_softmax_gather_rows / feddat_topk_rows against torch.softmax / index_select / topk / sort at rank_answer's
+    sizes (30 522-way vocabulary, 3 128 candidate answers, k = 128: albef_model.py:154-155)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import lib as L
+    L.load()
+    g = torch.Generator(device="cpu").manual_seed(77)
+    rows, V, Vp, n, k = 5, 30522, 30592, 3128, 128
+    logits = (torch.randn(rows * 3, Vp, generator=g) * 2.0).to(DEV)          # every third row is a question's position 0
+    ids = torch.randperm(V, generator=g)[:n].to(DEV)
+    alist = torch.stack([torch.full((n,), 101, device=DEV), ids, torch.full((n,), 102, device=DEV)], 1)     # [n, 3] int64
+    out = torch.empty(rows, n, device=DEV)
+    L.softmax_gather_rows(logits, rows, 3 * Vp, V, alist[:, 1], out)
+    ref = torch.softmax(logits[::3, :V].double(), 1).index_select(1, ids)
+    assert float((out.double() - ref).abs().max() / ref.max()) < 1e-5
+    tv, ti = L.topk_rows(out, k)
+    rv, ri = out.topk(k, 1)
+    assert torch.equal(tv, rv) and torch.equal(ti, ri)          # distinct fp32 values: the order is unique
+    # ties: lower index first; n not a power of two; k = n
+    x = torch.tensor([[0.5, 0.25, 0.5, 0.125, 0.25, 0.5, 1.0]], device=DEV)
+    v, i = L.topk_rows(x, 7)
+    assert i.tolist() == [[6, 0, 2, 5, 1, 4, 3]] and v.tolist() == [[1.0, 0.5, 0.5, 0.5, 0.25, 0.25, 0.125]]
+    # the re-ranking step: softmax(log(p) - loss) over k, sorted
+    loss = (torch.rand(rows, k, generator=g) * 8).to(DEV)
+    pv, pi = L.topk_rows(tv, k, minus=loss, log_first=True, softmax=True)
+    rp = torch.softmax(tv.double().log() - loss.double(), -1)
+    rps, rpi = rp.sort(1, descending=True)
+    assert float((pv.double() - rps).abs().max() / rps.max()) < 1e-5
+    agree = (pi == rpi).double().mean()
+    assert float(agree) > 0.98          # fp32 vs fp64 ordering of near-equal probabilities
+    assert abs(float(pv.sum(1).mean()) - 1.0) < 1e-5
+
+
+def test_rank_answer_k128_full_size_vs_oracle(eng_mod):
+    """rank_answer at the reference's operating point (k = 128 of the answer list, albef_model.py:154-155) on the real
+    architecture: B = 2 questions, 400 candidate answers of 5 tokens with distinct first tokens, against the oracle.  With
+    random-init weights the candidate probabilities are nearly flat, so the comparison is on probabilities, not ranks:
+    the two shortlists share >= 120 of 128 answers, and on the shared ones the re-ranked probabilities agree to 10 %."""
+    d = A.AlbefDims()
+    P = A.make_params(d)
+    B, k, n_list, La = 2, 128, 400, 5
+    eng = eng_mod.AlbefDatEngine(P, DEV, batch=B, n_answers=B * k, a_len=La)
+    g = torch.Generator().manual_seed(4242)
+    b0 = A.synthetic_batch(B, d, 4243)
+    alist = torch.randint(1000, 30000, (n_list, La), generator=g)
+    alist[:, 0], alist[:, -1] = 101, 102
+    alist[:, 1] = torch.randperm(29000, generator=g)[:n_list] + 1000
+    amask = torch.ones(n_list, La, dtype=torch.long)
+    amask[::3, -1] = 0                                                     # some shorter answers: [CLS] a b [SEP] [PAD]
+    alist[::3, -2], alist[::3, -1] = 102, d.pad_id
+    qb = {kk: b0[kk] for kk in ("image", "question_ids", "question_mask")}
+    ids, probs = eng.rank_answer(_dev(qb), alist, amask, k)
+    torch.set_num_threads(min(torch.get_num_threads(), 64))
+    with torch.no_grad():
+        rids, rprobs = A.albef_eval_forward(P, d, dict(qb, answer_list_ids=alist, answer_list_mask=amask), k, "gating")
+    ids, probs = ids.cpu(), probs.cpu()
+    assert bool((probs[:, :-1] >= probs[:, 1:]).all()) and float((probs.sum(1) - 1).abs().max()) < 1e-4
+    for b in range(B):
+        mine = {int(i): float(p) for i, p in zip(ids[b], probs[b])}
+        ref = {int(i): float(p) for i, p in zip(rids[b], rprobs[b])}
+        shared = set(mine) & set(ref)
+        assert len(shared) >= 120, (b, len(shared))
+        worst = max(abs(mine[i] - ref[i]) / ref[i] for i in shared)
+        print(f"rank_answer k=128 question {b}: {len(shared)} shared, worst relative probability error {worst:.3f}")
+        assert worst < 0.10, (b, worst)
+
+
 def test_full_size_albef_vs_reference_golden(eng_mod, golden_dir):
     """The real architecture (ViT-B/16 at 384 x 384 = 577 tokens, BERT-base 12 + 6 layers, 30 522-way LM head), B = 2:
     forward in two modes and 2 train_steps against the reference's own numbers (G10 full)."""
