@@ -74,6 +74,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const int H = heads * D;
     const long ld = 3L * H;
     const bf16* base = qkv + (size_t)b * S * ld + h * D;
+    const int g = lane >> 4, i16 = lane & 15;
+    // the Q fragments of a wave's NEXT query tile are requested before the current tile is computed (the first ones
+    // before K / V are staged), so that only K / V's own latency is exposed
+    bf16x8 qn[2];
+    qn[0] = gload_frag(base, ld, wave * 16 + i16, S, g);
+    qn[1] = gload_frag(base, ld, wave * 16 + i16, S, 4 + g);
     load_head(base + H, ld, S, S_pad, Ks, tid);
     load_head(base + 2 * H, ld, S, S_pad, Vs, tid);
     for (int k = tid; k < S_pad; k += 256) {
@@ -82,12 +88,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
     __syncthreads();
 
-    const int g = lane >> 4, i16 = lane & 15;
     for (int qt = wave; qt < NQT; qt += 4) {
         if (qt * 16 >= S) break;
-        bf16x8 qf[2];
-        qf[0] = gload_frag(base, ld, qt * 16 + i16, S, g);
-        qf[1] = gload_frag(base, ld, qt * 16 + i16, S, 4 + g);
+        bf16x8 qf[2] = {qn[0], qn[1]};
+        if (qt + 4 < NQT) {          // (rows beyond S come back as zeros from gload_frag)
+            qn[0] = gload_frag(base, ld, (qt + 4) * 16 + i16, S, g);
+            qn[1] = gload_frag(base, ld, (qt + 4) * 16 + i16, S, 4 + g);
+        }
         // S^T tiles: rows = keys kt*16 + 4g + r, col = query i16
         f32x4 s[NKT];
         float mx = -INFINITY;
@@ -327,6 +334,8 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
     // dbg (tools/attn_ablate.py, debug flags bits 20..22; 0 in production; timing only): 1 no global stores, 2 no phase-A
     // arithmetic, 4 no phase B
     constexpr int S_pad = NKS * 32, NT = NKS * 2, NTHR = NKS * 128;
+    constexpr int XROW = 144;                      // bytes per row of a wave's output staging tile (128 + 16: aligned b128 reads)
+    static_assert(2 * NKS * 16 * XROW <= 2 * S_pad * ROWB, "the waves' staging tiles fit in the Q + dO space");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
     char* Gs = Qs + S_pad * ROWB;
@@ -424,6 +433,8 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
     if (more) prefetch1(pair + gridDim.x);
 
     // ---------------- phase A: this wave's key tile ----------------
+    bf16x4 dk16[4], dv16[4];
+    bool have_kv = false;
     {
         const int kt = wave;
         const int key = kt * 16 + i16;
@@ -470,14 +481,11 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
                     dk[dt] = mfma16x32(tr_frag8(Qs, r0a, r0b, dt * 16, lane), dsb, dk[dt]);
                 }
             }
-            if (key < S && !(dbg & 1)) {
-                bf16* ok = dq_base + (size_t)key * ld + H;
-                bf16* ov = dq_base + (size_t)key * ld + 2 * H;
+            have_kv = true;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    *reinterpret_cast<bf16x4*>(ok + dt * 16 + 4 * g) = cvt4(dk[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
-                    *reinterpret_cast<bf16x4*>(ov + dt * 16 + 4 * g) = cvt4(dv[dt]);
-                }
+            for (int dt = 0; dt < 4; ++dt) {
+                dk16[dt] = cvt4(dk[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
+                dv16[dt] = cvt4(dv[dt]);
             }
         } else {
             // key tile beyond S: its panel rows must still be defined (phase B reads all S_pad keys)
@@ -487,6 +495,25 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
         }
     }
     __syncthreads();
+    // Q and dO are dead from here on: each wave owns a [16 rows][64] bf16 tile (144-byte rows) in their LDS space through
+    // which its dK / dV tile -- and, after phase B, its dQ tile -- is turned from the accumulator layout (8 bytes per lane,
+    // 16 rows apart) into 16-byte row-contiguous stores: 2 store instructions per tile instead of 4, whole 128-byte rows
+    // (the 8-byte form kept the CU's store path at ~8 B/clk: 10.7 of the launch's 46 us).
+    char* xt = Qs + wave * (16 * XROW);            // one tile per wave, reused: a wave's LDS operations execute in order
+    auto tile_out = [&](const bf16x4 (&t)[4], char* buf, bf16* gbase, int row0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(buf + i16 * XROW + dt * 32 + g * 8) = t[dt];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = p * 8 + (lane >> 3), c = lane & 7;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + r * XROW + c * 16);
+            if (row0 + r < S && !(dbg & 1)) *reinterpret_cast<bf16x8*>(gbase + (size_t)(row0 + r) * ld + c * 8) = v;
+        }
+    };
+    if (have_kv) {
+        tile_out(dk16, xt, dq_base + H, wave * 16);
+        tile_out(dv16, xt, dq_base + 2 * H, wave * 16);
+    }
     if (more) prefetch2(pair + gridDim.x);
 
     // ---------------- phase B: this wave's query tile ----------------
@@ -514,13 +541,10 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16x32(tr_frag8(Ks, r0a, r0b, dt * 16, lane), dsb, dq[dt]);
         }
-        const int q = qt * 16 + i16;
-        if (q < S && !(dbg & 1)) {
-            bf16* oq = dq_base + (size_t)q * ld;
+        bf16x4 dq16[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<bf16x4*>(oq + dt * 16 + 4 * g) = cvt4(dq[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
-        }
+        for (int dt = 0; dt < 4; ++dt) dq16[dt] = cvt4(dq[dt] * f32x4{0.125f, 0.125f, 0.125f, 0.125f});
+        tile_out(dq16, xt, dq_base, qt * 16);
         }
     }
     __syncthreads();        // every wave is done with this pair's LDS before the next pair's operands land in it
