@@ -11,4 +11,6 @@ for f in "" "--fp8"; do python bench.py --batch 64 $f --no-cpu-baseline --no-roo
 python tools/gemm_fp8_vs_bf16.py > gpurun_out/r03/gemm_fp8_vs_bf16.txt 2>&1
 python tools/adapter_ablate.py > gpurun_out/r03/adapter_ablate.txt 2>&1
 python tools/gemm_defer_probe.py > gpurun_out/r03/gemm_defer_probe.txt 2>&1
+python tools/attn_ablate.py > gpurun_out/r03/attn_ablate.txt 2>&1
+python tools/gemm_epi_split.py > gpurun_out/r03/gemm_epi_split.txt 2>&1
 ls -la gpurun_out/r03 gpurun_out/prof_r03 | head -40
