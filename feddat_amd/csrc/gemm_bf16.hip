@@ -387,7 +387,8 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
                                                  int m_end, int lane) {
     asm volatile("" : "+v"(lane));
     const int frow = lane & 15, fg = lane >> 4;
-    constexpr bool G8OUT_ = EPI == FEDDAT_EPI_GELU_G8 || EPI == FEDDAT_EPI_MUL_G8;      // column constants in LDS
+    constexpr bool G8OUT_ = EPI == FEDDAT_EPI_GELU_G8 || EPI == FEDDAT_EPI_MUL_G8 || EPI == FEDDAT_EPI_GELU_G8_F8 ||
+                            EPI == FEDDAT_EPI_MUL_G8_F8;      // column constants in LDS
     // GELU_G8 (two polynomials per element) / MUL_G8 (its codes in flight) have no registers for per-column constants at
     // 256-row tiles (57 / 26 spilled, and scratch traffic in the k-loop breaks its counted vmcnt waits): their bias / fp8
     // channel scales wait in the wave's staging buffer behind the slab and are re-read per row group
@@ -413,7 +414,9 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
         sc8[p] = idx - srow[p] * 12;
     }
     // 8-bit gelu' codes (GELU_G8 / MUL_G8): a slab is [16 rows][96 bytes] = 96 x 16-byte chunks, one per lane + 32
-    constexpr bool G8OUT = EPI == FEDDAT_EPI_GELU_G8, G8IN = EPI == FEDDAT_EPI_MUL_G8;
+    constexpr bool G8OUT = EPI == FEDDAT_EPI_GELU_G8 || EPI == FEDDAT_EPI_GELU_G8_F8;
+    constexpr bool G8IN = EPI == FEDDAT_EPI_MUL_G8 || EPI == FEDDAT_EPI_MUL_G8_F8;
+    constexpr bool F8OUT = EPI == FEDDAT_EPI_GELU_G8_F8 || EPI == FEDDAT_EPI_MUL_G8_F8;      // the main output leaves as e4m3
     int r8[2], c8[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -467,6 +470,18 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
             }
         }
     };
+    // a staged [16][96] slab of bytes (codes or e4m3) -> 16-byte row-contiguous stores
+    auto slab8_out = [&](uint8_t* o8, int ld, int i) {
+        u32x4 cv[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) cv[p] = *reinterpret_cast<const u32x4*>(stg + r8[p] * V2_EPI_LD8 + c8[p] * 16);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int m = mbase + i * 16 + r8[p];
+            if (m < m_end && (p == 0 || lane < 32) && !(g.nostore & 1))
+                *reinterpret_cast<u32x4*>(o8 + (size_t)m * ld + nbase + c8[p] * 16) = cv[p];
+        }
+    };
     f32x4 sw4[G8OUT_ ? 1 : 6];
     if (g.sw && !G8OUT_) {
 #pragma unroll
@@ -479,8 +494,13 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
         if (g.sw) {          // fp8 operands: dequantise the accumulators (per-row scale of A x per-channel scale of B)
             const float sa = g.sa[min(mbase + i * 16 + frow, m_end - 1)];
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
-                val[j] = acc[i][j] * ((G8OUT_ ? colc(1, j) : sw4[j]) * f32x4{sa, sa, sa, sa}) + (G8OUT_ ? colc(0, j) : bias4[j]);
+            for (int j = 0; j < 6; ++j) {
+                if (EPI == FEDDAT_EPI_MUL_G8_F8)      // the output keeps the input's row scale (x FEDDAT_F8_GRAD_HEADROOM): no sa
+                    val[j] = acc[i][j] * (colc(1, j) * f32x4{1.0f / FEDDAT_F8_GRAD_HEADROOM, 1.0f / FEDDAT_F8_GRAD_HEADROOM,
+                                                              1.0f / FEDDAT_F8_GRAD_HEADROOM, 1.0f / FEDDAT_F8_GRAD_HEADROOM});
+                else
+                    val[j] = acc[i][j] * ((G8OUT_ ? colc(1, j) : sw4[j]) * f32x4{sa, sa, sa, sa}) + (G8OUT_ ? colc(0, j) : bias4[j]);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 6; ++j) val[j] = acc[i][j] + (G8OUT_ ? colc(0, j) : bias4[j]);
@@ -517,18 +537,23 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
                 *reinterpret_cast<unsigned*>(wr8 + j * 16) = fd_g8_encode4((g.nostore & 2) ? val[j] : gj);
                 val[j] = fj;
             }
-            u32x4 cv[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) cv[p] = *reinterpret_cast<const u32x4*>(stg + r8[p] * V2_EPI_LD8 + c8[p] * 16);
-            uint8_t* o8 = reinterpret_cast<uint8_t*>(g.out2_bf16);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int m = mbase + i * 16 + r8[p];
-                if (m < m_end && (p == 0 || lane < 32) && !(g.nostore & 1))
-                    *reinterpret_cast<u32x4*>(o8 + (size_t)m * g.ldo2 + nbase + c8[p] * 16) = cv[p];
-            }
+            slab8_out(reinterpret_cast<uint8_t*>(g.out2_bf16), g.ldo2, i);
         }
-        put(g.out_bf16, g.ldo16, i, val);
+        if (F8OUT) {         // e4m3 with a scale the consumer knows (header): saturate, convert, same 8-bit slab route
+            constexpr float S = EPI == FEDDAT_EPI_GELU_G8_F8 ? 1.0f / FEDDAT_F8_ACT_SCALE : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x4 x = val[j] * f32x4{S, S, S, S};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(x[e], -448.0f, 448.0f);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], pk, true);
+                *reinterpret_cast<int*>(wr8 + j * 16) = pk;
+            }
+            slab8_out(reinterpret_cast<uint8_t*>(g.out_bf16), g.ldo16, i);
+        } else {
+            put(g.out_bf16, g.ldo16, i, val);
+        }
     }
 }
 
@@ -536,7 +561,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 // the accumulator layout from registers) go down as [16 rows][48 cols] fp32 chunks and come back row-contiguous
 // (192-byte runs per row); the residual / aux operands of chunk c+1 are requested before chunk c is stored, so the
 // six chunks do not serialise on HBM latency.
-template <int EPI, int WM>
+template <int EPI, int WM, bool DEQ = false>
 __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[WM][6], char* stg, int mbase, int nbase,
                                             int m_end, int lane) {
     // keep the per-lane index math of the (several, inlined) epilogue sites out of the main loop's live ranges:
@@ -547,6 +572,11 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[WM][
 #pragma unroll
     for (int j = 0; j < 6; ++j)
         bias4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nbase + j * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sw4[DEQ ? 6 : 1];            // DEQ = fp8 operands: per-channel scale of B (x per-row scale of A below)
+    if (DEQ) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sw4[j] = *reinterpret_cast<const f32x4*>(g.sw + nbase + j * 16 + fg * 4);
+    }
     // read-back slots of this lane: 3 per chunk, (row, 4-column group) = divmod(p * 64 + lane, 12)
     int srow[3], sc4[3];
 #pragma unroll
@@ -581,10 +611,18 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& g, f32x4 (&acc)[WM][
     }
     auto chunk = [&](int c, f32x4 (&r)[3], bf16x4 (&u)[3]) {
         const int i = c >> 1, half = c & 1;
+        if (DEQ) {
+            const float sa = g.sa[min(mbase + i * 16 + frow, m_end - 1)];
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
-            *reinterpret_cast<f32x4*>(stg + frow * V2_EPI_LD + (jj * 16 + fg * 4) * 4) =
-                acc[i][half * 3 + jj] + bias4[half * 3 + jj];
+            for (int jj = 0; jj < 3; ++jj)
+                *reinterpret_cast<f32x4*>(stg + frow * V2_EPI_LD + (jj * 16 + fg * 4) * 4) =
+                    acc[i][half * 3 + jj] * (sw4[DEQ ? half * 3 + jj : 0] * f32x4{sa, sa, sa, sa}) + bias4[half * 3 + jj];
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                *reinterpret_cast<f32x4*>(stg + frow * V2_EPI_LD + (jj * 16 + fg * 4) * 4) =
+                    acc[i][half * 3 + jj] + bias4[half * 3 + jj];
+        }
         f32x4 v[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) v[p] = *reinterpret_cast<const f32x4*>(stg + srow[p] * V2_EPI_LD + sc4[p] * 16);
@@ -707,10 +745,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
         const int mb = em0 + wm * (16 * WM), nb = en0 + wn * 96, me = eml + 1;
         if (!(a.dbg & 8)) {
             if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU || EPI == FEDDAT_EPI_GELU_G8 ||
-                EPI == FEDDAT_EPI_MUL_G8)
+                EPI == FEDDAT_EPI_MUL_G8 || EPI == FEDDAT_EPI_GELU_G8_F8 || EPI == FEDDAT_EPI_MUL_G8_F8)
                 v2_epilogue_bf16<EPI, WM>(g, acc, stg, mb, nb, me, lane);
             else
-                v2_epilogue<EPI, WM>(g, acc, stg, mb, nb, me, lane);
+                v2_epilogue<EPI, WM, FP8>(g, acc, stg, mb, nb, me, lane);
         }
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -1228,26 +1266,9 @@ int fd_prepare_gemm_kernels() {
 // "elements" (128 fp8 per 128-byte LDS row); only the MFMA -- ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per output
 // tile and k-tile, unit block scales, twice the bf16 rate (debug flag 256: the K = 32 fp8 instruction it replaced, which
 // issues at the bf16 rate) -- and the dequantising epilogue differ.
-extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb,
-                                  const float* b_scale, int M, int N, int K, int epi, const float* bias, const void* aux,
-                                  int ldaux, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream) {
-    FD_CHECK_ARG(A8 && B8 && a_scale && b_scale && out_bf16 && M >= 1024 && N > 0 && N % V2_BN == 0 && K > 0 && K % 128 == 0);
-    FD_CHECK_ARG(epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU || epi == FEDDAT_EPI_GELU_G8 ||
-                 epi == FEDDAT_EPI_MUL_G8);
-    FD_CHECK_ARG(epi != FEDDAT_EPI_MUL_DGELU || (aux && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0 &&
-                                                (size_t)M * ldaux * 2 < (1ull << 32)));
-    FD_CHECK_ARG(epi != FEDDAT_EPI_MUL_G8 || (aux && ldaux % 16 == 0 && ldaux >= N && ((uintptr_t)aux & 15) == 0 &&
-                                             (size_t)M * ldaux < (1ull << 32)));
-    FD_CHECK_ARG(epi != FEDDAT_EPI_GELU_G8 || (out2_bf16 && ldo2 % 16 == 0 && ldo2 >= N));
-    FD_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldo16 % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0);
-    FD_CHECK_ARG(!out2_bf16 || (ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0));
-    GemmArgsV2 a2;
+// shared launch of the fp8 persistent kernel; EPI_RESID_F32 / EPI_F32 through feddat_gemm_fp8_nt_f32
+static int fp8_launch(GemmArgsV2& a2, int M, int N, int K, int epi, hipStream_t stream) {
     GemmArgs& g = a2.g;
-    g = GemmArgs{};
-    g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.bias = bias; g.sa = a_scale; g.sw = b_scale;
-    g.aux = (const bf16*)aux; g.ldaux = ldaux;
-    g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
-    g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
     a2.dbg = fd_debug_flags() & 8;       // tools/ ablation: 8 = skip the epilogue (k-loop timing)
     int n_cu = 0;
     if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
@@ -1268,26 +1289,78 @@ extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale,
     };
     GemmArgsV2 a3 = a2, a4 = a2;
     const int rounds3 = plan(192, a3), rounds4 = plan(256, a4);
-    const bool wm4 = rounds4 * 12 < rounds3 * 10 && epi != FEDDAT_EPI_MUL_DGELU;      // . gelu'(bf16 u) stays on 192-row tiles (spills)
+    // . gelu'(bf16 u) and the dequantising + residual epilogue stay on 192-row tiles (their 256-row instantiations spill)
+    const bool wm4 = rounds4 * 12 < rounds3 * 10 && epi != FEDDAT_EPI_MUL_DGELU && epi != FEDDAT_EPI_RESID_F32;
     a2 = wm4 ? a4 : a3;
+    (void)g;
     using KernelFn = void (*)(GemmArgsV2);
-    KernelFn kern;
-    if (epi == FEDDAT_EPI_MUL_DGELU) {
-        kern = gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3, true>;
-    } else if (epi == FEDDAT_EPI_MUL_G8) {
-        kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_MUL_G8, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_MUL_G8, 3, true>;
-    } else if (epi == FEDDAT_EPI_GELU_G8) {
-        kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU_G8, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU_G8, 3, true>;
-    } else if (fd_debug_flags() & 256) {      // tools/ A/B only: the CDNA3-style K = 32 fp8 instruction (bf16 issue rate)
-        if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, true>;
-        else kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true, true>;
-    } else if (epi == FEDDAT_EPI_BF16) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true>;
-    else kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true>;
+    KernelFn kern = nullptr;
+#define FD_FP8_PICK(E) kern = wm4 ? gemm_nt_v2_kernel<E, 4, true> : gemm_nt_v2_kernel<E, 3, true>
+    switch (epi) {
+        case FEDDAT_EPI_MUL_DGELU: kern = gemm_nt_v2_kernel<FEDDAT_EPI_MUL_DGELU, 3, true>; break;
+        case FEDDAT_EPI_MUL_G8: FD_FP8_PICK(FEDDAT_EPI_MUL_G8); break;
+        case FEDDAT_EPI_GELU_G8: FD_FP8_PICK(FEDDAT_EPI_GELU_G8); break;
+        case FEDDAT_EPI_MUL_G8_F8: FD_FP8_PICK(FEDDAT_EPI_MUL_G8_F8); break;
+        case FEDDAT_EPI_GELU_G8_F8: FD_FP8_PICK(FEDDAT_EPI_GELU_G8_F8); break;
+        case FEDDAT_EPI_RESID_F32: kern = gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 3, true>; break;
+        case FEDDAT_EPI_F32: FD_FP8_PICK(FEDDAT_EPI_F32); break;
+        case FEDDAT_EPI_BF16:
+            if (fd_debug_flags() & 256) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, true>;
+            else FD_FP8_PICK(FEDDAT_EPI_BF16);
+            break;
+        case FEDDAT_EPI_GELU:      // debug flag 256, tools/ A/B only: the CDNA3-style K = 32 fp8 instruction (bf16 issue rate)
+            if (fd_debug_flags() & 256) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_GELU, 3, true, true>;
+            else FD_FP8_PICK(FEDDAT_EPI_GELU);
+            break;
+        default: return FEDDAT_EINVAL;
+    }
+#undef FD_FP8_PICK
     const int lds_bytes = wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS;
     if (fd_set_max_lds((const void*)kern, lds_bytes) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     const int total = a2.tiles_m * tiles_n;
     hipLaunchKernelGGL(kern, dim3(total < n_cu ? total : n_cu), dim3(512), lds_bytes, stream, a2);
     FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb,
+                                  const float* b_scale, int M, int N, int K, int epi, const float* bias, const void* aux,
+                                  int ldaux, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream) {
+    FD_CHECK_ARG(A8 && B8 && a_scale && b_scale && out_bf16 && M >= 1024 && N > 0 && N % V2_BN == 0 && K > 0 && K % 128 == 0);
+    const bool g8in = epi == FEDDAT_EPI_MUL_G8 || epi == FEDDAT_EPI_MUL_G8_F8;
+    const bool g8out = epi == FEDDAT_EPI_GELU_G8 || epi == FEDDAT_EPI_GELU_G8_F8;
+    const bool f8out = epi == FEDDAT_EPI_GELU_G8_F8 || epi == FEDDAT_EPI_MUL_G8_F8;
+    FD_CHECK_ARG(epi == FEDDAT_EPI_BF16 || epi == FEDDAT_EPI_GELU || epi == FEDDAT_EPI_MUL_DGELU || g8in || g8out);
+    FD_CHECK_ARG(epi != FEDDAT_EPI_MUL_DGELU || (aux && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0 &&
+                                                (size_t)M * ldaux * 2 < (1ull << 32)));
+    FD_CHECK_ARG(!g8in || (aux && ldaux % 16 == 0 && ldaux >= N && ((uintptr_t)aux & 15) == 0 && (size_t)M * ldaux < (1ull << 32)));
+    FD_CHECK_ARG(!g8out || (out2_bf16 && ldo2 % 16 == 0 && ldo2 >= N));
+    FD_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ((uintptr_t)out_bf16 & 15) == 0);
+    FD_CHECK_ARG(f8out ? (ldo16 % 16 == 0 && ldo16 >= N) : ldo16 % 8 == 0);
+    FD_CHECK_ARG(!out2_bf16 || (ldo2 % 8 == 0 && ((uintptr_t)out2_bf16 & 15) == 0));
+    GemmArgsV2 a2;
+    GemmArgs& g = a2.g;
+    g = GemmArgs{};
+    g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.bias = bias; g.sa = a_scale; g.sw = b_scale;
+    g.aux = (const bf16*)aux; g.ldaux = ldaux;
+    g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
+    g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
+    return fp8_launch(a2, M, N, K, epi, stream);
+}
+
+extern "C" int feddat_gemm_fp8_nt_f32(const void* A8, int lda, const float* a_scale, const void* B8, int ldb,
+                                      const float* b_scale, int M, int N, int K, const float* bias, const float* resid,
+                                      int ldr, float* out_f32, int ldo32, hipStream_t stream) {
+    FD_CHECK_ARG(A8 && B8 && a_scale && b_scale && out_f32 && M >= 1024 && N > 0 && N % V2_BN == 0 && K > 0 && K % 128 == 0);
+    FD_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldo32 % 4 == 0 && ldo32 >= N);
+    FD_CHECK_ARG(!resid || (ldr % 4 == 0 && ldr >= N && (size_t)M * ldr * 4 < (1ull << 32)));
+    GemmArgsV2 a2;
+    GemmArgs& g = a2.g;
+    g = GemmArgs{};
+    g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.bias = bias; g.sa = a_scale; g.sw = b_scale;
+    g.resid = resid; g.ldr = ldr; g.out_f32 = out_f32; g.ldo32 = ldo32;
+    const int epi = resid ? FEDDAT_EPI_RESID_F32 : FEDDAT_EPI_F32;
+    g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2; g.epi = epi;
+    return fp8_launch(a2, M, N, K, epi, stream);
 }
 
 extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,

@@ -65,7 +65,8 @@ class FlatGroup:
 class ViltDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], tasks: Sequence[str], device, batch: int, res: int,
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
-                 weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False):
+                 weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False,
+                 fp8_ffn_chain: bool = True):
         """fp8=True (BASELINE.json configs[4]): four frozen products per layer run on the block-scaled fp8 MFMA with e4m3
         operands -- forward QKV and FFN1 (activations quantised per token row by the LayerNorm kernel that produces them) and
         the dX products FFN2^T and attention-output^T (the gradient rows quantised per row: by feddat_quant_rows_fp8 behind the
@@ -85,6 +86,7 @@ class ViltDatEngine:
         self.R = batch * self.S
         self.lr, self.wd, self.eps = lr, weight_decay, adam_eps
         self.fp8 = bool(fp8)
+        self.fp8_ffn_chain = bool(fp8_ffn_chain)      # fp8: also FFN2 forward and FFN1^T (their A operands leave as e4m3)
         self.ksplit = wgrad_splits
         self.ln_eps = 1e-12
         dev = self.dev
@@ -140,6 +142,12 @@ class ViltDatEngine:
                 # dX products whose A operand (a gradient) is produced by a row kernel: FFN2^T and attention-output^T
                 extra["w2T8"], extra["s2T"] = fp8_of(w2.t().contiguous())
                 extra["woT8"], extra["soT"] = fp8_of(wo.t().contiguous())
+                # the FFN chain: FFN1's epilogue leaves gelu(u) as e4m3 (fixed scale) for an fp8 FFN2; FFN2^T's leaves dU as
+                # e4m3 rows that keep the incoming gradient's row scale x FEDDAT_F8_GRAD_HEADROOM (folded into W1^T's
+                # channel scales here) for an fp8 FFN1^T
+                extra["w28"], extra["s2"] = fp8_of(w2)
+                extra["w1T8"], s1T = fp8_of(w1.t().contiguous())
+                extra["s1T4"] = s1T * L.F8_GRAD_HEADROOM
             self.layers.append(dict(
                 extra, wqkv=bf16_of(wqkv), wqkvT=bf16_T(wqkv), bqkv=bqkv,
                 wo=bf16_of(wo), woT=bf16_T(wo), bo=P(Lp + "attention.output.dense.bias"),
@@ -197,6 +205,9 @@ class ViltDatEngine:
             self.xs = f32(R2)
             self.g8 = torch.empty(R2, H, dtype=torch.uint8, device=dev)     # gradient rows as e4m3 + per-row scale
             self.gsc = f32(R2)
+            self.f8 = torch.empty(R2, I, dtype=torch.uint8, device=dev)     # gelu(u) as e4m3, fixed scale
+            self.f8s = torch.full((R2,), L.F8_ACT_SCALE, dtype=torch.float32, device=dev)
+            self.dU8 = torch.empty(R2, I, dtype=torch.uint8, device=dev)    # dU rows as e4m3, row scale = headroom x gsc
         self.f16 = b16(R2, I)          # gelu(u), transient
         # layer 0 (shared body, R rows): only h3 is kept
         self.l0 = dict(qkv=b16(R, 3 * H), ctx=b16(R, H), lse=f32(B, self.heads, self.S), h2=f32(R, H), h3=f32(R, H))
@@ -373,6 +384,11 @@ class ViltDatEngine:
             L.attn_fwd(qkv, ctx, lse, nb, self.S, self.heads, key_mask=mask)
             L.gemm_bf16_nt(ctx, W["wo"], L.EPI_RESID_F32, bias=W["bo"], resid=h_in, out_f32=h2)
             L.layernorm_fwd_fp8(h2, W["ln2g"], W["ln2b"], self.ln_eps, rows, H, x8, xs, stats=st2)
+            if self.fp8_ffn_chain:      # FFN1 -> e4m3 gelu(u) (+ gelu' codes) -> fp8 FFN2
+                codes = u if g8 else self.dU.view(torch.uint8)[:rows, :self.I]       # (no backward through this call: scratch)
+                L.gemm_fp8_nt(x8, xs, W["w18"], W["s1"], L.EPI_GELU_G8_F8, bias=W["b1"], out_bf16=self.f8[:rows], out2_bf16=codes)
+                L.gemm_fp8_nt_f32(self.f8[:rows], self.f8s[:rows], W["w28"], W["s2"], bias=W["b2"], resid=h2, out_f32=h3)
+                return
             L.gemm_fp8_nt(x8, xs, W["w18"], W["s1"], L.EPI_GELU_G8 if g8 else L.EPI_GELU, bias=W["b1"], out_bf16=f16,
                           out2_bf16=u if u is not None else self.dU[:rows])
             L.gemm_bf16_nt(f16, W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=h2, out_f32=h3)
@@ -572,9 +588,13 @@ class ViltDatEngine:
                 L.adapter_bwd_fp8(cur, oth, self.g8, self.gsc, self._segs(i, False, True), R2, z_saved=self.zsave[i],
                                   z_out=self.z, dz_out=self.dz)
                 self._adapter_wgrads(i, a["h3"], 0, cur)
-                L.gemm_fp8_nt(self.g8, self.gsc, W["w2T8"], W["s2T"], L.EPI_MUL_G8 if self.g8u else L.EPI_MUL_DGELU, aux=a["u"],
-                              out_bf16=self.dU)
-                L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
+                if self.fp8_ffn_chain and self.g8u:
+                    L.gemm_fp8_nt(self.g8, self.gsc, W["w2T8"], W["s2T"], L.EPI_MUL_G8_F8, aux=a["u"], out_bf16=self.dU8)
+                    L.gemm_fp8_nt(self.dU8, self.gsc, W["w1T8"], W["s1T4"], L.EPI_BF16, out_bf16=self.dx16)
+                else:
+                    L.gemm_fp8_nt(self.g8, self.gsc, W["w2T8"], W["s2T"], L.EPI_MUL_G8 if self.g8u else L.EPI_MUL_DGELU,
+                                  aux=a["u"], out_bf16=self.dU)
+                    L.gemm_bf16_nt(self.dU, W["w1T"], L.EPI_BF16, out_bf16=self.dx16)
                 L.layernorm_bwd_dx_fp8(a["h2"], a["st2"], W["ln2g"], R2, H, self.g8, self.gsc, dy_bf16=self.dx16, dres=oth,
                                        out_f32=cur)
                 L.gemm_fp8_nt(self.g8, self.gsc, W["woT8"], W["soT"], L.EPI_BF16, out_bf16=self.dctx)

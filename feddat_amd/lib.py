@@ -15,7 +15,8 @@ import torch  # imported first on purpose: libfeddat_hip.so must bind to the HIP
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfeddat_hip.so")
 
-EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32, EPI_GELU_G8, EPI_MUL_G8 = 0, 1, 2, 3, 4, 5, 6
+EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32, EPI_GELU_G8, EPI_MUL_G8, EPI_GELU_G8_F8, EPI_MUL_G8_F8 = range(9)
+F8_ACT_SCALE, F8_GRAD_HEADROOM = 0.125, 4.0      # FEDDAT_F8_ACT_SCALE / FEDDAT_F8_GRAD_HEADROOM
 G8_LO, G8_STEP = -0.135, 0.005        # FEDDAT_G8_LO / FEDDAT_G8_STEP: gelu' ~ G8_LO + G8_STEP * code
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
@@ -69,6 +70,7 @@ _SIGS = {
     "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
     "feddat_gemm_fp8_nt": [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp],
     "feddat_layernorm_bwd_dx_fp8": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp],
+    "feddat_gemm_fp8_nt_f32": [vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, i32, vp],
     "feddat_quant_rows_fp8": [vp, i64, i32, i32, vp, vp, vp],
     "feddat_layernorm_fwd_fp8": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
     "feddat_gemm_bf16_nt_skinny": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32,
@@ -288,6 +290,16 @@ def gemm_fp8_nt(A8, a_scale, B8, b_scale, epi, *, bias=None, aux=None, out_bf16=
                                    _p(bias), _p(aux), 0 if aux is None else aux.stride(0), _p(out_bf16), out_bf16.stride(0),
                                    _p(out2_bf16),
                                    0 if out2_bf16 is None else out2_bf16.stride(0), _stream()), "feddat_gemm_fp8_nt")
+
+
+def gemm_fp8_nt_f32(A8, a_scale, B8, b_scale, *, bias=None, resid=None, out_f32=None):
+    """out_f32 = (A8 @ B8^T) * a_scale[:, None] * b_scale[None, :] + bias (+ resid)."""
+    _dev(A8, B8, a_scale, b_scale, out_f32, resid, bias)
+    M, K = A8.shape
+    N = B8.shape[0]
+    _chk(load().feddat_gemm_fp8_nt_f32(_p(A8), A8.stride(0), _p(a_scale), _p(B8), B8.stride(0), _p(b_scale), M, N, K, _p(bias),
+                                       _p(resid), 0 if resid is None else resid.stride(0), _p(out_f32), out_f32.stride(0),
+                                       _stream()), "feddat_gemm_fp8_nt_f32")
 
 
 def quant_rows_fp8(x, y8, scale):

@@ -75,6 +75,19 @@ int feddat_set_debug_flags(int flags);
  * kernels only: M >= 1024 and N % 192 == 0 (FEDDAT_EINVAL otherwise). */
 #define FEDDAT_EPI_GELU_G8 5    /* out2 = uint8 codes of gelu'(acc + bias); out_bf16 = gelu(acc + bias) */
 #define FEDDAT_EPI_MUL_G8 6     /* out_bf16 = (acc) * (FEDDAT_G8_LO + FEDDAT_G8_STEP * aux_u8)        */
+/* configs[4] only (feddat_gemm_fp8_nt): the same pair with the MAIN output as e4m3 bytes instead of bf16, so that the next
+ * product of the chain is an fp8 product too (out / ldo16: uint8 [M, N], ld in bytes, % 16 == 0).
+ *   GELU_G8_F8: out = e4m3(gelu(u) / FEDDAT_F8_ACT_SCALE), saturating at +-448 -- a FIXED scale (e4m3 is floating point:
+ *               3 mantissa bits from 2^-6 FEDDAT_F8_ACT_SCALE up to 448 FEDDAT_F8_ACT_SCALE = 56); the consumer passes a
+ *               constant a_scale vector.
+ *   MUL_G8_F8:  out = e4m3((A8 B8^T) * b_scale[n] * gelu' / FEDDAT_F8_GRAD_HEADROOM): row m of the output carries the row scale
+ *               FEDDAT_F8_GRAD_HEADROOM * a_scale[m] of the input gradient row it came from (|sum_k g W| <= 448 * 12 in code
+ *               units for ViLT's FFN2; typical 10-60: the headroom keeps outliers below 448 and typical values 6 binades above
+ *               the subnormals).  The consumer multiplies its weight scales by the headroom once, at load time. */
+#define FEDDAT_EPI_GELU_G8_F8 7
+#define FEDDAT_EPI_MUL_G8_F8 8
+#define FEDDAT_F8_ACT_SCALE 0.125f
+#define FEDDAT_F8_GRAD_HEADROOM 4.0f
 #define FEDDAT_G8_LO (-0.135f)     /* = -27 steps */
 #define FEDDAT_G8_STEP 0.005f
 int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
@@ -93,6 +106,11 @@ int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void
                        int N, int K, int epi, const float* bias, const void* aux_bf16, int ldaux, void* out_bf16, int ldo16,
                        void* out2_bf16, int ldo2,
                        hipStream_t stream);
+/* the same fp8 product with an fp32 output: out_f32 = (A8 B8^T) * a_scale[m] * b_scale[n] + bias (+ resid, fp32, may be NULL):
+ * FFN2 of a ViLT layer on configs[4], fed by the e4m3 gelu(u) that FEDDAT_EPI_GELU_G8_F8 leaves (adaptered_output.py:74-76). */
+int feddat_gemm_fp8_nt_f32(const void* A8, int lda, const float* a_scale, const void* B8, int ldb, const float* b_scale, int M,
+                           int N, int K, const float* bias, const float* resid, int ldr, float* out_f32, int ldo32,
+                           hipStream_t stream);
 int feddat_quant_rows_fp8(const float* x, long ld, int rows, int cols, void* y_fp8, float* scale, hipStream_t stream);
 int feddat_layernorm_fwd_fp8(const float* x, long x_stride, const float* gamma, const float* beta, float eps, int rows,
                              int H, void* y_fp8, float* y_scale, void* y_bf16, float* stats, hipStream_t stream);
