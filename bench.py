@@ -508,7 +508,8 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8(e4m3)+bf16" if args.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": ("configs[4]: ViLT-B/32 FedDAT, fp8 (e4m3) MFMA for the frozen QKV / FFN1 forward products, "
+            "config": {"workload": ("configs[4]: ViLT-B/32 FedDAT, fp8 (e4m3) MFMA for six of the eight frozen products per layer "
+                                    "(QKV, FFN1, FFN2 forward; FFN2^T, FFN1^T, attention-output^T backward), "
                                     f"bf16 elsewhere, batch={B}/client, " if args.fp8 else
                                     f"configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, bf16 MFMA, batch={B}/client, ") +
                                    "384x384 synthetic + 40-token questions, MKD on"

@@ -94,9 +94,9 @@ int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, i
                         const float* bias, const float* resid, int ldr, const void* aux, int ldaux, float* out_f32,
                         int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2, hipStream_t stream);
 /* configs[4]: fp8 (OCP e4m3) MFMA for frozen linears.  A8 [M,K] and B8 [N,K] are e4m3 with per-row scales (a_scale [M],
- * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias; epilogue BF16, GELU / GELU_G8 or
- * MUL_DGELU / MUL_G8 (aux = the saved pre-GELU u, or the gelu' codes) as above -- the last pair is the dX product of FFN2
- * with A8 = the e4m3 row-quantised gradient).
+ * b_scale [N] = per output channel): C = (A8 B8^T) * a_scale[m] * b_scale[n] (+ bias; epilogue BF16, GELU / GELU_G8 / GELU_G8_F8
+ * or MUL_DGELU / MUL_G8 / MUL_G8_F8 (aux = the saved pre-GELU u, or the gelu' codes) as above -- the last group is the dX
+ * product of FFN2 with A8 = the e4m3 row-quantised gradient; for the _F8 forms out_bf16 / ldo16 are the e4m3 output).
  * Same persistent kernel and data movement as the bf16 form (128 fp8 per 128-byte LDS row); the MFMA is the CDNA4
  * block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the bf16 rate).
  * Requirements: M >= 1024, N % 192 == 0, K % 128 == 0, lda / ldb % 16 == 0, 16-byte aligned outputs.
