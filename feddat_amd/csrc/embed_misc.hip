@@ -303,6 +303,45 @@ extern "C" int feddat_vilt_key_mask(const long* attention_mask, const long* pixe
     FD_LAUNCH_RET();
 }
 
+// The small per-batch inputs of a ViLT step -> the engine's static buffers in ONE launch (five device-to-device copies of a
+// few KB each cost 4-5 us apiece in front of every step).
+struct StageInputs {
+    const long *ids, *types, *amask, *pmask;
+    const float* target;
+    long *d_ids, *d_types, *d_amask, *d_pmask;
+    float* d_target;
+    int n_text, n_target, B, gh, gw, Hi, Wi, P;
+};
+__global__ __launch_bounds__(256) void stage_inputs_kernel(StageInputs a) {
+    const int n_patch = a.B * a.gh * a.gw;
+    const int n = max(max(a.n_text, a.n_target), n_patch);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (i < a.n_text) {
+            a.d_ids[i] = a.ids[i];
+            a.d_types[i] = a.types[i];
+            a.d_amask[i] = a.amask ? a.amask[i] : 1;
+        }
+        if (i < a.n_target && a.target) a.d_target[i] = a.target[i];
+        if (i < n_patch) {
+            const int b = i / (a.gh * a.gw), r = i - b * (a.gh * a.gw), y = r / a.gw, x = r - y * a.gw;
+            a.d_pmask[i] = a.pmask ? a.pmask[((size_t)b * a.Hi + (size_t)y * a.P) * a.Wi + (size_t)x * a.P] : 1;
+        }
+    }
+}
+
+extern "C" int feddat_vilt_stage_inputs(const long* input_ids, const long* token_type_ids, const long* attention_mask,
+                                        const float* target, const long* pixel_mask, long* d_input_ids,
+                                        long* d_token_type_ids, long* d_attention_mask, float* d_target, long* d_patch_mask,
+                                        int B, int Lt, int n_labels, int Hi, int Wi, int P, hipStream_t stream) {
+    FD_CHECK_ARG(input_ids && token_type_ids && d_input_ids && d_token_type_ids && d_attention_mask && d_patch_mask);
+    FD_CHECK_ARG(B > 0 && Lt > 0 && n_labels >= 0 && Hi > 0 && Wi > 0 && P > 0 && Hi % P == 0 && Wi % P == 0 && (!target || d_target));
+    StageInputs a{input_ids, token_type_ids, attention_mask, pixel_mask, target, d_input_ids, d_token_type_ids,
+                  d_attention_mask, d_patch_mask, d_target, B * Lt, target ? B * n_labels : 0, B, Hi / P, Wi / P, Hi, Wi, P};
+    const int n = max(max(a.n_text, a.n_target), B * a.gh * a.gw);
+    hipLaunchKernelGGL(stage_inputs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    FD_LAUNCH_RET();
+}
+
 extern "C" int feddat_cvt_f32_bf16(const float* in, void* out_bf16, long n, hipStream_t stream) {
     FD_CHECK_ARG(in && out_bf16 && n > 0);
     hipLaunchKernelGGL(cvt_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, stream, in, (bf16*)out_bf16,

@@ -339,6 +339,18 @@ class ViltDatEngine:
         if not px.is_cuda:
             px = px.to(self.dev, non_blocking=True)
         L.im2col_patches(px.to(torch.float32).contiguous(), self.patches, self.B, 3, self.res[0], self.res[1], self.P)
+        ids, tts, am, tg, pm = (batch.get(k) for k in ("input_ids", "token_type_ids", "attention_mask", "target_scores",
+                                                        "pixel_mask"))
+
+        def dev_ok(t, dt, shape):
+            return t is None or (t.is_cuda and t.dtype == dt and t.is_contiguous() and tuple(t.shape) == shape)
+        B, Lt = self.B, self.Lt
+        if (ids is not None and tts is not None and dev_ok(ids, torch.int64, (B, Lt)) and dev_ok(tts, torch.int64, (B, Lt))
+                and dev_ok(am, torch.int64, (B, Lt)) and dev_ok(tg, torch.float32, (B, self.C))
+                and dev_ok(pm, torch.int64, (B, self.res[0], self.res[1]))):
+            # the usual case (device-resident batch in the reference's dtypes): one launch for all five
+            L.vilt_stage_inputs(ids, tts, am, tg, pm, self.inp, B, Lt, self.C, self.res[0], self.res[1], self.P)
+            return
         self.inp["input_ids"].copy_(batch["input_ids"], non_blocking=True)
         self.inp["token_type_ids"].copy_(batch["token_type_ids"], non_blocking=True)
         if "target_scores" in batch:

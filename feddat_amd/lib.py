@@ -107,6 +107,7 @@ _SIGS = {
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
     "feddat_lm_loss_fwd_bwd": [vp, vp, i64, vp, vp, i32, i32, f32, f32, vp, i64, vp, vp],
     "feddat_axpby3": [vp, f32, vp, f32, vp, f32, vp, vp, i64, vp],
+    "feddat_vilt_stage_inputs": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "feddat_softmax_gather_rows": [vp, i64, i32, i32, vp, i64, i32, vp, vp],
     "feddat_topk_rows": [vp, i64, vp, i32, i32, i32, i32, vp, vp, vp],
     "feddat_gather_rows": [vp, vp, vp, vp, i32, i32, vp],
@@ -524,6 +525,16 @@ def lm_loss_fwd_bwd(logits, teacher, labels, row_weight, V, temp, kl_scale, dlog
     _chk(load().feddat_lm_loss_fwd_bwd(_p(logits), _p(teacher), logits.stride(0), _p(labels), _p(row_weight), R, V, temp,
                                        kl_scale, _p(dlogits_bf16), 0 if dlogits_bf16 is None else dlogits_bf16.stride(0),
                                        _p(scalars), _stream()), "feddat_lm_loss_fwd_bwd")
+
+
+def vilt_stage_inputs(input_ids, token_type_ids, attention_mask, target, pixel_mask, dst: dict, B, Lt, n_labels, Hi, Wi, P):
+    """The step's small inputs -> the engine's static buffers (dst: input_ids, token_type_ids, attention_mask, target,
+    patch_mask) in one launch.  All sources on the device, int64 / fp32, contiguous."""
+    _dev(input_ids, token_type_ids, attention_mask, target, pixel_mask)
+    _chk(load().feddat_vilt_stage_inputs(_p(input_ids), _p(token_type_ids), _p(attention_mask), _p(target), _p(pixel_mask),
+                                         _p(dst["input_ids"]), _p(dst["token_type_ids"]), _p(dst["attention_mask"]),
+                                         _p(dst["target"]), _p(dst["patch_mask"]), B, Lt, n_labels, Hi, Wi, P, _stream()),
+         "feddat_vilt_stage_inputs")
 
 
 def softmax_gather_rows(logits, rows, row_stride, V, ids, out):

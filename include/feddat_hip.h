@@ -417,6 +417,14 @@ int feddat_pos_embed_resize_masked(const float* pos_grid, const long* pixel_mask
  * (rows b + rep*B of key_mask, uint8 [nrep*B, S], S = Lt + 1 + (Hi/P)*(Wi/P)). */
 int feddat_vilt_key_mask(const long* attention_mask, const long* pixel_mask, uint8_t* key_mask, int B, int Lt, int Hi,
                          int Wi, int P, int nrep, hipStream_t stream);
+/* One launch that copies the small per-batch inputs of a step (HF ViLT encodings, reference schema of process_inputs,
+ * src/modeling/vilt.py:98, + target_scores) into the caller's static buffers: input_ids / token_type_ids / attention_mask
+ * int64 [B, Lt] (attention_mask NULL = all valid), target fp32 [B, n_labels] (NULL = leave d_target alone), pixel_mask int64
+ * [B, Hi, Wi] sampled at the patch origins into d_patch_mask int64 [B, Hi/P, Wi/P] (NULL = all valid). */
+int feddat_vilt_stage_inputs(const long* input_ids, const long* token_type_ids, const long* attention_mask, const float* target,
+                             const long* pixel_mask, long* d_input_ids, long* d_token_type_ids, long* d_attention_mask,
+                             float* d_target, long* d_patch_mask, int B, int Lt, int n_labels, int Hi, int Wi, int P,
+                             hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Input pipeline, image half: HF ViltImageProcessor as the reference calls it through

@@ -212,6 +212,26 @@ def test_padded_images_vs_reference_golden(eng_mod, golden_dir):
         _golden_update_parity(g, "after2.", eng.state_dict(), P0)
 
 
+def test_set_batch_one_launch_staging_equals_the_copies(eng_mod):
+    """A device-resident batch in the reference's dtypes takes feddat_vilt_stage_inputs (one launch); a host batch takes the
+    tensor copies: same static buffers either way, with padded questions / images and with the optional keys absent."""
+    d = O.ViltDims(layers=1)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=4, res=384, layers=1)
+    b = O.pad_batch(O.synthetic_batch(4, 384, 6100), G6_VALID, G6_TEXT)
+    for drop in ((), ("attention_mask", "pixel_mask"), ("target_scores",)):
+        bb = {k: v for k, v in b.items() if k not in drop}
+        for t in eng.inp.values():
+            t.fill_(7)
+        eng.set_batch(bb)                                    # host tensors: torch copies
+        want = {k: v.clone() for k, v in eng.inp.items()}
+        for t in eng.inp.values():
+            t.fill_(7)
+        eng.set_batch(_to_dev(bb))                           # device tensors: the staging kernel
+        for k in want:
+            assert torch.equal(eng.inp[k], want[k]), (drop, k)
+
+
 @pytest.mark.parametrize("B,res,layers,text_len,graph", [(1, 224, 2, 40, False), (3, 224, 3, 40, True),
                                                          (5, 384, 2, 16, False), (33, 224, 2, 40, False),
                                                          (2, 224, 1, 40, False)])
