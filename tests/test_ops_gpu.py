@@ -378,6 +378,17 @@ def test_adapter_full_size_and_ragged_rows(L):
         ref = torch.cat([(dzd.t() @ xd).flatten(), dzd.sum(0), (sc * dyd.t() @ zd).flatten(), sc * dyd.sum(0)])
         err = (grads[k].double() - ref).abs().max() / ref.abs().max()
         assert float(err) < 1e-5, (k, float(err))
+    # the per-layer form: partial sums now, ONE batched reduction later (two "layers" = two launches): bit-identical
+    ws = L.adapter_wgrad_workspace_elems(2)
+    parts = torch.empty(2 * ws, device=DEV)
+    g2 = torch.full((2, 2, n), float("nan"), device=DEV)        # [launch, segment, tensor block]
+    for l in range(2):
+        L.adapter_wgrad_partial(L.make_wgrad_segs([
+            dict(x=x, dy=dy, z=z, dz=dz, grad=g2[l, 0], rows=h, scale=0.5),
+            dict(x=x[h:], dy=dy[h:], z=z[h:], dz=dz[h:], grad=g2[l, 1], rows=T - h, scale=1.0)]), parts[l * ws:(l + 1) * ws])
+    ptrs = torch.tensor([g2[l, k].data_ptr() for l in range(2) for k in range(2)], dtype=torch.int64, device=DEV)
+    L.adapter_wgrad_reduce(ptrs, 2, 2, parts, ws)
+    assert torch.equal(g2[0], grads) and torch.equal(g2[1], grads)
 
 
 # ------------------------------------------------------------------ exact fp32 small GEMM

@@ -62,6 +62,33 @@ def test_realistic_round_40_steps_vs_reference_golden(engine, golden_dir):
     print(f"40-step round: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f}, worst norm ratio {worst_norm:.4f}")
 
 
+def test_fp8_round_40_steps_vs_reference_golden(engine, golden_dir):
+    """configs[4]'s arithmetic (six of the eight frozen products per layer on the fp8 MFMA) over the same 40-step reference
+    round: what the e4m3 operands cost at round length, stated and asserted -- loss trajectory within 2 % (measured 0.4 %), per
+    tensor on the update mean |ddW| <= 0.25 mean |dW| (measured 0.129), update norm within 6 % (3.0 %), max |ddW| < 6e-3 (3.7e-3:
+    NOT the north-star's 1e-3 -- that bar is for the bf16 path, which measures 7.8e-4 / 0.020 / 0.8 % on this round).  The size
+    and mean direction of every update survive; element-wise it is an fp8 run, which is why configs[4] is its own config."""
+    g = load(golden_dir, "g8_round40.npz")
+    steps = int(g["steps"])
+    d = O.ViltDims(layers=12)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    eng = engine.ViltDatEngine(P, ["art"], DEV, batch=4, res=384, layers=12, fp8=True)
+    assert eng._fp8_rows(2 * eng.R) and eng.fp8_ffn_chain and eng.g8u
+    eng.begin_local_update("art", steps_per_epoch=steps)
+    losses = np.array([float(eng.train_step(_dev(O.synthetic_batch(4, 384, 8000 + s)), use_graph=True)[0]) for s in range(steps)])
+    rel = np.abs(losses - g["losses"]) / np.maximum(g["losses"], 1.0)
+    sd = eng.state_dict()
+    worst = dict(max=0.0, ratio=0.0, norm=0.0)
+    for k in [k.split("::", 1)[1] for k in g if k.startswith("dsamp::")]:
+        mx, mean, ref_mean, dnorm = delta_vs_golden(g, k, sd[k].cpu() - P[k])
+        worst = dict(max=max(worst["max"], mx), ratio=max(worst["ratio"], mean / ref_mean),
+                     norm=max(worst["norm"], dnorm / float(g["dnorm::" + k])))
+    print(f"fp8 40-step round: loss trajectory within {rel.max():.3f}; worst max |ddW| {worst['max']:.2e}, mean ratio "
+          f"{worst['ratio']:.3f}, norm ratio {worst['norm']:.3f}")
+    assert rel.max() < 2e-2
+    assert worst["max"] < 6e-3 and worst["ratio"] < 0.25 and worst["norm"] < 0.06
+
+
 @pytest.fixture(scope="module")
 def round80(engine, golden_dir):
     """One 80-step round (configs[2]'s longest len(loader)) of the 12-layer model on the engine (hipGraph replay) and,
