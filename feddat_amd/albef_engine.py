@@ -144,7 +144,11 @@ class AlbefDatEngine:
         self.opt_adapters = (0, 1)
         self.graph = None
         self._segs_cache: Dict = {}
-        self.wpart = {m: torch.empty(L.adapter_wgrad_workspace_elems(1), device=dev) for m in ("gating", "adapter_1")}
+        # weight-gradient partial sums: one slot per adapter module and pass; ONE batched reduction per backward pass folds them
+        # into the flat gradient buffers (feddat_adapter_wgrad_partial / _reduce) instead of one reduce launch per module
+        self.wpart_stride = L.adapter_wgrad_workspace_elems(1)
+        self.wpart = {m: torch.empty(len(self.modules) * self.wpart_stride, device=dev) for m in ("gating", "adapter_1")}
+        self._wg_done = {m: [] for m in ("gating", "adapter_1")}
         self.side = None           # second stream of train_step (created lazily on the engine's device)
         self.drop_ctr = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] = train_steps since begin_local_update
         self._alloc()
@@ -251,7 +255,30 @@ class AlbefDatEngine:
             self._segs_cache[key] = L.make_wgrad_segs([dict(x=x, dy=dy, z=self.gs[mode]["z"], dz=self.gs[mode]["dz"],
                                                             grad=self.ad[a].g[m * n:(m + 1) * n], rows=rows,
                                                             scale=0.5 if mode == "gating" else 1.0)])
-        L.adapter_wgrad(self._segs_cache[key], self.wpart[mode])
+        ws = self.wpart_stride
+        L.adapter_wgrad_partial(self._segs_cache[key], self.wpart[mode][m * ws:(m + 1) * ws])
+        self._wg_done[mode].append(m)
+
+    def _wgrad_reduce(self, mode: str):
+        """Fold the partial sums of every module this backward pass produced into the adapter's gradient buffer (one launch)."""
+        done, self._wg_done[mode] = self._wg_done[mode], []
+        if not done:
+            return
+        a = 0 if mode == "gating" else int(mode.split("_")[1])
+        ms = tuple(sorted(done))
+        key = ("wg-reduce", mode, ms)
+        if key not in self._segs_cache:
+            n, ws = self.ad_numel, self.wpart_stride
+            contiguous = ms == tuple(range(ms[0], ms[0] + len(ms)))
+            ptrs = torch.tensor([self.ad[a].g[m * n:(m + 1) * n].data_ptr() for m in ms], dtype=torch.int64, device=self.dev)
+            self._segs_cache[key] = (ptrs, contiguous)
+        ptrs, contiguous = self._segs_cache[key]
+        ws = self.wpart_stride
+        if contiguous:       # the usual case (all 30 modules): slots m0 .. m0 + len - 1 are one strided batch
+            L.adapter_wgrad_reduce(ptrs, len(ms), 1, self.wpart[mode][ms[0] * ws:], ws)
+        else:
+            for j, m in enumerate(ms):
+                L.adapter_wgrad_reduce(ptrs[j:j + 1], 1, 1, self.wpart[mode][m * ws:], ws)
 
     def copy_global_to_teacher(self):
         self.ad[2].p.copy_(self.ad[1].p)
@@ -514,6 +541,7 @@ class AlbefDatEngine:
         """L = (loss + kl) / 2 of the pass `mode` (task_trainer.py:300-302 / 320-323) -> gradients of its trainable adapter."""
         self._backward_text(mode, teacher_logits, pass_id)
         self._vit_bwd(self.acts[mode], mode, self.gs[mode]["d_img"])
+        self._wgrad_reduce(mode)
 
     def _backward_text(self, mode: str, teacher_logits, pass_id=None):
         """Loss, LM head, decoder and text encoder backward of the pass `mode`; leaves d(image_embeds) in its scratch set."""
