@@ -41,7 +41,8 @@ int feddat_abi_version(void);
  * (feddat_vilt_layer_fwd/bwd) take a ctx.
  * feddat_set_debug_flags: ablation switches used by tools/ only (GEMM: 1 / 2 = everything on the two-wave-group / the
  * one-wave-per-SIMD kernel, 8 = skip epilogue, 32 / 64 = force 192- / 256-row tiles, 256 = K = 32 fp8 MFMA, 512 = deferred-
- * epilogue timing probe, bits 28..31 = cap the persistent grid at 16 x value workgroups; adapters: bits 24..26).  The one piece
+ * epilogue timing probe, bits 28..31 = cap the persistent grid at 16 x value workgroups; adapters: bits 24..26; attention
+ * backward: bits 20..22 = timing-only ablations, bit 23 = one block per (sample, head) instead of the persistent grid).  The one piece
  * of process-wide mutable state in the library: 0 by default, never read from the environment, and no production path sets
  * it -- with flags = 0 every launch is a pure function of its arguments.
  * ------------------------------------------------------------------------------------------- */
