@@ -197,14 +197,23 @@ def make_exchange(eng, world, rank, dist):
         return None, None
     from feddat_amd.fedavg import allreduce_average, make_rccl_comm
     nbytes = eng.comm_flat().numel() * 4
+    why = "single-GPU test rig"
     if dist.get_backend() == "nccl":
-        comm = make_rccl_comm(world, rank)
-        info = comm.info()
-        v = info["rccl_version"]
-        desc = {"library": "RCCL %d.%d.%d (C ABI: feddat_fedavg_allreduce)" % (v // 10000, v // 100 % 100, v % 100),
-                "ranks_in_communicator": info["ranks"], "payload_bytes": nbytes, "per_round": 1}
-        return (lambda: allreduce_average(eng, world, comm=comm)), desc
-    desc = {"library": "torch.distributed " + dist.get_backend() + " (single-GPU test rig)",
+        comm, err = None, ""
+        try:
+            comm = make_rccl_comm(world, rank)
+            info = comm.info()
+        except Exception as e:      # noqa: BLE001 -- reported on the line; the ranks agree on the fallback below
+            comm, err = None, f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1.0 if comm is not None else 0.0], device=eng.dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
+        if float(ok) > 0:
+            v = info["rccl_version"]
+            desc = {"library": "RCCL %d.%d.%d (C ABI: feddat_fedavg_allreduce)" % (v // 10000, v // 100 % 100, v % 100),
+                    "ranks_in_communicator": info["ranks"], "payload_bytes": nbytes, "per_round": 1}
+            return (lambda: allreduce_average(eng, world, comm=comm)), desc
+        why = "C-ABI communicator unavailable on some rank" + (f" ({err[:200]})" if err else "")
+    desc = {"library": "torch.distributed " + dist.get_backend() + f" ({why})",
             "ranks_in_communicator": dist.get_world_size(), "payload_bytes": nbytes, "per_round": 1}
     return (lambda: allreduce_average(eng, world)), desc
 

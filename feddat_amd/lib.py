@@ -204,9 +204,13 @@ class RcclComm:
 
     def __init__(self, world: int, rank: int, exchange):
         buf = C.create_string_buffer(128)
-        if rank == 0:
-            _chk(load().feddat_comm_unique_id(buf), "feddat_comm_unique_id")
-        ident = exchange(bytes(buf.raw))
+        rc0 = load().feddat_comm_unique_id(buf) if rank == 0 else 0
+        # rank 0 ships its return code with the id, so that a failure there (RCCL not loadable) raises on EVERY rank instead of
+        # leaving the others waiting in the exchange
+        msg = exchange(bytes([0 if rc0 == 0 else 1]) + bytes(buf.raw))
+        if msg[0] != 0:
+            raise FeddatHipError("feddat_comm_unique_id failed on rank 0 (is librccl loadable?)")
+        ident = msg[1:]
         self._h = vp()
         _chk(load().feddat_comm_create(C.c_char_p(ident), world, rank, C.byref(self._h)), "feddat_comm_create")
         self.world, self.rank = world, rank
