@@ -136,17 +136,25 @@ __device__ __forceinline__ f32x2 gelu_grad_pk(f32x2 u) {
 }
 // gelu(u) AND gelu'(u) (the FFN1 epilogue that stores 8-bit gelu' codes): gelu' = 1/2 + erf(u / sqrt 2) / 2 + u phi(u) shares
 // the erf polynomial with gelu; u phi(u) = u exp2(-u^2 log2(e) / 2) / sqrt(2 pi) costs one v_exp_f32 (~5/3 of a VALU slot on
-// gfx950) + 5 packed ops per element pair instead of a second 9-coefficient polynomial (14 packed ops).  |error| of this
-// gelu' <= 2.7e-5 + the exp's ulp.
+// gfx950) + 4 packed ops per element pair instead of a second 9-coefficient polynomial (14 packed ops).  |error| of this
+// gelu' <= 2.7e-5 + the exp's ulp (+ 7.2e-5 beyond |u| = 4.5, see below).
 __device__ __forceinline__ void gelu_and_grad_pk(f32x2 u, f32x2& f, f32x2& gp) {
     constexpr float C[9] = {3.589798371e+00f, -1.207231863e+01f, 3.590728051e+01f, -8.046883329e+01f, 1.320808609e+02f,
                             -1.519935397e+02f, 1.145676310e+02f, -5.029529085e+01f, 9.684438904e+00f};
-    const f32x2 e = odd_poly9_pk(clamp_unit_pk(u), C);
+    const f32x2 t = clamp_unit_pk(u);
+    const f32x2 t2 = t * t;
+    f32x2 p = f32x2{C[8], C[8]};
+#pragma unroll
+    for (int k = 7; k >= 0; --k) p = p * t2 + f32x2{C[k], C[k]};
+    const f32x2 e = p * t;
     const f32x2 h = u * f32x2{0.5f, 0.5f};
     f = h * e + h;
-    const f32x2 a = (u * u) * f32x2{-0.72134752044448170f, -0.72134752044448170f};
-    const f32x2 ux = u * f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-    gp = ux * f32x2{0.39894228040143268f, 0.39894228040143268f} + (e * f32x2{0.5f, 0.5f} + f32x2{0.5f, 0.5f});
+    // u phi(u) from the clamped t the polynomial already has: exp2(KE t^2) = exp(-(4.5 t)^2 / 2); beyond |u| = 4.5 the true
+    // u phi(u) is < 7.2e-5 and the clamped one is 7.2e-5 (0.014 code steps)
+    constexpr float KE = -0.72134752044448170f * 20.25f;
+    const f32x2 a = t2 * f32x2{KE, KE};
+    const f32x2 tx = t * f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};      // (u phi(u) / 4.5, |u| clamped)
+    gp = tx * f32x2{4.5f * 0.39894228040143268f, 4.5f * 0.39894228040143268f} + (e * f32x2{0.5f, 0.5f} + f32x2{0.5f, 0.5f});
 }
 __device__ __forceinline__ void gelu_and_grad4_pk(f32x4 u, f32x4& f, f32x4& gp) {
     f32x2 f0, f1, g0, g1;
