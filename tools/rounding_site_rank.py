@@ -3,8 +3,8 @@
 
 CPU-only.  The fp32 oracle (oracle/feddat_oracle.py, pinned to the reference) runs an N-step round next to EMULATIONS of
 the engine's arithmetic: the same oracle code with bf16 round-to-nearest-even applied at the places where the engine
-stores or feeds a bf16 value (forward: frozen weights, LN outputs, qkv, softmax probabilities, ctx, gelu(u), the saved
-pre-GELU u, the adapter's operand copies; backward: every dY / dX that is a bf16 GEMM operand or a bf16 store).  Sites are
+stores or feeds a bf16 value (forward: frozen weights, LN outputs, qkv, softmax probabilities, ctx, gelu(u), what is saved
+of the pre-GELU u -- 8-bit gelu' codes since round 3 --, the adapter's operand copies; backward: every dY / dX that is a bf16 GEMM operand or a bf16 store).  Sites are
 switched individually:
 
     all          every site on  (should land where the real engine lands: tools/round_length_probe.py)
@@ -95,17 +95,30 @@ def lin(x, W, b):
     return _LinW.apply(x, W, b)
 
 
+G8_LO, G8_STEP = -0.135, 0.005            # FEDDAT_G8_LO / FEDDAT_G8_STEP (include/feddat_hip.h)
+U_AS_CODES = os.environ.get("ROUND_U_CODES", "1") != "0"
+
+
 class _Gelu(torch.autograd.Function):
-    """f = gelu(u) from the fp32 accumulator; the backward evaluates gelu'(u) on the SAVED u, which the engine keeps in
-    bf16 (site u)."""
+    """f = gelu(u) from the fp32 accumulator; site u = what the engine keeps of u for the backward: since round 3 the 8-bit
+    code of gelu'(u) computed from the fp32 u (FEDDAT_EPI_GELU_G8; ROUND_U_CODES=0: the bf16 u of rounds 1-2)."""
     @staticmethod
     def forward(ctx, u):
-        ctx.save_for_backward(bf(u) if "u" in ON else u)
+        if "u" in ON and U_AS_CODES:
+            cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2)))
+            gp = cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+            ctx.codes = True
+            ctx.save_for_backward(G8_LO + G8_STEP * torch.round((gp - G8_LO) / G8_STEP).clamp(0, 255))
+        else:
+            ctx.codes = False
+            ctx.save_for_backward(bf(u) if "u" in ON else u)
         return F.gelu(u)
 
     @staticmethod
     def backward(ctx, g):
         (u,) = ctx.saved_tensors
+        if ctx.codes:
+            return g * u                       # the saved tensor IS the decoded gelu'
         cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2)))
         pdf = torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
         return g * (cdf + u * pdf)
