@@ -323,6 +323,14 @@ struct WsLaunch {
 };
 
 #define FD_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// After [tile 0 pieces][weight loads][tile 1 pieces] have been issued: tile 0 has landed once at most as many requests are
+// outstanding as were issued behind it.  One adapter: 18 + 12 + 12 weight loads + 12 (+ 2) pieces; two adapters: 84 + 12, more
+// than the counter's 63.
+template <int NA>
+__device__ __forceinline__ void FD_WAIT_TILE0() {
+    if (NA == 1) asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+}
 
 // LDS-DMA piece: the 64 lanes' 16-byte loads land at LDS bytes [m0, m0 + 1024).  Issued as inline asm ON PURPOSE: for the
 // builtin, hipcc's waitcnt pass assumes every later ds_read may alias the DMA's destination and puts vmcnt(0) in front of
@@ -421,18 +429,20 @@ __device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* 
     float* sbet = sgam + H;
     if (t0 >= ntiles) return;
 
-    // ---- prologue: the first two tiles in flight, weights -> registers, small tables -> LDS
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    // ---- prologue: small tables -> LDS, then (in this order in the memory pipe) tile 0, the weights -> registers, tile 1.
+    // Only tile 0 is waited for by hand (FD_WAIT_TILE0: everything older than the last 63 requests has landed, and more than 63
+    // are younger than tile 0's pieces); the weight registers are waited for by the compiler where they are first used -- the
+    // down-type matrix ahead of the down-projection, the up-type one ahead of the up-projection -- so the first tile's
+    // down-projection runs while the second half of the 295 KB of weights is still on its way (the whole prologue used to
+    // stand behind one vmcnt(0): 8.8 us of a 30 us launch).
+    auto tile_dma = [&](int p) {
         const int t = t0 + p * tstep;
         if (t < ntiles && !(p && (dbg & 4))) {
             const int row0 = sg.row_begin + t * 16;
             const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
             ws_tile_dma(x + (size_t)(row0 + sg.x_row_delta) * H, nvalid, smem + p * TILE_F, wave, lane);
         }
-    }
-    WsWeights<NA> W;
-    ws_load_weights<NA>(W, sg.wd, sg.wu, wave, lane);
+    };
     for (int i = threadIdx.x; i < NA * H; i += 256) sbu[i] = sg.bu[i / H][i % H];
     if (threadIdx.x < NA * R) sbd[(threadIdx.x / R) * 64 + threadIdx.x % R] = sg.bd[threadIdx.x / R][threadIdx.x % R];
     if (ln.gamma)
@@ -443,7 +453,12 @@ __device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* 
     float sc[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) sc[a] = sg.scale[a];
-    FD_WAIT_VM0();
+    tile_dma(0);
+    WsWeights<NA> W;
+    ws_load_weights<NA>(W, sg.wd, sg.wu, wave, lane);
+    tile_dma(1);
+    if (dbg & 4) FD_WAIT_VM0();        // (ablation without the second tile: fewer requests behind tile 0 than the count assumes)
+    else FD_WAIT_TILE0<NA>();
     __syncthreads();
 
     // Steady state, iteration t (its tile is in LDS): compute -> vmcnt(0) [tile t+1 landed; the stores of tile t-1, issued
@@ -657,8 +672,7 @@ __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float*
     float* ztile = kspl + KSPL_F;              // [2][ZT_F]
     float* amred = ztile + 2 * ZT_F;           // [4 waves][16 rows]: row maxima of |dx| (fp8 copy only)
     if (t0 >= ntiles) return;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    auto tile_dma = [&](int p) {       // prologue order and waits as in ws_fwd_body
         const int t = t0 + p * tstep;
         if (t < ntiles && !(p && (dbg & 4))) {
             const int row0 = sg.row_begin + t * 16;
@@ -666,15 +680,31 @@ __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float*
             ws_tile_dma(dy + (size_t)row0 * H, nvalid, smem + p * TILE_F, wave, lane);
             ws_ztile_dma(z_saved + (size_t)row0 * (2 * R), nvalid, ztile + p * ZT_F, wave, lane);
         }
+    };
+    if (Q8) {      // (the fp8 instantiation keeps the one-wait prologue: any other form costs it 7 spilled registers)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int t = t0 + p * tstep;
+            if (t < ntiles && !(p && (dbg & 4))) {
+                const int row0 = sg.row_begin + t * 16;
+                const int nvalid = (sg.row_end - row0) < 16 ? (sg.row_end - row0) : 16;
+                ws_tile_dma(dy + (size_t)row0 * H, nvalid, smem + p * TILE_F, wave, lane);
+                ws_ztile_dma(z_saved + (size_t)row0 * (2 * R), nvalid, ztile + p * ZT_F, wave, lane);
+            }
+        }
+    } else {
+        tile_dma(0);
     }
     WsWeights<NA> W;
     ws_load_weights<NA>(W, sg.wuT, sg.wdT, wave, lane);
+    if (!Q8) tile_dma(1);
     float sc[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) sc[a] = sg.scale[a];
     const int train_slot = sg.train_slot;
     const bool exp_z = train_slot >= 0 && wave < NT && z_out;
-    FD_WAIT_VM0();
+    if (Q8 || (dbg & 4)) FD_WAIT_VM0();
+    else FD_WAIT_TILE0<NA>();
     __syncthreads();
 
     int cur = 0;      // pipeline order as in ws_fwd_body
