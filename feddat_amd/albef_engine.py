@@ -567,8 +567,12 @@ class AlbefDatEngine:
 
     # ------------------------------------------------------------------------------------------ train step
     def begin_local_update(self, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,
-                           opt_adapters: Sequence[int] = (0, 1)):
-        """TaskTrainer.train prologue (task_trainer.py:36-59): teacher snapshot, fresh AdamW state and schedule."""
+                           opt_adapters: Sequence[int] = (0, 1), dropout_epoch: int = 0):
+        """TaskTrainer.train prologue (task_trainer.py:36-59): teacher snapshot, fresh AdamW state and schedule.
+        dropout_epoch: which local update this is, federation-wide (train.main passes round * n_clients + client index).  The
+        masks are a function of (seed, site, step counter): the counter starts at dropout_epoch * 2^16, so every round and
+        every client draws its own masks -- like the reference's nn.Dropout, which keeps consuming the global RNG across
+        rounds and clients -- and a resumed run reproduces them without any saved RNG state."""
         self.copy_global_to_teacher()
         total = steps_per_epoch * num_epochs
         self.sched = dict(total=total, warmup=int(total * warmup_ratio))
@@ -579,10 +583,10 @@ class AlbefDatEngine:
             grp.g.zero_()
         self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))       # adapter_1 is stepped at tick 2b
         self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))       # adapter_0 at tick 2b + 1
-        self.drop_ctr.zero_()
+        self.drop_ctr.copy_(torch.tensor([(int(dropout_epoch) << 16) & 0x7FFFFFFF, 0], dtype=torch.int32))
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
-        sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps)
+        sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.dropout)
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig

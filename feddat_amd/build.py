@@ -25,10 +25,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+ABLATE_LIB = os.path.join(PKG, "libfeddat_hip_ablate.so")
+
+
+def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+    """ablate=True: the -DFEDDAT_ABLATE build with the timing-only (wrong-result) probes of tools/ compiled in, written to
+    libfeddat_hip_ablate.so; the production library has none of them (csrc/common.hip.h: FD_ABL)."""
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "feddat_hip.h")]
-    objdir = os.path.join(PKG, "build")
+    objdir = os.path.join(PKG, "build_ablate" if ablate else "build")
+    LIB = ABLATE_LIB if ablate else globals()["LIB"]
+    FLAGS = globals()["FLAGS"] + (["-DFEDDAT_ABLATE"] if ablate else [])
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for s in srcs:
@@ -58,4 +65,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablate="--ablate" in sys.argv))

@@ -324,12 +324,18 @@ struct WsLaunch {
 
 #define FD_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // After [tile 0 pieces][weight loads][tile 1 pieces] have been issued: tile 0 has landed once at most as many requests are
-// outstanding as were issued behind it.  One adapter: 18 + 12 + 12 weight loads + 12 (+ 2) pieces; two adapters: 84 + 12, more
-// than the counter's 63.
+// outstanding as were issued BEHIND it.  The count is derived from the loop bounds of ws_load_weights (one vector load per
+// fragment: NA x (NT*KS/4 down-type + CT/4 + 2*CT/8 up-type) = 42 per adapter) plus the 12 pieces of tile 1, capped at the
+// counter's 63; it is only valid when tile 1 exists -- a block with a single tile has just the weight loads behind tile 0 and
+// must wait for everything (ws_wait_tile0 below; block-uniform condition).
+constexpr int WS_WEIGHT_LOADS_PER_ADAPTER = NT * (KS / 4) + CT / 4 + 2 * (CT / 8);
+static_assert(WS_WEIGHT_LOADS_PER_ADAPTER == 42, "ws_load_weights changed: re-derive the counted wait");
 template <int NA>
-__device__ __forceinline__ void FD_WAIT_TILE0() {
-    if (NA == 1) asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+__device__ __forceinline__ void ws_wait_tile0(bool has_tile1) {
+    constexpr int behind = NA * WS_WEIGHT_LOADS_PER_ADAPTER + 12;
+    constexpr int cnt = behind < 63 ? behind : 63;
+    if (has_tile1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
+    else FD_WAIT_VM0();
 }
 
 // LDS-DMA piece: the 64 lanes' 16-byte loads land at LDS bytes [m0, m0 + 1024).  Issued as inline asm ON PURPOSE: for the
@@ -430,7 +436,7 @@ __device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* 
     if (t0 >= ntiles) return;
 
     // ---- prologue: small tables -> LDS, then (in this order in the memory pipe) tile 0, the weights -> registers, tile 1.
-    // Only tile 0 is waited for by hand (FD_WAIT_TILE0: everything older than the last 63 requests has landed, and more than 63
+    // Only tile 0 is waited for by hand (ws_wait_tile0: everything older than the last 63 requests has landed, and more than 63
     // are younger than tile 0's pieces); the weight registers are waited for by the compiler where they are first used -- the
     // down-type matrix ahead of the down-projection, the up-type one ahead of the up-projection -- so the first tile's
     // down-projection runs while the second half of the 295 KB of weights is still on its way (the whole prologue used to
@@ -457,8 +463,7 @@ __device__ __forceinline__ void ws_fwd_body(const float* __restrict__ x, float* 
     WsWeights<NA> W;
     ws_load_weights<NA>(W, sg.wd, sg.wu, wave, lane);
     tile_dma(1);
-    if (dbg & 4) FD_WAIT_VM0();        // (ablation without the second tile: fewer requests behind tile 0 than the count assumes)
-    else FD_WAIT_TILE0<NA>();
+    ws_wait_tile0<NA>(!(dbg & 4) && t0 + tstep < ntiles);
     __syncthreads();
 
     // Steady state, iteration t (its tile is in LDS): compute -> vmcnt(0) [tile t+1 landed; the stores of tile t-1, issued
@@ -640,8 +645,8 @@ __global__ __launch_bounds__(256, 1) void adapter_fwd_ws_kernel(const float* __r
     int s, t0, tstep, ntiles;
     ws_walk(L, s, t0, tstep, ntiles);
     const feddat_adapter_seg& sg = L.a.seg[s];
-    if (sg.n_adapters == 2) ws_fwd_body<2>(x, out, sg, t0, tstep, ntiles, ws_smem, ln, z_save, L.dbg);
-    else ws_fwd_body<1>(x, out, sg, t0, tstep, ntiles, ws_smem, ln, z_save, L.dbg);
+    if (sg.n_adapters == 2) ws_fwd_body<2>(x, out, sg, t0, tstep, ntiles, ws_smem, ln, z_save, FD_ABL(L.dbg));
+    else ws_fwd_body<1>(x, out, sg, t0, tstep, ntiles, ws_smem, ln, z_save, FD_ABL(L.dbg));
 }
 
 
@@ -703,8 +708,7 @@ __device__ __forceinline__ void ws_bwd_body(const float* __restrict__ dy, float*
     for (int a = 0; a < NA; ++a) sc[a] = sg.scale[a];
     const int train_slot = sg.train_slot;
     const bool exp_z = train_slot >= 0 && wave < NT && z_out;
-    if (Q8 || (dbg & 4)) FD_WAIT_VM0();
-    else FD_WAIT_TILE0<NA>();
+    ws_wait_tile0<NA>(!Q8 && !(dbg & 4) && t0 + tstep < ntiles);
     __syncthreads();
 
     int cur = 0;      // pipeline order as in ws_fwd_body
@@ -878,9 +882,9 @@ __global__ __launch_bounds__(256, 1) void adapter_bwd_ws_kernel(const float* __r
     int s, t0, tstep, ntiles;
     ws_walk(L, s, t0, tstep, ntiles);
     const feddat_adapter_seg& sg = L.a.seg[s];
-    if (sg.n_adapters == 2) ws_bwd_body<2, Q8>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg, dx8,
+    if (sg.n_adapters == 2) ws_bwd_body<2, Q8>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, FD_ABL(L.dbg), dx8,
                                                dx8_scale);
-    else ws_bwd_body<1, Q8>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, L.dbg, dx8, dx8_scale);
+    else ws_bwd_body<1, Q8>(dy, dx, dx16, z_out, dz_out, sg, t0, tstep, ntiles, ws_smem, z_saved, FD_ABL(L.dbg), dx8, dx8_scale);
 }
 
 // host: blocks per segment, proportional to the tiles (at least one block per non-empty segment, one block per CU in all)
@@ -889,7 +893,7 @@ int ws_plan(const AdapterLaunch& A, int tiles, WsLaunch& L, int& grid) {
     const int rc = fd_device_cus(&n_cu);
     if (rc) return rc;
     L.a = A;
-    L.dbg = (fd_debug_flags() >> 24) & 7;
+    L.dbg = FD_ABL((fd_debug_flags() >> 24) & 7);
     const int t0 = A.tiles0, t1 = tiles - A.tiles0;
     grid = tiles < n_cu ? tiles : n_cu;
     if (t1 == 0) L.g0 = grid;
@@ -969,7 +973,7 @@ int prep_launch(const feddat_adapter_seg* segs, int nseg, int T, AdapterLaunch& 
 }
 
 // tools/ ablation: bits 16..23 of the debug flags = extra dynamic LDS in KiB (caps the resident blocks per CU)
-int dbg_extra_lds() { return ((fd_debug_flags() >> 16) & 0xff) * 1024; }
+int dbg_extra_lds() { return FD_ABL(((fd_debug_flags() >> 16) & 0xff) * 1024); }
 
 int ws_launch_fwd(const float* x, float* out, const AdapterLaunch& A, int tiles, const LnFuse& ln, float* z_save,
                   hipStream_t stream) {

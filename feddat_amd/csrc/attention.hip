@@ -330,9 +330,10 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
                                                                      const float* __restrict__ lse,
                                                                      const bf16* __restrict__ dctx,
                                                                      bf16* __restrict__ dqkv, int S, int heads,
-                                                                     const int npairs, const int dbg) {
-    // dbg (tools/attn_ablate.py, debug flags bits 20..22; 0 in production; timing only): 1 no global stores, 2 no phase-A
-    // arithmetic, 4 no phase B
+                                                                     const int npairs, const int dbg_in) {
+    // dbg (tools/attn_ablate.py, debug flags bits 20..22; -DFEDDAT_ABLATE build only, the constant 0 otherwise; timing only):
+    // 1 no global stores, 2 no phase-A arithmetic, 4 no phase B
+    const int dbg = FD_ABL(dbg_in);
     constexpr int S_pad = NKS * 32, NT = NKS * 2, NTHR = NKS * 128;
     constexpr int XROW = 144;                      // bytes per row of a wave's output staging tile (128 + 16: aligned b128 reads)
     static_assert(2 * NKS * 16 * XROW <= 2 * S_pad * ROWB, "the waves' staging tiles fit in the Q + dO space");
@@ -610,7 +611,7 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
             return FEDDAT_ELAUNCH;                                                                             \
         hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(grid), dim3((N) * 128), ldsf, stream,                \
                            (const bf16*)qkv, key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dqkv, S, heads, \
-                           B * heads, (fd_debug_flags() >> 20) & 7);                                           \
+                           B * heads, FD_ABL((fd_debug_flags() >> 20) & 7));                                          \
         break;
         switch (nks) {
             ATTN_BWD_F(1) ATTN_BWD_F(2) ATTN_BWD_F(3) ATTN_BWD_F(4) ATTN_BWD_F(5) ATTN_BWD_F(6)

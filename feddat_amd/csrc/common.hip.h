@@ -35,6 +35,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // host side, device_state.hip: per-device caches (thread-safe, keyed by the calling thread's current HIP device)
 int fd_device_cus(int* n_cu);                          // compute units of the current device
 int fd_set_max_lds(const void* kernel, int bytes);     // hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel)
+// Wrong-result ablations (timing probes of tools/: skip-epilogue, no-store, no-compute, deferred-epilogue probe ...) exist
+// only in the -DFEDDAT_ABLATE build (`python -m feddat_amd.build --ablate` -> libfeddat_hip_ablate.so, loaded explicitly by
+// tools/ through lib.use_ablation_build()).  The production library compiles them out: FD_ABL(x) is the constant 0 there, and
+// feddat_set_debug_flags rejects every bit outside FD_DEBUG_SELECT_BITS, which only choose among kernels that give the same
+// (bit-identical) results: 1 / 2 everything on the two-group / one-wave-per-SIMD GEMM kernel (2 in attention.hip: the
+// two-role backward), 32 / 64 force 192- / 256-row tiles, 128 no small-tile kernel, 256 the K = 32 fp8 MFMA, bit 23 one
+// attention-backward block per pair, bits 28..31 cap the persistent GEMM grid at 16 x value workgroups.
+#ifdef FEDDAT_ABLATE
+#define FD_ABL(x) (x)
+#else
+#define FD_ABL(x) 0
+#endif
+constexpr unsigned FD_DEBUG_SELECT_BITS = 1u | 2u | 32u | 64u | 128u | 256u | (1u << 23) | (0xfu << 28);
 int fd_debug_flags();                                  // ablation flags (feddat_set_debug_flags), 0 in production
 int fd_prepare_all_kernels();                          // sets every kernel's LDS attribute on the current device
 int fd_prepare_gemm_kernels();

@@ -3,7 +3,8 @@
 // Nothing here is keyed on "the first device that called": every cache is indexed by the CURRENT HIP device of the calling
 // thread and guarded by a mutex, so one process may drive several GPUs (one feddat_ctx per device, or none at all: the
 // stateless entry points look the device up themselves).  The ablation flags (tools/ only) are set explicitly through
-// feddat_set_debug_flags(); the launch path never reads the environment.
+// feddat_set_debug_flags() (kernel-selection bits only in the production build: common.hip.h FD_ABL); the launch path never
+// reads the environment.
 #include <atomic>
 #include <mutex>
 #include <unordered_set>
@@ -59,6 +60,9 @@ struct feddat_ctx {
 };
 
 extern "C" int feddat_set_debug_flags(int flags) {
+#ifndef FEDDAT_ABLATE
+    if ((unsigned)flags & ~FD_DEBUG_SELECT_BITS) return FEDDAT_EINVAL;      // timing-only ablations are not in this build
+#endif
     g_debug.store(flags, std::memory_order_relaxed);
     return FEDDAT_OK;
 }

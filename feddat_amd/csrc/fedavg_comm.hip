@@ -4,7 +4,11 @@
 // RCCL is bound at run time (dlopen of the librccl the process already has -- PyTorch-ROCm ships one -- or the system
 // one), so libfeddat_hip.so carries no link-time dependency on it and the single-GPU path never touches it.
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 #include "common.hip.h"
 
@@ -34,9 +38,18 @@ std::once_flag g_once;
 
 const Rccl& rccl() {
     std::call_once(g_once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // First the librccl the process has ALREADY mapped (RTLD_NOLOAD: PyTorch-ROCm ships its own torch/lib/librccl.so and
+        // its process group uses it -- binding a second, system RCCL next to it would put two RCCLs with separate state in
+        // one process); only if none is mapped, load one by name.
+        const char* const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* name : names) {
+            g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (g_rccl.h) break;
+        }
+        if (!g_rccl.h && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) g_rccl.h = dlopen(nullptr, RTLD_NOW);   // mapped under another name
+        for (const char* name : names) {
+            if (g_rccl.h) break;
+            g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!g_rccl.h) return;
         g_rccl.get_id = (GetUniqueIdFn)dlsym(g_rccl.h, "ncclGetUniqueId");
@@ -60,12 +73,46 @@ extern "C" int feddat_comm_unique_id(void* id_128_bytes) {
 }
 
 extern "C" int feddat_comm_create(const void* id_128_bytes, int world, int rank, void** comm_out) {
-    FD_CHECK_ARG(id_128_bytes && comm_out && world > 0 && rank >= 0 && rank < world);
+    return feddat_comm_create_timeout(id_128_bytes, world, rank, 0, comm_out);
+}
+
+// ncclCommInitRank is collective: a rank whose peer died (or never loaded RCCL) would wait in the bootstrap forever.  With
+// timeout_ms > 0 the call runs on a helper thread (same HIP device as the caller) and the caller gives up after the
+// timeout: FEDDAT_ETIMEOUT, *comm_out = NULL, the helper thread is abandoned (detached; its state block is kept alive by
+// the shared_ptr it holds), so the surviving ranks can agree on a fallback exchange instead of hanging.
+extern "C" int feddat_comm_create_timeout(const void* id_128_bytes, int world, int rank, int timeout_ms, void** comm_out) {
+    FD_CHECK_ARG(id_128_bytes && comm_out && world > 0 && rank >= 0 && rank < world && timeout_ms >= 0);
+    *comm_out = nullptr;
     const Rccl& r = rccl();
     if (!r.ok) return FEDDAT_ELAUNCH;
     ncclUniqueId_ id;
     __builtin_memcpy(&id, id_128_bytes, sizeof(id));
-    return r.init_rank(comm_out, world, id, rank) == 0 ? FEDDAT_OK : FEDDAT_ELAUNCH;
+    if (timeout_ms == 0) return r.init_rank(comm_out, world, id, rank) == 0 ? FEDDAT_OK : FEDDAT_ELAUNCH;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return FEDDAT_ELAUNCH;
+    struct Job {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+        int rc = -1;
+        void* comm = nullptr;
+    };
+    auto job = std::make_shared<Job>();
+    const CommInitRankFn init = r.init_rank;
+    std::thread([job, init, id, world, rank, dev] {
+        void* c = nullptr;
+        int rc = hipSetDevice(dev) == hipSuccess ? init(&c, world, id, rank) : -1;
+        std::lock_guard<std::mutex> lk(job->mu);
+        job->rc = rc;
+        job->comm = c;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->mu);
+    if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) return FEDDAT_ETIMEOUT;
+    if (job->rc != 0) return FEDDAT_ELAUNCH;
+    *comm_out = job->comm;
+    return FEDDAT_OK;
 }
 
 extern "C" int feddat_comm_destroy(void* comm) {

@@ -465,7 +465,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
             if (SINK) {
                 bf16* o = m < m_end ? dst + (size_t)m * ld + nbase + sc8[p] * 8 : reinterpret_cast<bf16*>(fd_epi_sink) + lane * 8;
                 *reinterpret_cast<bf16x8*>(o) = v[p];
-            } else if (m < m_end && !(g.nostore & 1)) {
+            } else if (m < m_end && !FD_ABL(g.nostore & 1)) {
                 *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
             }
         }
@@ -478,7 +478,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int m = mbase + i * 16 + r8[p];
-            if (m < m_end && (p == 0 || lane < 32) && !(g.nostore & 1))
+            if (m < m_end && (p == 0 || lane < 32) && !FD_ABL(g.nostore & 1))
                 *reinterpret_cast<u32x4*>(o8 + (size_t)m * ld + nbase + c8[p] * 16) = cv[p];
         }
     };
@@ -511,7 +511,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const bf16x4 u = *reinterpret_cast<const bf16x4*>(wr + j * 32);
-                if (!(g.nostore & 2)) val[j] = val[j] * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
+                if (!FD_ABL(g.nostore & 2)) val[j] = val[j] * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
                 else val[j] = val[j] * f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
             }
             if (i + AUX_AHEAD < WM) aux_load(i + AUX_AHEAD);
@@ -520,7 +520,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
             if (g.out2_bf16) put(g.out2_bf16, g.ldo2, i, val);
 #pragma unroll
             for (int j = 0; j < 6; ++j)
-                if (!(g.nostore & 2)) val[j] = gelu4_pk(val[j]);
+                if (!FD_ABL(g.nostore & 2)) val[j] = gelu4_pk(val[j]);
         }
         if (G8IN) {          // codes: row-contiguous 16-byte chunks -> LDS -> one dword (4 codes) per accumulator
 #pragma unroll
@@ -534,7 +534,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
                 f32x4 fj, gj;
                 gelu_and_grad4_pk(val[j], fj, gj);
                 // (debug flag 4, timing only: codes without the gelu' arithmetic)
-                *reinterpret_cast<unsigned*>(wr8 + j * 16) = fd_g8_encode4((g.nostore & 2) ? val[j] : gj);
+                *reinterpret_cast<unsigned*>(wr8 + j * 16) = fd_g8_encode4(FD_ABL(g.nostore & 2) ? val[j] : gj);
                 val[j] = fj;
             }
             slab8_out(reinterpret_cast<uint8_t*>(g.out2_bf16), g.ldo2, i);
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     int pm0 = 0, pn0 = 0, pml = 0;
     auto run_epilogue = [&](int em0, int en0, int eml) {
         const int mb = em0 + wm * (16 * WM), nb = en0 + wn * 96, me = eml + 1;
-        if (!(a.dbg & 8)) {
+        if (!FD_ABL(a.dbg & 8)) {
             if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU || EPI == FEDDAT_EPI_GELU_G8 ||
                 EPI == FEDDAT_EPI_MUL_G8 || EPI == FEDDAT_EPI_GELU_G8_F8 || EPI == FEDDAT_EPI_MUL_G8_F8)
                 v2_epilogue_bf16<EPI, WM>(g, acc, stg, mb, nb, me, lane);
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
         for (int i = 0; i < RT; ++i)
             asm volatile("s_nop 15\n\ts_nop 15"
                          : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
-        if (!(a.dbg & 8) && !FAKE) {
+        if (!FD_ABL(a.dbg & 8) && !FAKE) {
             const int mb = m0 + wm * (16 * RT), nb = n0 + wn * 96, me = m_last + 1;
             if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU)
                 v2_epilogue_bf16<EPI, RT, true>(g, acc, stg, mb, nb, me, lane);
@@ -1269,7 +1269,7 @@ int fd_prepare_gemm_kernels() {
 // shared launch of the fp8 persistent kernel; EPI_RESID_F32 / EPI_F32 through feddat_gemm_fp8_nt_f32
 static int fp8_launch(GemmArgsV2& a2, int M, int N, int K, int epi, hipStream_t stream) {
     GemmArgs& g = a2.g;
-    a2.dbg = fd_debug_flags() & 8;       // tools/ ablation: 8 = skip the epilogue (k-loop timing)
+    a2.dbg = FD_ABL(fd_debug_flags() & 8);       // -DFEDDAT_ABLATE build: 8 = skip the epilogue (k-loop timing)
     int n_cu = 0;
     if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     const int tiles_n = N / V2_BN;
@@ -1402,7 +1402,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;
     g.ldo32 = ldo32; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
-    g.nostore = ((fd_debug_flags() & 16) ? 1 : 0) | ((fd_debug_flags() & 4) ? 2 : 0);   // 4: ablate the GELU math
+    g.nostore = FD_ABL(((fd_debug_flags() & 16) ? 1 : 0) | ((fd_debug_flags() & 4) ? 2 : 0));   // 4: ablate the GELU math
     if (use_v2) {
         GemmArgsV2 a2;
         a2.g = g;
@@ -1445,6 +1445,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         // keeps everything on v2, flag 2 forces v3
         const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU && !g8;
         if (g8 && (dbg & (2 | 512))) return FEDDAT_EINVAL;      // the code epilogues exist on the two-group kernel only
+#ifdef FEDDAT_ABLATE
         if (dbg & 512) {        // tools/gemm_defer_probe.py: the deferred-epilogue timing probe (RT = 6; wrong results)
             static const V2Kernel fk[5] = {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 6, 1>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 6, 1>,
                                            gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 6, 1>, gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 6, 1>,
@@ -1455,6 +1456,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             hipLaunchKernelGGL(fk[epi], dim3(total3 < n_cu ? total3 : n_cu), dim3(256), V3Cfg<6>::LDS, stream, a2);
             FD_LAUNCH_RET();
         }
+#endif
         if (((dbg & 2) || v3_pick) && !(dbg & 1)) {
             const bool rt8 = (dbg & 64) ? true : (dbg & 32) ? false : wm4;
             const V2Kernel k3 = v3_kernel_table()[rt8 ? 1 : 0][epi];
@@ -1470,7 +1472,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         if (fd_set_max_lds((const void*)kern, lds_bytes) != FEDDAT_OK) return FEDDAT_ELAUNCH;
         const int total = a2.tiles_m * (N / V2_BN);
         int grid = total < n_cu ? total : n_cu;
-        if ((dbg >> 8) > 0 && (dbg >> 8) < grid) grid = dbg >> 8;      // ablation: cap the number of persistent blocks
+        if (FD_ABL((dbg >> 8) & 0xfff) > 0 && FD_ABL((dbg >> 8) & 0xfff) < grid) grid = (dbg >> 8) & 0xfff;      // ablation: cap the number of persistent blocks
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, a2);
         FD_LAUNCH_RET();
     }

@@ -68,6 +68,38 @@ __global__ __launch_bounds__(64) void dat_loss_finish(const float* __restrict__ 
     }
 }
 
+// VQA score of a batch (train_vqa_crossvqa.py:241-257, task_trainer.py:125-157): acc[0] += sum_b target[b, argmax_j logits[b, j]],
+// acc[1] += B.  One block, one wave per row at a time; argmax takes the FIRST maximal index (torch.argmax); the row scores
+// are added in row order by lane 0 of wave 0 (deterministic).
+__global__ __launch_bounds__(256) void vqa_score_kernel(const float* __restrict__ logits, const float* __restrict__ target,
+                                                        int B, int C, float* __restrict__ acc) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mine = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        const float* x = logits + (size_t)b * C;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = lane; j < C; j += 64) {
+            const float v = x[j];
+            if (v > best || (v == best && j < bi)) { best = v; bi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (bi < C) mine += target[(size_t)b * C + bi];       // (wave-uniform; rows b, b+4, ... in order)
+    }
+    if (lane == 0) part[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc[0] += (part[0] + part[1]) + (part[2] + part[3]);
+        acc[1] += (float)B;
+    }
+}
+
 // HF get_polynomial_decay_schedule_with_warmup(lr_end=0, power=1) multiplier (task_trainer.py:53-59).
 __device__ __forceinline__ float poly_lambda(int t, int warmup, int total) {
     if (t < warmup) return (float)t / (float)max(1, warmup);
@@ -159,6 +191,13 @@ extern "C" int feddat_dat_loss_fwd_bwd(const float* logits, const float* teacher
     hipLaunchKernelGGL(dat_loss_kernel, dim3(B), dim3(64), 0, stream, logits, teacher, target, B, C, temp, dlogits,
                        row_terms);
     hipLaunchKernelGGL(dat_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, B, temp, scalars);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_vqa_score_accumulate(const float* logits, const float* target, int B, int C, float* acc,
+                                           hipStream_t stream) {
+    FD_CHECK_ARG(logits && target && acc && B > 0 && C > 0);
+    hipLaunchKernelGGL(vqa_score_kernel, dim3(1), dim3(256), 0, stream, logits, target, B, C, acc);
     FD_LAUNCH_RET();
 }
 

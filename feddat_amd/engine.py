@@ -749,7 +749,8 @@ class ViltDatEngine:
         self.head[task].state.copy_(torch.tensor([0, 0], dtype=torch.int32))
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
-        sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps)
+        sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.use_layer_calls, self.fp8,
+               self.fp8_ffn_chain)        # host-side switches that change the launch list are part of the signature
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig

@@ -19,6 +19,7 @@ EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32, EPI_GELU_G8, EPI_MUL_
 F8_ACT_SCALE, F8_GRAD_HEADROOM = 0.125, 4.0      # FEDDAT_F8_ACT_SCALE / FEDDAT_F8_GRAD_HEADROOM
 G8_LO, G8_STEP = -0.135, 0.005        # FEDDAT_G8_LO / FEDDAT_G8_STEP: gelu' ~ G8_LO + G8_STEP * code
 
+ABI_VERSION = 6
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 
 
@@ -63,6 +64,7 @@ _SIGS = {
     "feddat_set_debug_flags": [i32],
     "feddat_comm_unique_id": [vp],
     "feddat_comm_create": [vp, i32, i32, C.POINTER(vp)],
+    "feddat_comm_create_timeout": [vp, i32, i32, i32, C.POINTER(vp)],
     "feddat_comm_destroy": [vp],
     "feddat_fedavg_allreduce": [vp, vp, vp, i64, f32, f32, vp],
     "feddat_comm_info": [vp, vp, vp, vp],
@@ -105,6 +107,7 @@ _SIGS = {
     "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
+    "feddat_vqa_score_accumulate": [vp, vp, i32, i32, vp, vp],
     "feddat_lm_loss_fwd_bwd": [vp, vp, i64, vp, vp, i32, i32, f32, f32, vp, i64, vp, vp],
     "feddat_axpby3": [vp, f32, vp, f32, vp, f32, vp, vp, i64, vp],
     "feddat_vilt_stage_inputs": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
@@ -160,17 +163,27 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes", "_table_entries")) else i32
-    if lib.feddat_abi_version() != 5:
+    if lib.feddat_abi_version() != ABI_VERSION:
         raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
-    if os.environ.get("FEDDAT_GEMM_DEBUG"):       # tools/ ablations: the env var is read HERE, never by the library
-        lib.feddat_set_debug_flags(int(os.environ["FEDDAT_GEMM_DEBUG"]))
     _lib = lib
     return lib
 
 
+def use_ablation_build():
+    """tools/ only, and only before the first load(): bind libfeddat_hip_ablate.so (`python -m feddat_amd.build --ablate`), the
+    -DFEDDAT_ABLATE build that contains the timing-only probes (wrong results).  Nothing in feddat_amd/, bench.py or tests/
+    calls this; the production library rejects those flags (feddat_set_debug_flags -> EINVAL)."""
+    global LIB_PATH
+    if _lib is not None:
+        raise FeddatHipError("use_ablation_build() must be called before the library is loaded")
+    LIB_PATH = os.path.join(_PKG, "libfeddat_hip_ablate.so")
+
+
 def set_debug_flags(flags: int):
-    """tools/ ablations only (GEMM: 8 skip epilogue, 32/64 force tile height, bits 8..15 block cap; adapter kernels: bits
-    16..23 extra dynamic LDS in KiB)."""
+    """Kernel-selection switches (bit-identical results): 1 / 2 GEMMs on the two-group / one-wave-per-SIMD kernel, 32 / 64
+    force 192- / 256-row tiles, 128 no small-tile kernel, 256 K = 32 fp8 MFMA, bit 23 one attention-backward block per pair,
+    bits 28..31 cap the persistent GEMM grid.  The timing-only ablations (8 skip epilogue, 4 / 16, 512, bits 8..22, 24..26)
+    exist in the ablation build only (use_ablation_build)."""
     _chk(load().feddat_set_debug_flags(int(flags)), "feddat_set_debug_flags")
 
 
@@ -202,7 +215,9 @@ class RcclComm:
     """ncclComm_t made through the C ABI (feddat_comm_*): rank 0 draws the unique id, `exchange(id_bytes) -> id_bytes`
     ships it to the other ranks over any host channel (torch.distributed object broadcast, a TCPStore, MPI, a file)."""
 
-    def __init__(self, world: int, rank: int, exchange):
+    def __init__(self, world: int, rank: int, exchange, timeout_s: float = 120.0):
+        """timeout_s: watchdog on the collective ncclCommInitRank (feddat_comm_create_timeout): a peer that died or could not
+        load RCCL makes this raise after timeout_s instead of hanging; 0 = wait forever."""
         buf = C.create_string_buffer(128)
         rc0 = load().feddat_comm_unique_id(buf) if rank == 0 else 0
         # rank 0 ships its return code with the id, so that a failure there (RCCL not loadable) raises on EVERY rank instead of
@@ -212,7 +227,8 @@ class RcclComm:
             raise FeddatHipError("feddat_comm_unique_id failed on rank 0 (is librccl loadable?)")
         ident = msg[1:]
         self._h = vp()
-        _chk(load().feddat_comm_create(C.c_char_p(ident), world, rank, C.byref(self._h)), "feddat_comm_create")
+        _chk(load().feddat_comm_create_timeout(C.c_char_p(ident), world, rank, int(timeout_s * 1000), C.byref(self._h)),
+             "feddat_comm_create_timeout")
         self.world, self.rank = world, rank
 
     def fedavg_allreduce(self, flat, scratch, num: float, total: float):
@@ -244,7 +260,7 @@ def _stream():
 
 def _chk(rc: int, what: str):
     if rc != 0:
-        raise FeddatHipError(f"{what} failed with code {rc} ({'EINVAL' if rc == 1 else 'ELAUNCH'})")
+        raise FeddatHipError(f"{what} failed with code {rc} ({ {1: 'EINVAL', 2: 'ELAUNCH', 3: 'ETIMEOUT'}.get(rc, '?') })")
 
 
 def _dev(*ts):
@@ -520,6 +536,14 @@ def dat_loss_fwd_bwd(logits, teacher, target, dlogits, scalars, temp=3.0):
     assert scalars.numel() >= 4 + 2 * B
     _chk(load().feddat_dat_loss_fwd_bwd(_p(logits), _p(teacher), _p(target), B, Cn, temp, _p(dlogits), _p(scalars),
                                         _stream()), "feddat_dat_loss_fwd_bwd")
+
+
+def vqa_score_accumulate(logits, target, acc):
+    """acc[0] += sum_b target[b, argmax logits[b]], acc[1] += B (device; train_vqa_crossvqa.py:241-257)."""
+    _dev(logits, target, acc)
+    assert logits.shape == target.shape and logits.is_contiguous() and target.is_contiguous() and acc.numel() >= 2
+    _chk(load().feddat_vqa_score_accumulate(_p(logits), _p(target), logits.shape[0], logits.shape[1], _p(acc), _stream()),
+         "feddat_vqa_score_accumulate")
 
 
 def lm_loss_fwd_bwd(logits, teacher, labels, row_weight, V, temp, kl_scale, dlogits_bf16, scalars):

@@ -128,15 +128,15 @@ class TaskTrainer:
 
     @torch.no_grad()
     def eval_one_loader(self, model: ViltContinualLearner, loader) -> float:
-        """VQA score (train_vqa_crossvqa.py:241-257; task_trainer.py:125-157): score of the arg-max answer."""
-        score, seen = 0.0, 0
+        """VQA score (train_vqa_crossvqa.py:241-257; task_trainer.py:125-157): score of the arg-max answer, accumulated on
+        the device (feddat_vqa_score_accumulate); ONE read-back per loader."""
+        acc = torch.zeros(2, device=model.device)
         for batch in loader:
             _, logits = model(task_key=self.task_key, images=batch, texts=None)
-            tgt = batch["target_scores"].to(logits.device)
-            idx = logits.argmax(1, keepdim=True)       # host-side metric bookkeeping, not part of the hot path
-            score += float(tgt.gather(1, idx).sum())
-            seen += logits.shape[0]
-        return 100.0 * score / max(seen, 1)
+            tgt = batch["target_scores"].to(logits.device, torch.float32, non_blocking=True).contiguous()
+            L.vqa_score_accumulate(logits, tgt, acc)
+        score, seen = acc.tolist()
+        return 100.0 * score / max(seen, 1.0)
 
     def eval(self, model: ViltContinualLearner):
         loader = self.vqa_test_dataloader
@@ -160,7 +160,8 @@ class AlbefTaskTrainer(TaskTrainer):
         optimizer = self.create_optimizer(model, self.args.optimizer_mode)
         eng.lr, eng.eps, eng.wd = optimizer.lr, optimizer.eps, optimizer.weight_decay
         eng.begin_local_update(steps_per_epoch=len(self.vqa_train_dataloader), num_epochs=self.num_epochs,
-                               warmup_ratio=self.warmup_ratio, opt_adapters=optimizer.adapters)
+                               warmup_ratio=self.warmup_ratio, opt_adapters=optimizer.adapters,
+                               dropout_epoch=getattr(self, "dropout_epoch", 0))
         model.adapter_requires_grad[2] = False
         for epoch in range(self.local_epochs):
             for step, batch in enumerate(self.vqa_train_dataloader):
@@ -189,6 +190,51 @@ class AlbefTaskTrainer(TaskTrainer):
 
 
 # -------------------------------------------------------------------------------------------------------------
+def deal_clients(steps: Sequence[int], world: int) -> List[int]:
+    """owner[k] = rank of client k.  K <= world: client k on rank k.  K > world: longest-processing-time dealing (clients by
+    descending len(loader), ties by client index, each to the currently least-loaded rank, ties to the lowest rank)."""
+    K = len(steps)
+    if K <= world:
+        return list(range(K))
+    owner, load = [0] * K, [0] * world
+    for k in sorted(range(K), key=lambda k: (-steps[k], k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[k], load[r] = r, load[r] + steps[k]
+    return owner
+
+
+def round_efficiency(loads: Sequence[int]) -> float:
+    """Upper bound of a round's scaling efficiency with heterogeneous clients: every rank waits at the all-reduce for the
+    rank with the most steps, so N ranks deliver sum(loads) / max(loads) ranks' worth of work (SURVEY 8d config 3:
+    len(loader) in {40..80} on 8 ranks -> 0.70)."""
+    return float(sum(loads)) / (len(loads) * max(max(loads), 1))
+
+
+def agree_on_exchange(make_comm, world: int, log):
+    """RCCL communicator for the round's collective, or None on EVERY rank together.  A rank where creation fails (librccl
+    not loadable, bootstrap timeout) must not raise while its peers enter feddat_fedavg_allreduce: all ranks all-reduce(MIN)
+    an ok flag over the torch.distributed group and fall back to torch.distributed's all-reduce as one."""
+    comm, err = None, None
+    try:
+        comm = make_comm()
+    except L.FeddatHipError as e:
+        err = e
+    if world > 1:
+        import torch.distributed as dist
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            ok = ok.cuda()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+    if comm is None:
+        log.warning("C-ABI RCCL communicator unavailable%s: %s", f" ({err})" if err else " on a peer",
+                    "torch.distributed all_reduce takes the exchange on all ranks" if world > 1 else
+                    "single rank, the exchange is the identity")
+    return comm
+
+
 def build_parser() -> argparse.ArgumentParser:
     """Same flags as src/train/main.py:262-323 (unused ones are accepted and ignored) + synthetic-data knobs."""
     p = argparse.ArgumentParser()
@@ -255,6 +301,9 @@ def main(argv=None):
         raise L.FeddatHipError("only --optimizer_mode dat is on the MI355X hot path (SURVEY.md section 2, row 13)")
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
     log = logging.getLogger("feddat_amd")
+    from . import weights
+    # a checkpoint that was asked for must exist (local path; no network): never a silent random initialisation
+    pretrained = weights.resolve(args.pretrained_model_name)
     import torch.distributed as dist
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -270,26 +319,43 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
     tasks = TASK_SETS.get(args.ordered_cl_tasks, args.ordered_cl_tasks.split(","))
-    my_tasks = tasks[rank::world]                       # client -> GPU mapping
+    steps_list = [int(x) for x in str(args.synthetic_steps).split(",")]
+    steps_of = {t: steps_list[i % len(steps_list)] for i, t in enumerate(tasks)}
+    # client -> GPU mapping.  One client per rank when there are at least as many ranks as clients (rank k <-> client k);
+    # with more clients than ranks the clients are dealt by longest-processing-time (descending len(loader), each to the
+    # least-loaded rank) instead of round-robin, which bounds the round's imbalance; a rank visits its clients in the
+    # reference's client order (the local pre-sum below is order-sensitive in the last bit).
+    owner = deal_clients([steps_of[t] for t in tasks], world)
+    my_tasks = [t for t, o in zip(tasks, owner) if o == rank]
+    loads = [sum(steps_of[t] for t, o in zip(tasks, owner) if o == r) for r in range(world)]
+    if rank == 0:
+        log.info("client -> rank %s; steps per rank %s; predicted round efficiency sum/(N*max) = %.3f (the all-reduce "
+                 "barrier waits for the longest rank)", dict(zip(tasks, owner)), loads, round_efficiency(loads))
     if not my_tasks:
         # more GPUs than clients (the reference's default 'domain' set has 5): this rank holds no client; it still joins
         # every round's all-reduce with a zero contribution so that the average over the K real clients is unchanged
         log.warning("rank %d of %d holds no client (%d clients): idle, joins the all-reduce only", rank, world, len(tasks))
-    steps_list = [int(x) for x in str(args.synthetic_steps).split(",")]
-    steps_of = {t: steps_list[i % len(steps_list)] for i, t in enumerate(tasks)}
     dev = torch.device("cuda", local)
     albef = "albef" in args.encoder_name
     if albef:
         from . import albef_spec
         from .albef_modeling import create_albef_continual_learner_model
         dims = {k: int(v) for k, v in (kv.split("=") for kv in args.albef_dims.split(",") if kv)}
-        params = albef_spec.random_init(seed=args.seed, image=args.image_size, **dims)   # stand-in for ALBEF.pth
+        if pretrained:       # load_albef (albef.py:205-241): ALBEF.pth['model'] + pos-embed interpolation + key surgery
+            params = weights.load_albef_pretrained(pretrained, seed=args.seed, image=args.image_size, **dims)
+            log.info("loaded ALBEF weights from %s", pretrained)
+        else:                # no --pretrained_model_name: random weights of the real architecture (synthetic benchmarks)
+            params = albef_spec.random_init(seed=args.seed, image=args.image_size, **dims)
         model = create_albef_continual_learner_model(params, dev, args.batch_size, args.batch_size, lr=args.lr,
                                                      image=args.image_size, dropout=args.albef_dropout,
                                                      seed=args.seed + 7919 * rank, **dims)
         Trainer = AlbefTaskTrainer
     else:
-        params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)    # stand-in for from_pretrained
+        if pretrained:       # load_vilt_encoder (vilt.py:387-420): HF directory / state dict + modality-embedding expansion
+            params = weights.load_vilt_pretrained(pretrained, tasks, layers=args.num_layers, seed=args.seed)
+            log.info("loaded ViLT weights from %s", pretrained)
+        else:                # no --pretrained_model_name: random weights of the real architecture (synthetic benchmarks)
+            params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)
         model = create_vilt_continual_learner_model(params, tasks, dev, args.batch_size, args.image_size,
                                                     args.num_layers, args.lr)
         Trainer = TaskTrainer
@@ -312,9 +378,13 @@ def main(argv=None):
     rccl, rccl_scratch = None, None
     if args.exchange == "rccl_cabi" and (world == 1 or dist.get_backend() == "nccl"):
         from .fedavg import make_rccl_comm
-        rccl = make_rccl_comm(world, rank) if world > 1 else L.RcclComm(1, 0, lambda ident: ident)
-        rccl_scratch = torch.empty_like(acc)
-        log.info("FedAvg exchange: feddat_fedavg_allreduce, %s", rccl.info())
+        # one rank: the collective is the identity and nothing may depend on librccl being loadable (the communicator is
+        # still made when it can be, so the single-GPU run exercises the same entry points)
+        rccl = agree_on_exchange((lambda: make_rccl_comm(world, rank)) if world > 1 else
+                                 (lambda: L.RcclComm(1, 0, lambda ident: ident)), world, log)
+        if rccl is not None:
+            rccl_scratch = torch.empty_like(acc)
+            log.info("FedAvg exchange: feddat_fedavg_allreduce, %s", rccl.info())
     comm_names = model.comm_state_dict_names
     first_round = 0
     # requires_grad flags of the SERVER model.  Clients train on deepcopy(server) (main.py:472), so whatever train_step
@@ -337,6 +407,7 @@ def main(argv=None):
             model.load_state_dict(personal_params[task_key])        # main.py:473-478
             model.adapter_requires_grad = dict(server_flags)
             trainer = Trainer(args, task_key, data[task_key], data[task_key][:2], log)
+            trainer.dropout_epoch = comm_round * len(tasks) + tasks.index(task_key)     # fresh dropout masks per round and client
             trainer.train(model, comm_round)
             personal_params[task_key] = personal(model.state_dict())     # main.py:493-497
             # local pre-sum in client order, then (if distributed) one all-reduce: main.py:50-65

@@ -28,8 +28,9 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_OK 0
 #define FEDDAT_EINVAL 1
 #define FEDDAT_ELAUNCH 2
+#define FEDDAT_ETIMEOUT 3   /* feddat_comm_create_timeout only */
 
-#define FEDDAT_ABI_VERSION 5   /* 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
+#define FEDDAT_ABI_VERSION 6   /* 6: feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -351,6 +352,10 @@ int feddat_reduce_partials(const float* in, long stride, int nsplit, long n, flo
  * ------------------------------------------------------------------------------------------- */
 int feddat_dat_loss_fwd_bwd(const float* logits, const float* teacher, const float* target, int B, int C, float temp,
                             float* dlogits, float* scalars, hipStream_t stream);
+/* VQA score bookkeeping of the eval path on the device (train_vqa_crossvqa.py:241-257; task_trainer.py:125-157):
+ * acc[0] += sum_b target[b, argmax_j logits[b, j]] (first maximal index, like torch.argmax), acc[1] += B.
+ * acc: fp32 [2] device buffer the caller zeroes before a loader and reads back ONCE after it (score = 100 acc[0] / acc[1]). */
+int feddat_vqa_score_accumulate(const float* logits, const float* target, int B, int C, float* acc, hipStream_t stream);
 
 /* ALBEF (configs[3]) loss: BertLMHeadModel's shifted next-token cross-entropy, weighted per answer
  * (src/modeling/models/xbert.py:1283-1297 with reduction='none'; ALBEF.forward: loss = sum_n weights[n] * lm_loss[n] / B,
@@ -514,6 +519,12 @@ int feddat_fedavg_accumulate(float* acc, const float* x, long n, float num, floa
  * Replaces get_average_net's host loop over K clients x 48 tensors (main.py:50-65, call site main.py:510). */
 int feddat_comm_unique_id(void* id_128_bytes);
 int feddat_comm_create(const void* id_128_bytes, int world, int rank, void** comm_out);
+/* The same with a watchdog: ncclCommInitRank waits for ALL ranks, so one rank that died (or could not load RCCL) would
+ * hang the others.  timeout_ms > 0: give up after that long with FEDDAT_ETIMEOUT and *comm_out = NULL (the bootstrap
+ * attempt is abandoned on a helper thread), so the survivors can agree on another exchange (feddat_amd/train.py does,
+ * over torch.distributed); timeout_ms = 0: wait forever (= feddat_comm_create).  RCCL binding order: the librccl
+ * the process has already mapped (dlopen RTLD_NOLOAD -- e.g. the one PyTorch-ROCm ships), else the system one. */
+int feddat_comm_create_timeout(const void* id_128_bytes, int world, int rank, int timeout_ms, void** comm_out);
 int feddat_comm_destroy(void* comm);
 int feddat_fedavg_allreduce(void* comm, float* flat, float* scratch, long n, float num, float total, hipStream_t stream);
 /* What the communicator is: the RCCL version the library bound at run time (ncclGetVersion code, e.g. 22105 = 2.21.5),

@@ -115,7 +115,7 @@ class _Wrapper(nn.Module):
         return [loss, logits]
 
 
-def build_reference_model(d: A.AlbefDims, dropout: float = 0.0):
+def build_albef_module(d: A.AlbefDims, dropout: float = 0.0):
     ac = {"names": ["adapter_0", "adapter_1", "adapter_2"], "device": "cpu"}
     cfgd = dict(hidden_size=d.hidden, intermediate_size=d.inter, num_attention_heads=d.heads, num_hidden_layers=d.enc_layers,
                 vocab_size=d.vocab, max_position_embeddings=d.max_pos, type_vocab_size=2, layer_norm_eps=1e-12,
@@ -136,6 +136,11 @@ def build_reference_model(d: A.AlbefDims, dropout: float = 0.0):
     m.text_decoder = xb.BertLMHeadModel(config=cd)
     # transformers 4.16.2 init_weights -> tie_weights: LM-head decoder weight IS the decoder's word-embedding matrix
     m.text_decoder.cls.predictions.decoder.weight = m.text_decoder.bert.embeddings.word_embeddings.weight
+    return m
+
+
+def build_reference_model(d: A.AlbefDims, dropout: float = 0.0, albef_module=None):
+    m = albef_module if albef_module is not None else build_albef_module(d, dropout)
     CL = _load_continual_learner_class()
     cl = CL.__new__(CL)
     nn.Module.__init__(cl)
@@ -152,7 +157,8 @@ def build_reference_model(d: A.AlbefDims, dropout: float = 0.0):
     with torch.no_grad():
         for k, shp in shapes.items():
             assert tuple(sd[k].shape) == tuple(shp), (k, sd[k].shape, shp)
-            sd[k].copy_(A.O.seeded_value(k, shp, 0.02, 0.02))
+            if albef_module is None or "adapter_" in k:        # (a loaded checkpoint keeps its backbone: golden_loader)
+                sd[k].copy_(A.O.seeded_value(k, shp, 0.02, 0.02))
     extra = [k for k in sd if k not in shapes and "position_ids" not in k and "decoder.weight" not in k and "decoder.bias" not in k]
     assert not extra, extra[:5]
     dec = m.text_decoder
@@ -377,9 +383,55 @@ def golden_dropout(out, steps=3, p=0.1, seed=77):
     print("G12 losses", rec["losses"], "dropout sites fired", len(state["fired"]))
 
 
+LOADER_DIMS = dict(vit_depth=1, enc_layers=7, fusion_layer=6, dec_layers=1, image=64, vocab=3072, max_pos=64)
+LOADER_PRE_IMAGE = 48          # the synthetic ALBEF.pth was "pre-trained" at 48 x 48: a 3 x 3 position grid -> 4 x 4
+
+
+def golden_loader(out):
+    """G14: PRETRAINED-weight loading for ALBEF.  tests/ckpt_util.write_albef_checkpoint writes a file in the layout of the
+    published ALBEF.pth (BertForMaskedLM text encoder with `bert.` keys, 12-layer numbering with fusion from layer 6, smaller
+    pre-training position grid, momentum / projection / queue tensors).  The reference's OWN load_albef (src/modeling/albef.py:
+    188-241: torch.load, interpolate_pos_embed, `bert.` strip, text-encoder layers >= 6 -> decoder layers, strict=False load)
+    runs on it; only its constructor calls are redirected (ALBEF(...) -> the shimmed module of build_albef_module, tokenizer and
+    ALBEFWrapper -> stand-ins: both load ./models/bert-base-uncased).  Stored per resulting state-dict key: L2 norm + 8 samples;
+    plus loss / logits of a training forward in two modes with name-seeded adapters."""
+    import logging
+    import tempfile
+    import src.modeling.albef as ref_albef
+    from tests.ckpt_util import write_albef_checkpoint
+    d = A.AlbefDims(**LOADER_DIMS)
+    ref_albef.ALBEF = lambda config, text_encoder, text_decoder, tokenizer: build_albef_module(d)
+    ref_albef.BertTokenizer = types.SimpleNamespace(from_pretrained=lambda *a, **k: None)
+    ref_albef.ALBEFWrapper = lambda model, device: model
+    with tempfile.TemporaryDirectory() as tmp:
+        path = write_albef_checkpoint(os.path.join(tmp, "ALBEF.pth"), vit_depth=d.vit_depth, enc_layers=d.enc_layers,
+                                      pre_image=LOADER_PRE_IMAGE, vocab=d.vocab, max_pos=d.max_pos)
+        m = ref_albef.load_albef(logging.getLogger("g14"), {"text_encoder": None, "text_decoder": None, "distill": False},
+                                 path, torch.device("cpu"), path)
+    model = build_reference_model(d, albef_module=m)
+    rec = {}
+    for k, v in model.state_dict().items():
+        if "adapter_" in k or "position_ids" in k:
+            continue
+        f = v.detach().float().flatten()
+        rec["norm::" + k] = np_(f.norm())
+        rec["samp::" + k] = np_(f[(torch.arange(8, dtype=torch.int64) * (f.numel() - 1)) // 7])
+    b0 = A.synthetic_batch(3, d, 1400, q_len=12, a_len=5, k=[2, 1, 3], ragged=True)
+    with torch.no_grad():
+        for mode in ("gating", "adapter_1"):
+            set_mode(model, mode)
+            loss, logits = model("art", dict(b0, train=True))
+            rec[f"fwd.{mode}.loss"], rec[f"fwd.{mode}.logits"] = np_(loss), np_(logits)
+    np.savez_compressed(os.path.join(out, "g14_albef_pretrained.npz"), **rec)
+    print("G14 keys", len(rec), "losses", float(rec["fwd.gating.loss"]), float(rec["fwd.adapter_1.loss"]))
+
+
 if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden")
     torch.manual_seed(0)
+    if "--only-g14" in sys.argv:
+        golden_loader(out)
+        sys.exit(0)
     if "--only-g12" in sys.argv:
         golden_dropout(out)
         sys.exit(0)

@@ -267,13 +267,105 @@ def golden_g8(out, steps=40):
     print("G8 losses", losses[:3], "...", losses[-3:])
 
 
+def golden_g8b(out, steps=80, batch=32, snaps=(20, 40, 60, 80)):
+    """G8b: the same realistic local round as G8, at configs[1]/[2]'s OWN batch size (B = 32, 384x384, S = 185) on the
+    reference: len(loader) = steps, num_epochs = 15 (task_trainer.py:53-59: 1200 ticks, warm-up 120 ticks = 60 batches
+    at steps = 80).  The update dW = W_after_n - W_init is stored at every n in `snaps`, so one fixture serves all round
+    lengths: per adapter_0 / adapter_1 / head tensor its L2 norm, mean |dW|, max |dW| and 1024 strided samples."""
+    d = O.ViltDims(layers=12)
+    model = build_reference_model(d, ["art"], bias_std=0.02)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batches = [O.synthetic_batch(batch, 384, 8000 + s) for s in range(steps)]
+    rec = {"steps": np.array(steps), "batch": np.array(batch), "snaps": np.array(snaps)}
+
+    def cap(step, m):
+        n = step + 1
+        print("G8b step", n, flush=True)
+        if n not in snaps:
+            return
+        for k, v in m.state_dict().items():
+            if "adapter_0" in k or "adapter_1" in k or k.startswith("task_layer.art."):
+                dw = (v.detach() - init[k]).flatten()
+                idx = torch.linspace(0, dw.numel() - 1, min(1024, dw.numel())).long()
+                rec[f"s{n}::dnorm::" + k] = np_(dw.norm())
+                rec[f"s{n}::dmean::" + k] = np_(dw.abs().mean())
+                rec[f"s{n}::dmax::" + k] = np_(dw.abs().max())
+                rec[f"s{n}::dsamp::" + k] = np_(dw[idx])
+
+    losses, _ = ref_local_update(model, "art", batches, lr=1e-4, capture=cap)
+    rec["losses"] = np.array(losses, np.float32)
+    np.savez_compressed(os.path.join(out, f"g8b_round{steps}_b{batch}.npz"), **rec)
+    print("G8b losses", losses[:3], "...", losses[-3:])
+
+
+def golden_g13(out):
+    """G13: PRETRAINED-weight loading.  tests/ckpt_util.write_hf_vilt_checkpoint lays down a HuggingFace directory in the
+    layout of dandelin/vilt-b32-mlm (ViltForMaskedLM keys, 2 layers, key-seeded fill); here it is loaded the way the reference
+    does -- ViltModel.from_pretrained(dir) (vilt.py:401-405), ViltEncoderWrapper.expand_modality_type_embeddings
+    (vilt.py:102-113, called from its __init__ :53), ViltContinualLearner + Adaptered_ViltOutput -- and the fixture keeps, per
+    state-dict key of the resulting model, the tensor's L2 norm and 8 samples, plus pooled features / logits of two forward
+    modes with name-seeded adapters and heads.  feddat_amd.weights must reproduce every entry from the same directory."""
+    import tempfile
+    from tests.ckpt_util import write_hf_vilt_checkpoint
+    d = O.ViltDims(layers=2)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_hf_vilt_checkpoint(tmp, layers=2)
+        vilt, info = ViltModel.from_pretrained(tmp, output_loading_info=True)
+        assert not info["missing_keys"], info["missing_keys"][:5]           # HF itself finds every ViltModel tensor in the file
+        assert all(k.startswith("mlm_score") for k in info["unexpected_keys"]), info["unexpected_keys"][:5]
+    enc = ViltEncoderWrapper.__new__(ViltEncoderWrapper)
+    nn.Module.__init__(enc)
+    enc.processor, enc.vilt, enc.device = None, vilt, torch.device("cpu")
+    enc.max_text_length, enc.encoder_dim = vilt.config.max_position_embeddings, vilt.config.hidden_size
+    enc.expand_modality_type_embeddings()
+    enc.process_inputs = lambda images, texts: images
+    task_cfg = {"art": {"num_labels": d.num_labels, "num_images": 1, "model_type": "classification"}}
+    model = ViltContinualLearner(["art"], enc, vilt.config.hidden_size, task_cfg, torch.device("cpu"),
+                                 {"names": ["adapter_0", "adapter_1", "adapter_2"], "device": "cpu"})
+    from src.modeling.adaptered_output import Adaptered_ViltOutput
+    for i in range(d.layers):
+        model.vilt_encoder.vilt.encoder.layer[i].output = Adaptered_ViltOutput(
+            model.vilt_encoder.vilt.encoder.layer[i].output, model.adapter_config)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, shp in O.param_shapes(d, ["art"]).items():
+            if "adapter_" in k or k.startswith("task_layer."):
+                sd[k].copy_(O.seeded_value(k, shp, 0.02, 0.02))
+    model.eval()
+    rec = {}
+    for k, v in model.state_dict().items():
+        if "adapter_" in k or k.startswith("task_layer.") or "position_ids" in k or "token_type_ids" in k:
+            continue
+        f = v.detach().float().flatten()
+        rec["norm::" + k] = np_(f.norm())
+        rec["samp::" + k] = np_(f[(torch.arange(8, dtype=torch.int64) * (f.numel() - 1)) // 7])
+    batch = O.synthetic_batch(2, 384, 1300)
+    with torch.no_grad():
+        for mode in ("gating", "adapter_1"):
+            if mode == "gating":
+                model.activate_gating()
+            else:
+                model.deactivate_gating()
+                model.set_active_adapter(mode)
+            pooled, lg = model(task_key="art", images=_enc_only(batch), texts=None)
+            rec[f"fwd.{mode}.pooled"], rec[f"fwd.{mode}.logits"] = np_(pooled), np_(lg)
+    np.savez_compressed(os.path.join(out, "g13_vilt_pretrained.npz"), **rec)
+    print("G13 keys", len(rec), "logits", rec["fwd.gating.logits"][0, :4])
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     torch.manual_seed(0)
     if "--only-g8" in sys.argv:          # [--steps N]: the same round at another length (g8_round<N>.npz; 80 = the longest
         steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 40      # len(loader) of configs[2])
+        if "--batch" in sys.argv:        # --batch 32: the round at configs[1]'s own batch (g8b_round<N>_b<B>.npz,
+            golden_g8b(out, steps, int(sys.argv[sys.argv.index("--batch") + 1]))      # updates stored every 20 steps)
+            return
         golden_g8(out, steps)
+        return
+    if "--only-g13" in sys.argv:
+        golden_g13(out)
         return
     if "--only-g6" in sys.argv:          # the other fixtures are unchanged; regenerate just this one
         golden_g6(out)

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/feddat_hip.h but not exported"
-    assert lib.feddat_abi_version() == 5
+    assert lib.feddat_abi_version() == 6
 
 
 def test_python_binding_covers_the_header():
@@ -62,3 +62,25 @@ def test_library_does_not_read_the_environment_or_link_rccl():
     assert "getenv" not in und
     needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
     assert "rccl" not in needed.lower()
+
+
+def test_production_library_has_no_wrong_result_ablations():
+    """The timing-only probes of tools/ (skip-epilogue, no-store, no-compute, the deferred-epilogue GEMM instantiation, ...)
+    are compiled out of libfeddat_hip.so (-DFEDDAT_ABLATE builds libfeddat_hip_ablate.so for tools/): the production library
+    rejects their flags, keeps the kernel-SELECTION bits (bit-identical results), has no deferred-epilogue kernel, and the
+    binding does not switch anything on from the environment."""
+    import subprocess
+    from feddat_amd import build, lib
+    path = build.build()
+    L = ctypes.CDLL(path)
+    for wrong in (4, 8, 16, 512, 1 << 10, 1 << 16, 1 << 20, 2 << 20, 4 << 20, 1 << 24, 2 << 24, 4 << 24):
+        assert L.feddat_set_debug_flags(wrong) == 1, wrong           # FEDDAT_EINVAL
+    for ok in (0, 1, 2, 32, 64, 128, 256, 1 << 23, 8 << 28, 1 | 32):
+        assert L.feddat_set_debug_flags(ok) == 0, ok
+    L.feddat_set_debug_flags(0)
+    # gemm_nt_v3_kernel<EPI, RT, FAKE = 1> is the deferred-epilogue probe: no such instantiation in the production object
+    syms = subprocess.run(["strings", path], capture_output=True, text=True).stdout
+    assert "gemm_nt_v3_kernelILi0ELi6ELi0EE" in syms
+    assert "gemm_nt_v3_kernelILi0ELi6ELi1EE" not in syms
+    src = open(os.path.join(ROOT, "feddat_amd", "lib.py")).read()
+    assert "FEDDAT_GEMM_DEBUG" not in src and "environ" not in src

@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feddat_amd import lib as L  # noqa: E402
+L.use_ablation_build()      # timing-only probes live in libfeddat_hip_ablate.so (python -m feddat_amd.build --ablate)
 
 M, N, K, epi, flags = (int(v, 0) for v in sys.argv[1:6])
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3

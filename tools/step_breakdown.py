@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="feddat_set_debug_flags value (ablations)")
     args = ap.parse_args()
     from feddat_amd import engine, lib as L, vilt_spec
+    if args.debug_flags & ~(1 | 2 | 32 | 64 | 128 | 256 | (1 << 23) | (0xf << 28)):
+        L.use_ablation_build()      # timing-only probes: libfeddat_hip_ablate.so (python -m feddat_amd.build --ablate)
     L.set_debug_flags(args.debug_flags)
     dev = torch.device("cuda", 0)
     params = vilt_spec.random_init(12, ["c0"], seed=0)
