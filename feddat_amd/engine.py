@@ -269,6 +269,10 @@ class ViltDatEngine:
         # True: one composite C-ABI call per middle layer (feddat_vilt_layer_fwd / _bwd); False: the same kernel sequence
         # issued op by op from here (what tools/step_breakdown.py brackets with events)
         self.use_layer_calls = True
+        # True: the serial tail (token-0 LayerNorm + pooler, task head forward / backward, loss, optimizer bookkeeping) on the
+        # fused kernels of csrc/head_tail.hip (20 launches); False: the round-3 sequence of 46 single-purpose launches (same
+        # arithmetic up to fp32 summation order; tools/step_breakdown.py --unfused-tail, and the tests compare the two)
+        self.fused_tail = True
         self.sched = dict(warmup=1, total=2)
         self.opt_adapters = (0, 1)
         self.task = self.tasks[0]
@@ -528,6 +532,11 @@ class ViltDatEngine:
         """ViltModel.layernorm on token 0 + ViltPooler (dense + tanh) -> self.pooled[:nb]."""
         H = self.H
         self._pool_src, self._pool_stride = h_last, (self.S * H if x_stride is None else x_stride)
+        if self.fused_tail:      # LayerNorm (statistics in the block) -> dense -> tanh in one launch
+            L.head_gemm(L.ht_job(h_last, self._pool_stride, 1, self.pool_w, 1, H, nb, H, H, self.pooled, bias_j=self.pool_b,
+                                 pro=L.HT_PRO_LN, pro_a=self.lnf_g, pro_b=self.lnf_b, pro_eps=self.ln_eps,
+                                 stats_out=self.cls_st, epi=L.HT_EPI_TANH))
+            return
         L.layernorm_fwd(h_last, self.lnf_g, self.lnf_b, self.ln_eps, nb, H, x_stride=self._pool_stride,
                         y_f32=self.cls_ln, stats=self.cls_st)
         self._sg(self.cls_ln, H, 1, self.pool_w, 1, H, nb, H, H, self.pooled, ksplit=4, bias_j=self.pool_b)
@@ -539,6 +548,14 @@ class ViltDatEngine:
         B, H, C = pooled.shape[0], self.H, self.C
         hp, s = self.head[task], self.hd[slot]
         pre = f"task_layer.{task}."
+        if self.fused_tail:
+            L.head_gemm(L.ht_job(pooled, H, 1, hp.view(pre + "clf_fc0.weight"), 1, H, B, 2 * H, H, s["a0"],
+                                 bias_j=hp.view(pre + "clf_fc0.bias")))
+            L.head_ln_gelu(s["a0"], hp.view(pre + "clf_norm0.weight"), hp.view(pre + "clf_norm0.bias"), 1e-5, s["n0"], s["st"],
+                           s["g0"])
+            L.head_gemm(L.ht_job(s["g0"], 2 * H, 1, hp.view(pre + "clf_fc1.weight"), 1, 2 * H, B, C, 2 * H, s["logits"],
+                                 bias_j=hp.view(pre + "clf_fc1.bias")))
+            return s["logits"]
         self._sg(pooled, H, 1, hp.view(pre + "clf_fc0.weight"), 1, H, B, 2 * H, H, s["a0"], ksplit=4,
                  bias_j=hp.view(pre + "clf_fc0.bias"))
         L.layernorm_fwd(s["a0"], hp.view(pre + "clf_norm0.weight"), hp.view(pre + "clf_norm0.bias"), 1e-5, B, 2 * H,
@@ -557,6 +574,18 @@ class ViltDatEngine:
         def G(n):
             return hp.view(pre + n, hp.g)
         dl = self.dlogits
+        if self.fused_tail:
+            # {dW_fc1 = dl^T g0, db_fc1} next to {dn0 = (dl W_fc1) * gelu'(n0)}; LayerNorm backward (dx, dgamma, dbeta);
+            # {dW_fc0 = da0^T pooled, db_fc0} next to {dpooled = da0 W_fc0}: three launches
+            L.head_gemm(L.ht_job(dl, 1, C, s["g0"], 2 * H, 1, C, 2 * H, B, G("clf_fc1.weight"), mode=1, colsum=G("clf_fc1.bias")),
+                        L.ht_job(dl, C, 1, hp.view(pre + "clf_fc1.weight"), 2 * H, 1, B, 2 * H, C, self.dn0,
+                                 epi=L.HT_EPI_MUL_DGELU, aux=s["n0"], ld_aux=2 * H))
+            L.head_ln_bwd_full(self.dn0, s["a0"], s["st"], hp.view(pre + "clf_norm0.weight"), self.da0, G("clf_norm0.weight"),
+                               G("clf_norm0.bias"))
+            L.head_gemm(L.ht_job(self.da0, 1, 2 * H, pooled, H, 1, 2 * H, H, B, G("clf_fc0.weight"), mode=1,
+                                 colsum=G("clf_fc0.bias")),
+                        L.ht_job(self.da0, 2 * H, 1, hp.view(pre + "clf_fc0.weight"), H, 1, B, H, 2 * H, dpooled_out))
+            return
         L.sgemm_f32(dl, 1, C, s["g0"], 2 * H, 1, C, 2 * H, B, G("clf_fc1.weight"), colsum=G("clf_fc1.bias"))
         L.sgemm_f32(dl, C, 1, hp.view(pre + "clf_fc1.weight"), 2 * H, 1, B, 2 * H, C, self.dg0)
         L.gelu_bwd(s["n0"], self.dg0, self.dn0)
@@ -580,8 +609,12 @@ class ViltDatEngine:
         """dpooled [2B,H] -> adapter_0 grads (rows [0,R)) and adapter_1 grads (rows [R,2R))."""
         R, R2, B, H = self.R, 2 * self.R, self.B, self.H
         nb = 2 * B
-        L.tanh_bwd(self.pooled, self.dpooled, self.dpre)
-        self._sg(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, ksplit=4)
+        if self.fused_tail:      # d(pooler input) = (dpooled * (1 - pooled^2)) W_pool in one launch
+            L.head_gemm(L.ht_job(self.dpooled, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, pro=L.HT_PRO_TANH_BWD,
+                                 pro_a=self.pooled))
+        else:
+            L.tanh_bwd(self.pooled, self.dpooled, self.dpre)
+            self._sg(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, ksplit=4)
         L.layernorm_bwd_dx(self._pool_src, self.cls_st, self.lnf_g, nb, H, dy_f32=self.dcls_ln,
                            x_stride=self._pool_stride, out_f32=self.dcls)
         cur, oth = self.dh
@@ -750,10 +783,22 @@ class ViltDatEngine:
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.use_layer_calls, self.fp8,
-               self.fp8_ffn_chain)        # host-side switches that change the launch list are part of the signature
+               self.fp8_ffn_chain, self.fused_tail)        # host-side switches that change the launch list are part of the signature
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig
+
+    def _adamw_group(self, grp: FlatGroup, d_sched: int = 0, d_adam: int = 0):
+        return L.adamw_group(grp.p, grp.g, grp.m, grp.v, grp.seg_off, self._wd_vec(grp), grp.state, d_sched, d_adam)
+
+    def _adamw_many(self, groups):
+        L.adamw_multi(groups, self.lr, self.sched["warmup"], self.sched["total"], 0.9, 0.98, self.eps)
+
+    def _loss(self, logits, teacher, slot):
+        if self.fused_tail:
+            L.dat_loss_fwd_bwd_single(logits, teacher, self.inp["target"], self.dlogits, self.loss_buf[slot])
+        else:
+            L.dat_loss_fwd_bwd(logits, teacher, self.inp["target"], self.dlogits, self.loss_buf[slot])
 
     def _step_kernels(self):
         B, task = self.B, self.task
@@ -765,16 +810,30 @@ class ViltDatEngine:
         # same head weights for both -> one 2B-row pass over [pooled_g; pooled_s]
         logits_both = self._head_fwd(self.pooled[:2 * B], "both", task)
         logits_all, logits_1 = logits_both[:B], logits_both[B:]
-        L.dat_loss_fwd_bwd(logits_1, logits_all, self.inp["target"], self.dlogits, self.loss_buf["p1"])
+        self._loss(logits_1, logits_all, "p1")
         self._head_bwd(pooled_s, "p1", task, self.dpooled[B:])
-        self._adamw(hp)
-        L.step_tick(hp.state, 1, 1)
+        if self.fused_tail:
+            self._adamw_many([self._adamw_group(hp)])       # sub-step 2b; its counters are ticked once, at the end of the step
+        else:
+            self._adamw(hp)
+            L.step_tick(hp.state, 1, 1)
         # P2: gated pass again -- same pooled features, UPDATED head, KL to logits_1     task_trainer.py:311-328
         logits_0 = self._head_fwd(pooled_g, "p2", task)
-        L.dat_loss_fwd_bwd(logits_0, logits_1, self.inp["target"], self.dlogits, self.loss_buf["p2"])
+        self._loss(logits_0, logits_1, "p2")
         self._head_bwd(pooled_g, "p2", task, self.dpooled[:B])
         # one backward for both passes, then the deferred adapter_1 step (lr index 2b) and the P2 steps (2b+1)
         self._backward_dual()
+        if self.fused_tail:
+            # adapter_1 (2b), head (2b + 1: reads its counters one ahead), adapter_0 (2b + 1) in ONE launch, then the bf16
+            # operand copies, then ONE tick for all counters
+            groups = ([self._adamw_group(self.ad[1])] if 1 in self.opt_adapters else []) + [self._adamw_group(hp, 1, 1)] + \
+                ([self._adamw_group(self.ad[0])] if 0 in self.opt_adapters else [])
+            self._adamw_many(groups)
+            for a in (1, 0):
+                if a in self.opt_adapters:
+                    self.repack_adapter(a)
+            L.step_tick_multi([hp.state, self.ad[1].state, self.ad[0].state], [2, 2, 2], [2, 1, 1])
+            return
         if 1 in self.opt_adapters:
             self._adamw(self.ad[1])
             self.repack_adapter(1)

@@ -47,6 +47,22 @@ class ViltLayerGrads(C.Structure):
     _fields_ = [(n, vp) for n in ("dh_out", "dh_in", "dh3", "dh16", "dU", "dx16", "dctx", "dqkv", "z", "dz")]
 
 
+class HtJob(C.Structure):            # feddat_ht_job
+    _fields_ = [("A", vp), ("sa_i", i64), ("sa_k", i64), ("B", vp), ("sb_k", i64), ("sb_j", i64), ("I", i32), ("J", i32),
+                ("K", i32), ("mode", i32), ("alpha", f32), ("bias_j", vp), ("out", vp), ("ldo", i64), ("colsum", vp),
+                ("pro", i32), ("pro_a", vp), ("pro_b", vp), ("pro_eps", f32), ("stats_out", vp), ("epi", i32), ("aux", vp),
+                ("ld_aux", i64)]
+
+
+class AdamwGroup(C.Structure):       # feddat_adamw_group
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("seg_off", vp), ("seg_wd", vp), ("nseg", i32),
+                ("state", vp), ("d_sched", i32), ("d_adam", i32)]
+
+
+HT_PRO_NONE, HT_PRO_LN, HT_PRO_TANH_BWD = 0, 1, 2
+HT_EPI_NONE, HT_EPI_TANH, HT_EPI_MUL_DGELU = 0, 1, 2
+
+
 def _fill(struct, **tensors):
     """ctypes struct of device pointers from tensors (None -> NULL); keeps the tensors alive on the struct."""
     s = struct()
@@ -107,6 +123,12 @@ _SIGS = {
     "feddat_sgemm_f32": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, i64, vp],
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
+    "feddat_dat_loss_fwd_bwd_single": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
+    "feddat_head_gemm": [C.POINTER(HtJob), i32, vp],
+    "feddat_head_ln_gelu": [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp],
+    "feddat_head_ln_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
+    "feddat_adamw_multi": [C.POINTER(AdamwGroup), i32, f32, i32, i32, f32, f32, f32, vp],
+    "feddat_step_tick_multi": [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, vp],
     "feddat_vqa_score_accumulate": [vp, vp, i32, i32, vp, vp],
     "feddat_lm_loss_fwd_bwd": [vp, vp, i64, vp, vp, i32, i32, f32, f32, vp, i64, vp, vp],
     "feddat_axpby3": [vp, f32, vp, f32, vp, f32, vp, vp, i64, vp],
@@ -536,6 +558,71 @@ def dat_loss_fwd_bwd(logits, teacher, target, dlogits, scalars, temp=3.0):
     assert scalars.numel() >= 4 + 2 * B
     _chk(load().feddat_dat_loss_fwd_bwd(_p(logits), _p(teacher), _p(target), B, Cn, temp, _p(dlogits), _p(scalars),
                                         _stream()), "feddat_dat_loss_fwd_bwd")
+
+
+def ht_job(A, sa_i, sa_k, B, sb_k, sb_j, I, J, K, out, ldo=None, mode=0, alpha=1.0, bias_j=None, colsum=None, pro=HT_PRO_NONE,
+           pro_a=None, pro_b=None, pro_eps=0.0, stats_out=None, epi=HT_EPI_NONE, aux=None, ld_aux=0) -> HtJob:
+    """One product of feddat_head_gemm (include/feddat_hip.h: feddat_ht_job); keeps its tensors alive."""
+    _dev(A, B, out)
+    j = HtJob()
+    j._keep = (A, B, out, bias_j, colsum, pro_a, pro_b, stats_out, aux)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    j.A, j.sa_i, j.sa_k, j.B, j.sb_k, j.sb_j = ptr(A), sa_i, sa_k, ptr(B), sb_k, sb_j
+    j.I, j.J, j.K, j.mode, j.alpha = I, J, K, mode, alpha
+    j.bias_j, j.out, j.ldo, j.colsum = ptr(bias_j), ptr(out), (J if ldo is None else ldo), ptr(colsum)
+    j.pro, j.pro_a, j.pro_b, j.pro_eps, j.stats_out = pro, ptr(pro_a), ptr(pro_b), pro_eps, ptr(stats_out)
+    j.epi, j.aux, j.ld_aux = epi, ptr(aux), ld_aux
+    return j
+
+
+def head_gemm(*jobs: HtJob):
+    """One launch for one or two independent small fp32 products (feddat_head_gemm)."""
+    arr = (HtJob * len(jobs))(*jobs)
+    arr._keep = jobs
+    _chk(load().feddat_head_gemm(arr, len(jobs), _stream()), "feddat_head_gemm")
+
+
+def head_ln_gelu(x, gamma, beta, eps, y, stats, gelu_out):
+    _dev(x, y, stats, gelu_out)
+    _chk(load().feddat_head_ln_gelu(_p(x), _p(gamma), _p(beta), eps, x.shape[0], x.shape[1], _p(y), _p(stats), _p(gelu_out),
+                                    _stream()), "feddat_head_ln_gelu")
+
+
+def head_ln_bwd_full(dy, x, stats, gamma, dx, dgamma, dbeta):
+    _dev(dy, x, stats, dx)
+    _chk(load().feddat_head_ln_bwd_full(_p(dy), _p(x), _p(stats), _p(gamma), x.shape[0], x.shape[1], _p(dx), _p(dgamma),
+                                        _p(dbeta), _stream()), "feddat_head_ln_bwd_full")
+
+
+def dat_loss_fwd_bwd_single(logits, teacher, target, dlogits, scalars, temp=3.0):
+    _dev(logits, teacher, target)
+    B, Cn = logits.shape
+    assert scalars.numel() >= 4
+    _chk(load().feddat_dat_loss_fwd_bwd_single(_p(logits), _p(teacher), _p(target), B, Cn, temp, _p(dlogits), _p(scalars),
+                                               _stream()), "feddat_dat_loss_fwd_bwd_single")
+
+
+def adamw_group(p, g, m, v, seg_off, seg_wd, state, d_sched=0, d_adam=0) -> AdamwGroup:
+    _dev(p, g, m, v, seg_off, seg_wd, state)
+    G = AdamwGroup()
+    G._keep = (p, g, m, v, seg_off, seg_wd, state)
+    G.p, G.g, G.m, G.v, G.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+    G.seg_off, G.seg_wd, G.nseg, G.state, G.d_sched, G.d_adam = (seg_off.data_ptr(), seg_wd.data_ptr(), seg_wd.numel(),
+                                                                   state.data_ptr(), d_sched, d_adam)
+    return G
+
+
+def adamw_multi(groups, lr, warmup, total, beta1, beta2, eps):
+    arr = (AdamwGroup * len(groups))(*groups)
+    arr._keep = groups
+    _chk(load().feddat_adamw_multi(arr, len(groups), lr, warmup, total, beta1, beta2, eps, _stream()), "feddat_adamw_multi")
+
+
+def step_tick_multi(states, d_sched, d_adam):
+    n = len(states)
+    _dev(*states)
+    sp = (vp * n)(*[s.data_ptr() for s in states])
+    _chk(load().feddat_step_tick_multi(sp, (i32 * n)(*d_sched), (i32 * n)(*d_adam), n, _stream()), "feddat_step_tick_multi")
 
 
 def vqa_score_accumulate(logits, target, acc):

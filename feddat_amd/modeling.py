@@ -175,16 +175,27 @@ class Adaptered_ViltOutput:
 class ViltContinualLearner:
     """vilt.py:154-382 for the classification / single-image path, on the HIP engine.
 
-    forward(task_key, images, texts) -> (pooled, logits): `images` carries the pre-built HF ViLT encodings dict
-    (pixel_values, pixel_mask, input_ids, attention_mask, token_type_ids) -- the host image processor / tokenizer
-    are out of scope, exactly as in the golden harness."""
+    forward(task_key, images, texts) -> (pooled, logits) takes the reference's batch schema: `images` = list of decoded
+    RGB images ([H, W, 3] uint8 arrays / tensors, or PIL images), `texts` = list of questions (vilt.py:244-264); they go
+    through process_inputs -- the device image processor + device WordPiece tokenizer, ONCE per batch (the reference runs
+    its host processor inside every one of the three forward passes of a train_step).  A ready-made HF ViLT encodings
+    dict (pixel_values, pixel_mask, input_ids, attention_mask, token_type_ids) in `images` with texts=None is taken as is
+    (the golden harness and the synthetic benchmarks feed tensors).
+
+    vocab: path of the BERT vocab.txt (the reference loads ./models/bert-base-uncased, vilt.py:47-48) or the token list."""
+
+    BERT_LOCAL_PATH = "./models/bert-base-uncased"       # vilt.py:47
 
     def __init__(self, ordered_cl_tasks: List[str], params: Dict[str, torch.Tensor], device, batch_size: int,
-                 image_size: int = 384, num_layers: int = 12, lr: float = 1e-4):
+                 image_size: int = 384, num_layers: int = 12, lr: float = 1e-4, vocab=None):
         self.ordered_cl_tasks = list(ordered_cl_tasks)
         self.device = torch.device(device)
         self.engine = ViltDatEngine(params, self.ordered_cl_tasks, self.device, batch=batch_size, res=image_size,
                                     layers=num_layers, lr=lr)
+        self.max_text_length = self.engine.Lt               # vilt.py:50: config.max_position_embeddings = 40
+        self._vocab = vocab
+        self._tokenizer = None
+        self._image_processor = None
         self.gating = False
         self.active = "adapter_1"
         # requires_grad flags per adapter, toggled exactly like adapter.py:66-95; prepare_model's initial state
@@ -225,8 +236,49 @@ class ViltContinualLearner:
         for a in range(3):
             self.engine.repack_adapter(a)
 
+    # ---- the reference's batch schema (vilt.py:87-100): images + questions -> HF ViLT encodings, on the device ----
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            import os
+            from .tokenization import WordPieceTokenizer
+            vocab = self._vocab
+            if vocab is None:
+                vocab = os.path.join(self.BERT_LOCAL_PATH, "vocab.txt")
+                if not os.path.exists(vocab):
+                    raise L.FeddatHipError(
+                        f"texts were given but there is no BERT vocabulary: pass vocab=<vocab.txt path or token list> to "
+                        f"ViltContinualLearner, or place bert-base-uncased at {self.BERT_LOCAL_PATH} as the reference does")
+            self._tokenizer = WordPieceTokenizer(vocab, self.device)
+        return self._tokenizer
+
+    @property
+    def image_processor(self):
+        if self._image_processor is None:
+            from .image_processing import ViltImageProcessor
+            # every batch is padded to the engine's static frame; patches outside an image's valid rectangle are masked keys
+            self._image_processor = ViltImageProcessor(self.device, pad_to=self.engine.res)
+        return self._image_processor
+
+    def process_inputs(self, images: List, texts: List[str]) -> Dict[str, torch.Tensor]:
+        """ViltEncoderWrapper.process_inputs (vilt.py:87-100): ViltProcessor(images, text, max_length=40, padding=True,
+        truncation=True) -> {pixel_values, pixel_mask, input_ids, attention_mask, token_type_ids}, as device tensors in the
+        engine's static frame: images resized by the ViLT rule (shorter edge 384, longer <= 640, multiples of 32) and
+        zero-padded to the frame with their pixel_mask, questions padded to max_text_length with attention_mask 0 -- the
+        pooled feature does not depend on how far a batch is padded (masked keys; golden G6)."""
+        import numpy as np
+        arrs = [np.asarray(im.convert("RGB")) if hasattr(im, "convert") else im for im in images]
+        if len(arrs) != len(texts):
+            raise L.FeddatHipError(f"{len(arrs)} images but {len(texts)} texts")
+        enc = dict(self.image_processor(arrs))
+        tok = self.tokenizer(list(texts), padding="max_length", truncation=True, max_length=self.max_text_length)
+        enc.update(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"], token_type_ids=tok["token_type_ids"])
+        return enc
+
     def forward(self, task_key: str, images, texts=None):
         mode = "gating" if self.gating else self.active
+        if not isinstance(images, dict):
+            images = self.process_inputs(images, texts)
         return self.engine.forward(images, mode, task_key)
 
     __call__ = forward
@@ -234,6 +286,12 @@ class ViltContinualLearner:
 
 def create_vilt_continual_learner_model(params: Dict[str, torch.Tensor], ordered_cl_tasks: List[str], device,
                                         batch_size: int, image_size: int = 384, num_layers: int = 12,
-                                        lr: float = 1e-4) -> ViltContinualLearner:
-    """vilt.py:421-452 (the pretrained checkpoint is passed in as a tensor dict: there is no hub access here)."""
-    return ViltContinualLearner(ordered_cl_tasks, params, device, batch_size, image_size, num_layers, lr)
+                                        lr: float = 1e-4, vocab=None) -> ViltContinualLearner:
+    """vilt.py:421-452 (the pretrained checkpoint is passed in as a tensor dict: feddat_amd.weights.load_vilt_pretrained
+    reads it from a local HF directory; there is no hub access here)."""
+    return ViltContinualLearner(ordered_cl_tasks, params, device, batch_size, image_size, num_layers, lr, vocab=vocab)
+
+
+def convert_batch_to_vilt_input_dict(batch: Dict):
+    """vilt.py:455-459: what batch_collate yields -> the arguments of ViltContinualLearner.forward / process_inputs."""
+    return {"images": batch["images"], "texts": batch["raw_texts"]}

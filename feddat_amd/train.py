@@ -24,7 +24,7 @@ import torch
 from . import lib as L
 from . import vilt_spec
 from .fedavg import all_reduce_sum, allreduce_average, get_average_net  # noqa: F401  (re-exported: main.py:50)
-from .modeling import ViltContinualLearner, create_vilt_continual_learner_model
+from .modeling import ViltContinualLearner, convert_batch_to_vilt_input_dict, create_vilt_continual_learner_model
 
 
 class OptimizerHandle:
@@ -83,6 +83,19 @@ class TaskTrainer:
         self.max_steps = len(train_batches) * self.num_epochs          # train_vqa_crossvqa.py:238
         self.logger = logger or logging.getLogger("feddat_amd")
         self.use_graph = getattr(args, "hip_graph", True)
+        self.batch2inputs_converter = convert_batch_to_vilt_input_dict     # train_vqa_crossvqa.py:70
+
+    def encode_batch(self, model: ViltContinualLearner, batch: Dict) -> Dict[str, torch.Tensor]:
+        """The reference's batches are {"images": [PIL / uint8 arrays], "raw_texts": [str], "target_scores": [B, C]}
+        (vqa_dataset_crossvqa.py:377-422); the processor + tokenizer run here ONCE per batch on the device
+        (task_trainer.py:281,285,293,313 call them inside each of the three forward passes).  Batches that already carry the
+        encodings (synthetic benchmarks, the golden harness) pass through."""
+        if "pixel_values" in batch:
+            return batch
+        enc = model.process_inputs(**self.batch2inputs_converter(batch))
+        tgt = batch["target_scores"]
+        enc["target_scores"] = tgt.to(model.device, torch.float32, non_blocking=True).contiguous()
+        return enc
 
     def create_optimizer(self, model: ViltContinualLearner, mode: str = "dat") -> OptimizerHandle:
         return OptimizerHandle(model.optimizer_adapters(), self.lr, self.adam_epsilon, self.weight_decay)
@@ -103,7 +116,10 @@ class TaskTrainer:
             eng.ensure_captured()      # before the upload worker below starts: capture never overlaps a prefetch
         loss = None
         dev = model.device
-        upload = lambda b: {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+
+        def upload(b):      # raw batches (images + questions): processor + tokenizer run here, on the prefetch stream
+            b = self.encode_batch(model, b)
+            return {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
         for epoch in range(self.local_epochs):
             # host batches cross PCIe on a side stream while the previous step computes (device batches pass through)
             loader = self.vqa_train_dataloader
@@ -121,7 +137,7 @@ class TaskTrainer:
         """One DAT + MKD step; returns loss_0 (BCE * num_labels of the P2 pass) as a 0-d device tensor.  The mode
         switches the reference performs inside (activate_gating / set_active_adapter, task_trainer.py:284-312)
         leave the model in the same final state: gating on, adapter_0 active."""
-        out = model.engine.train_step(batch, use_graph=self.use_graph)
+        out = model.engine.train_step(self.encode_batch(model, batch), use_graph=self.use_graph)
         model.activate_gating()
         model.set_active_adapter("adapter_0")
         return out[0]
@@ -132,6 +148,7 @@ class TaskTrainer:
         the device (feddat_vqa_score_accumulate); ONE read-back per loader."""
         acc = torch.zeros(2, device=model.device)
         for batch in loader:
+            batch = self.encode_batch(model, batch)
             _, logits = model(task_key=self.task_key, images=batch, texts=None)
             tgt = batch["target_scores"].to(logits.device, torch.float32, non_blocking=True).contiguous()
             L.vqa_score_accumulate(logits, tgt, acc)

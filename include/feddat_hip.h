@@ -30,7 +30,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_ELAUNCH 2
 #define FEDDAT_ETIMEOUT 3   /* feddat_comm_create_timeout only */
 
-#define FEDDAT_ABI_VERSION 6   /* 6: feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
+#define FEDDAT_ABI_VERSION 6   /* 6: fused step tail (feddat_head_gemm, feddat_head_ln_gelu, feddat_head_ln_bwd_full, feddat_dat_loss_fwd_bwd_single, feddat_adamw_multi, feddat_step_tick_multi), feddat_vqa_score_accumulate, feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -343,6 +343,64 @@ int feddat_sgemm_f32(const float* A, long sa_i, long sa_k, const float* B, long 
                      float* colsum, long colsum_split_stride, hipStream_t stream);
 /* out[i] = sum_s in[s*stride + i], i < n   (deterministic reduction of split-K partials). */
 int feddat_reduce_partials(const float* in, long stride, int nsplit, long n, float* out, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The serial tail of a train_step, fused (csrc/head_tail.hip): token-0 LayerNorm + ViltPooler (HF ViltModel.layernorm /
+ * ViltPooler via vilt.py:127), the task head (vilt.py:202-209) forward / backward for the P0 / P1 / P2 passes, and the
+ * optimizer bookkeeping of task_trainer.py:280-330,477-504.  All exact fp32.
+ *
+ * feddat_head_gemm: one or two INDEPENDENT small products in ONE launch, each
+ *     out[i, j] = epi( alpha * sum_k pro(A)[i, k] * B[k, j] + bias_j[j] ),   colsum[i] = alpha * sum_k pro(A)[i, k]
+ * with arbitrary element strides (A[i, k] at A + i sa_i + k sa_k, B[k, j] at B + k sb_k + j sb_j), fp32 MFMA, the K
+ * range split over the 16 waves of a block and summed in wave order (mode 0: no split-K partials in HBM), or -- mode 1,
+ * for contractions over the batch (K ~ 32) -- the waves on consecutive 64-column groups.  Prologues on A: LN = LayerNorm
+ * of row i over k with gamma = pro_a, beta = pro_b, eps (sa_k must make rows contiguous enough to re-read; statistics
+ * {mean, rstd} computed in the block, optionally written to stats_out [I, 2]); TANH_BWD = A[i, k] * (1 - y^2), y = pro_a
+ * indexed like A.  Epilogues: TANH; MUL_DGELU = times gelu'(aux[i, j]) (erf GELU).
+ * ------------------------------------------------------------------------------------------- */
+#define FEDDAT_HT_PRO_NONE 0
+#define FEDDAT_HT_PRO_LN 1
+#define FEDDAT_HT_PRO_TANH_BWD 2
+#define FEDDAT_HT_EPI_NONE 0
+#define FEDDAT_HT_EPI_TANH 1
+#define FEDDAT_HT_EPI_MUL_DGELU 2
+typedef struct feddat_ht_job {
+    const float* A; long sa_i, sa_k;
+    const float* B; long sb_k, sb_j;
+    int I, J, K, mode;
+    float alpha;
+    const float* bias_j;       /* [J] or NULL */
+    float* out; long ldo;
+    float* colsum;             /* [I] or NULL */
+    int pro;
+    const float* pro_a; const float* pro_b; float pro_eps;
+    float* stats_out;
+    int epi;
+    const float* aux; long ld_aux;
+} feddat_ht_job;
+int feddat_head_gemm(const feddat_ht_job* jobs, int njobs, hipStream_t stream);
+/* y = LayerNorm(x) (stats [rows, 2] = {mean, rstd}), gelu_out = gelu(y): clf_norm0 + clf_actv0 (vilt.py:205-206) */
+int feddat_head_ln_gelu(const float* x, const float* gamma, const float* beta, float eps, int rows, int H, float* y,
+                        float* stats, float* gelu_out, hipStream_t stream);
+/* full LayerNorm backward with trainable affine (dx, dgamma, dbeta) in one launch; rows <= 4096, H <= 2048 */
+int feddat_head_ln_bwd_full(const float* dy, const float* x, const float* stats, const float* gamma, int rows, int H,
+                            float* dx, float* dgamma, float* dbeta, hipStream_t stream);
+/* feddat_dat_loss_fwd_bwd (below) as ONE launch; bit-identical outputs; scalars needs only 4 floats */
+int feddat_dat_loss_fwd_bwd_single(const float* logits, const float* teacher, const float* target, int B, int C, float temp,
+                                   float* dlogits, float* scalars, hipStream_t stream);
+/* feddat_adamw_flat for up to FEDDAT_ADAMW_MAX_GROUPS parameter groups in one launch (n % 4 == 0, 16-byte aligned
+ * buffers).  A group reads its schedule index / Adam step count at (state[0] + d_sched, state[1] + d_adam), so two
+ * updates of one group inside a step (the task head: sub-steps 2b and 2b + 1) need no counter tick between them.
+ * feddat_step_tick_multi: state[k][0] += d_sched[k], state[k][1] += d_adam[k] for up to that many counters, one launch. */
+#define FEDDAT_ADAMW_MAX_GROUPS 4
+typedef struct feddat_adamw_group {
+    float* p; const float* g; float* m; float* v; long n;
+    const long* seg_off; const float* seg_wd; int nseg;
+    const int* state; int d_sched, d_adam;
+} feddat_adamw_group;
+int feddat_adamw_multi(const feddat_adamw_group* groups, int ngroups, float base_lr, int warmup, int total, float beta1,
+                       float beta2, float eps, hipStream_t stream);
+int feddat_step_tick_multi(int* const* states, const int* d_sched, const int* d_adam, int n, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  loss.  L = (BCEWithLogits_mean(logits,target) * C + 9 * KL_batchmean(log_softmax(logits/3) ||

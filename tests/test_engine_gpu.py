@@ -272,6 +272,34 @@ def test_composite_layer_calls_equal_the_op_by_op_sequence(eng_mod):
         assert torch.equal(finals[0][k], finals[1][k]), k
 
 
+def test_fused_tail_equals_the_single_purpose_launches(eng_mod):
+    """The fused serial tail (csrc/head_tail.hip: 20 launches) against the round-3 sequence of 46 single-purpose launches:
+    same arithmetic up to fp32 summation order in the small products -- losses to 1e-6 relative, every trainable tensor to
+    2e-6 after three steps (eager and hipGraph replay), counters identical."""
+    d = O.ViltDims(layers=3)
+    finals, losses, states = [], [], []
+    for fused, graph in ((True, False), (False, False), (True, True)):
+        P = O.make_params(d, ["art"], bias_std=0.02)
+        eng = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=5, res=224, layers=3)
+        eng.fused_tail = fused
+        eng.begin_local_update("art", steps_per_epoch=3)
+        ls = []
+        for s in range(3):
+            out = eng.train_step(_to_dev(O.synthetic_batch(5, 224, 700 + s)), use_graph=graph)
+            ls.append([float(out[0]), float(out[2]), float(eng.loss_buf["p1"][2])])
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in eng.state_dict().items()})
+        losses.append(np.array(ls))
+        states.append([g.state.tolist() for g in (eng.ad[0], eng.ad[1], eng.head["art"])])
+    assert states[0] == states[1] == states[2] == [[7, 3], [6, 3], [6, 6]]
+    assert np.abs(losses[0] - losses[1]).max() < 1e-6 * np.abs(losses[1]).max() and np.array_equal(losses[0], losses[2])
+    for k in finals[0]:
+        assert float((finals[0][k] - finals[1][k]).abs().max()) < 2e-6, k
+        assert torch.equal(finals[0][k], finals[2][k]), k
+    assert float((finals[0]["task_layer.art.clf_fc1.weight"] - O.make_params(d, ["art"], bias_std=0.02)[
+        "task_layer.art.clf_fc1.weight"].to(DEV)).abs().max()) > 1e-5
+
+
 def test_fp8_forward_config4_stated_tolerances(eng_mod):
     """BASELINE.json configs[4]: e4m3 MFMA for the forward QKV / FFN1 products and the dX products FFN2^T / attention-output^T
     of the frozen backbone (per-row activation / gradient scales, per-channel weight scales), bf16 adapters.  e4m3 has 3 mantissa bits: the stated tolerances are LOOSER than the

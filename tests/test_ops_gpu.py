@@ -490,6 +490,115 @@ def test_sgemm_f32(L, I, J, K, ksplit):
     assert (out2.double() - A.double() @ Bm.double()).abs().max() < 2e-5 * math.sqrt(K) * 4
 
 
+# ------------------------------------------------------------------ fused step tail (csrc/head_tail.hip)
+def test_head_gemm_prologues_epilogues_and_two_jobs(L):
+    """feddat_head_gemm against fp64: plain / bias, LayerNorm prologue on strided rows (+ stats), tanh epilogue, tanh'
+    prologue, gelu' epilogue, the batch-contraction mode with its column sum, ragged sizes, and two jobs in one launch."""
+    g = torch.Generator().manual_seed(17)
+    H, nb, S = 768, 64, 5
+    hl = torch.randn(nb, S * H, generator=g).to(DEV)                    # token-0 rows at stride S * H
+    gam, bet = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV), (0.1 * torch.randn(H, generator=g)).to(DEV)
+    W = (torch.randn(H, H, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(H, generator=g).to(DEV)
+    pooled, st = torch.empty(nb, H, device=DEV), torch.empty(nb, 2, device=DEV)
+    L.head_gemm(L.ht_job(hl, S * H, 1, W, 1, H, nb, H, H, pooled, bias_j=bias, pro=L.HT_PRO_LN, pro_a=gam, pro_b=bet,
+                         pro_eps=1e-12, stats_out=st, epi=L.HT_EPI_TANH))
+    x = hl[:, :H].double()
+    ln = F.layer_norm(x, (H,), gam.double(), bet.double(), 1e-12)
+    ref = torch.tanh(ln @ W.double().t() + bias.double())
+    assert (pooled.double() - ref).abs().max() < 2e-5
+    assert (st[:, 0].double() - x.mean(1)).abs().max() < 1e-6
+    assert (st[:, 1].double() - 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-12)).abs().max() < 1e-4
+    # backward through the pooler: (dpooled * (1 - pooled^2)) W
+    dp = torch.randn(nb, H, generator=g).to(DEV)
+    dcls = torch.empty(nb, H, device=DEV)
+    L.head_gemm(L.ht_job(dp, H, 1, W, H, 1, nb, H, H, dcls, pro=L.HT_PRO_TANH_BWD, pro_a=pooled))
+    assert (dcls.double() - (dp.double() * (1 - pooled.double() ** 2)) @ W.double()).abs().max() < 2e-5
+    # two jobs in one launch, the head backward's first pair: dW_fc1 = dl^T g0 (+ db) | dn0 = (dl W1) * gelu'(n0); ragged B, C
+    for B, C, H2 in ((32, 100, 1536), (7, 37, 200)):
+        dl = torch.randn(B, C, generator=g).to(DEV)
+        g0, n0 = torch.randn(B, H2, generator=g).to(DEV), torch.randn(B, H2, generator=g).to(DEV)
+        W1 = (torch.randn(C, H2, generator=g) * 0.05).to(DEV)
+        dW, db = torch.full((C, H2), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV)
+        dn0 = torch.full((B, H2), float("nan"), device=DEV)
+        L.head_gemm(L.ht_job(dl, 1, C, g0, H2, 1, C, H2, B, dW, mode=1, colsum=db),
+                    L.ht_job(dl, C, 1, W1, H2, 1, B, H2, C, dn0, epi=L.HT_EPI_MUL_DGELU, aux=n0, ld_aux=H2))
+        n0d = n0.double()
+        gp = 0.5 * (1 + torch.erf(n0d / math.sqrt(2))) + n0d * torch.exp(-0.5 * n0d ** 2) / math.sqrt(2 * math.pi)
+        assert (dW.double() - dl.double().t() @ g0.double()).abs().max() < 2e-5
+        assert (db.double() - dl.double().sum(0)).abs().max() < 2e-5
+        assert (dn0.double() - (dl.double() @ W1.double()) * gp).abs().max() < 2e-5
+    with pytest.raises(L.FeddatHipError):
+        L.head_gemm(L.ht_job(dp, H, 1, W, H, 1, nb, H, H, dcls, pro=L.HT_PRO_LN))        # LN without gamma / beta
+
+
+def test_head_layernorm_gelu_and_full_backward(L):
+    g = torch.Generator().manual_seed(19)
+    for rows, H in ((64, 1536), (5, 100)):
+        x = torch.randn(rows, H, generator=g)
+        gam, bet = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+        dy = torch.randn(rows, H, generator=g)
+        y, st, ge = torch.empty(rows, H, device=DEV), torch.empty(rows, 2, device=DEV), torch.empty(rows, H, device=DEV)
+        L.head_ln_gelu(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, y, st, ge)
+        xd = x.double().requires_grad_(True)
+        gd, bd = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+        yr = F.layer_norm(xd, (H,), gd, bd, 1e-5)
+        assert (y.cpu().double() - yr).abs().max() < 2e-6 and (ge.cpu().double() - F.gelu(yr)).abs().max() < 2e-6
+        yr.backward(dy.double())
+        dx, dg, db = torch.empty(rows, H, device=DEV), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+        L.head_ln_bwd_full(dy.to(DEV), x.to(DEV), st, gam.to(DEV), dx, dg, db)
+        assert (dx.cpu().double() - xd.grad).abs().max() < 1e-5
+        assert (dg.cpu().double() - gd.grad).abs().max() < 1e-5 and (db.cpu().double() - bd.grad).abs().max() < 1e-5
+        # ... and it is the two-launch form (feddat_layernorm_bwd_full) bit for bit on the affine gradients
+        dx2, dg2, db2 = torch.empty_like(dx), torch.empty_like(dg), torch.empty_like(db)
+        L.layernorm_bwd_full(dy.to(DEV), x.to(DEV), st, gam.to(DEV), rows, H, dx2, dg2, db2)
+        assert torch.equal(dg, dg2) and torch.equal(db, db2) and (dx - dx2).abs().max() < 1e-6
+
+
+def test_loss_single_launch_and_adamw_multi_are_bit_identical_with_the_separate_launches(L, golden_dir):
+    g = load(golden_dir, "g2_loss.npz")
+    lg, te, ta = (torch.from_numpy(g[k]).to(DEV) for k in ("logits", "teacher", "target"))
+    gen = torch.Generator().manual_seed(2)
+    for lgs, tes, tas in ((lg, te, ta), tuple(torch.randn(32, 100, generator=gen).to(DEV) for _ in range(3)),
+                          tuple(torch.randn(70, 33, generator=gen).to(DEV) for _ in range(3))):
+        B = lgs.shape[0]
+        dl1, dl2 = torch.empty_like(lgs), torch.empty_like(lgs)
+        sc1, sc2 = torch.zeros(4 + 2 * B, device=DEV), torch.zeros(4, device=DEV)
+        L.dat_loss_fwd_bwd(lgs, tes, tas, dl1, sc1)
+        L.dat_loss_fwd_bwd_single(lgs, tes, tas, dl2, sc2)
+        assert torch.equal(dl1, dl2) and torch.equal(sc1[:3], sc2[:3])
+    # three groups in one launch, the middle one reading its counters one ahead == separate launches with a tick between
+    sizes = (48 * 768 + 48, 1536 * 4, 768 * 48 + 768)
+    def mk():
+        gg = torch.Generator().manual_seed(9)
+        out = []
+        for n in sizes:
+            p, gr = (torch.randn(n, generator=gg) * 0.05).to(DEV), torch.randn(n, generator=gg).to(DEV)
+            m, v = (torch.randn(n, generator=gg) * 0.01).to(DEV), (torch.rand(n, generator=gg) * 0.01).to(DEV)
+            seg_off = torch.tensor([0, n // 2, n], dtype=torch.int64, device=DEV)
+            seg_wd = torch.tensor([0.01, 0.0], device=DEV)
+            out.append([p, gr, m, v, seg_off, seg_wd])
+        return out
+    A, Bg = mk(), mk()
+    states = [torch.tensor(s, dtype=torch.int32, device=DEV) for s in ([6, 3], [6, 6], [7, 3])]
+    states_b = [s.clone() for s in states]
+    L.adamw_multi([L.adamw_group(*A[0], states[0]), L.adamw_group(*A[1], states[1], 1, 1), L.adamw_group(*A[2], states[2])],
+                  1e-4, 5, 60, 0.9, 0.98, 1e-8)
+    L.step_tick_multi(states, [2, 2, 2], [1, 2, 1])
+    L.step_tick(states_b[1], 1, 1)
+    for k in range(3):
+        L.adamw_flat(Bg[k][0], Bg[k][1], Bg[k][2], Bg[k][3], Bg[k][4], Bg[k][5], states_b[k], 1e-4, 5, 60, 0.9, 0.98, 1e-8)
+    L.step_tick(states_b[0], 2, 1)
+    L.step_tick(states_b[1], 1, 1)
+    L.step_tick(states_b[2], 2, 1)
+    torch.cuda.synchronize()
+    for k in range(3):
+        for a, b in zip(A[k][:4], Bg[k][:4]):
+            assert torch.equal(a, b), k
+        assert torch.equal(states[k], states_b[k])
+    assert float((A[0][0] - mk()[0][0]).abs().max()) > 0
+
+
 # ------------------------------------------------------------------ K5 loss
 def test_loss_vs_reference_golden(L, golden_dir):
     g = load(golden_dir, "g2_loss.npz")
