@@ -428,6 +428,8 @@ def main():
     ap.add_argument("--albef-dropout", dest="albef_dropout", type=float, default=0.0,
                     help="--workload albef: BERT hidden / attention dropout inside train_step (reference recipe: 0.1; the "
                          "default 0 is the deterministic configuration SURVEY.md 8d quotes config 4 in)")
+    ap.add_argument("--unfused-tail", action="store_true",
+                    help="A/B switch: the round-3 serial tail (46 single-purpose launches) instead of csrc/head_tail.hip")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -475,6 +477,7 @@ def main():
     # identical frozen backbone + server adapter on every client (seed 0); heterogeneous data per client
     params = vilt_spec.random_init(12, tasks, seed=0, device="cpu")
     eng = engine.ViltDatEngine(params, [task], dev, batch=B, res=res, layers=12, fp8=args.fp8)
+    eng.fused_tail = not args.unfused_tail
     nb = 4
     batches = [vilt_spec.synthetic_batch(B, res, 1234 + 100 * rank + i, device=dev) for i in range(nb)]
     steps_per_epoch = max(args.steps + args.warmup, 40)

@@ -164,6 +164,72 @@ __global__ __launch_bounds__(256) void pos_resize_masked_kernel(const float* __r
     out[(size_t)b * gh * gw * H + i] = v;
 }
 
+// image_assemble_kernel + pos_resize_masked_kernel + key_mask_kernel in ONE launch (round 4): the per-sample resized position
+// grid is interpolated where it is consumed (same expressions in the same order: bit-identical hidden states) instead of
+// being written to a [B, np, H] buffer and read back (2 x 14 MB at configs[1]), and block (0, b) also writes sample b's
+// attention key mask.  pmask is the pixel mask sampled at the patch origins: [B, gh, gw].
+__global__ __launch_bounds__(256) void image_assemble_masked_kernel(const float* __restrict__ proj,
+                                                                    const float* __restrict__ cls,
+                                                                    const float* __restrict__ pos0,
+                                                                    const float* __restrict__ grid,
+                                                                    const long* __restrict__ pmask,
+                                                                    const long* __restrict__ amask,
+                                                                    const float* __restrict__ mod1, float* __restrict__ h,
+                                                                    uint8_t* __restrict__ key_mask, int B, int Lt, int gh,
+                                                                    int gw, int g, int S, int H, int nrep) {
+    const int np = gh * gw, nc = H >> 2;
+    const int b = blockIdx.y;
+    const long* pm = pmask + (size_t)b * np;
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int t_ = threadIdx.x;
+    if (t_ < gh && pm[(size_t)t_ * gw] != 0) atomicAdd(&cnt[0], 1);
+    if (t_ >= 64 && t_ - 64 < gw && pm[t_ - 64] != 0) atomicAdd(&cnt[1], 1);
+    __syncthreads();
+    const int vh = cnt[0], vw = cnt[1];
+    if (blockIdx.x == 0 && key_mask) {
+        for (int t = threadIdx.x; t < S; t += 256) {
+            uint8_t v = 1;
+            if (t < Lt) {
+                if (amask) v = amask[(size_t)b * Lt + t] != 0;
+            } else if (t > Lt) {
+                v = pm[t - Lt - 1] != 0;
+            }
+            for (int r = 0; r < nrep; ++r) key_mask[(size_t)(b + r * B) * S + t] = v;
+        }
+    }
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)(np + 1) * nc) return;
+    const int c = (int)(i % nc);
+    const int t = (int)(i / nc);
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(mod1 + c * 4);
+    f32x4 o;
+    if (t == 0) {
+        o = (*reinterpret_cast<const f32x4*>(cls + c * 4) + *reinterpret_cast<const f32x4*>(pos0 + c * 4)) + m4;
+    } else {
+        const int p = t - 1;
+        const int y = p / gw, x = p - y * gw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y < vh && x < vw) {
+            const float sy = vh > 1 ? ((float)(g - 1) / (float)(vh - 1)) * (float)y : 0.f;
+            const float sx = vw > 1 ? ((float)(g - 1) / (float)(vw - 1)) * (float)x : 0.f;
+            const int y0 = min((int)sy, g - 1), x0 = min((int)sx, g - 1);
+            const int y1 = min(y0 + 1, g - 1), x1 = min(x0 + 1, g - 1);
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(grid + ((size_t)y0 * g + x0) * H + c * 4);
+            const f32x4 v01 = *reinterpret_cast<const f32x4*>(grid + ((size_t)y0 * g + x1) * H + c * 4);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(grid + ((size_t)y1 * g + x0) * H + c * 4);
+            const f32x4 v11 = *reinterpret_cast<const f32x4*>(grid + ((size_t)y1 * g + x1) * H + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = (1.f - ly) * ((1.f - lx) * v00[e] + lx * v01[e]) + ly * ((1.f - lx) * v10[e] + lx * v11[e]);
+        }
+        o = (*reinterpret_cast<const f32x4*>(proj + ((size_t)b * np + p) * H + c * 4) + v) + m4;
+    }
+    *reinterpret_cast<f32x4*>(h + ((size_t)b * S + Lt + t) * H + c * 4) = o;
+}
+
 // attention key mask of the [text | CLS | patches] sequence, written nrep times (rows b + rep * B)
 __global__ __launch_bounds__(256) void key_mask_kernel(const long* __restrict__ amask, const long* __restrict__ pmask,
                                                        uint8_t* __restrict__ out, int B, int Lt, int Hi, int Wi, int P,
@@ -272,6 +338,20 @@ extern "C" int feddat_image_embed_assemble(const float* proj, const float* cls, 
     const long total = (long)B * (np + 1) * (H / 4);
     hipLaunchKernelGGL(image_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, proj, cls,
                        pos0, pos_img, modality1, h, B, Lt, np, S, H, pos_batch_stride);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_image_embed_assemble_masked(const float* proj, const float* cls, const float* pos0,
+                                                  const float* pos_grid, const long* patch_mask,
+                                                  const long* attention_mask, const float* modality1, float* h,
+                                                  uint8_t* key_mask, int B, int Lt, int gh, int gw, int g, int H, int nrep,
+                                                  hipStream_t stream) {
+    FD_CHECK_ARG(proj && cls && pos0 && pos_grid && patch_mask && modality1 && h && B > 0 && B <= 65535 && Lt >= 0);
+    FD_CHECK_ARG(gh > 0 && gw > 0 && gh <= 64 && gw <= 64 && g > 0 && H % 4 == 0 && nrep >= 1);
+    const int np = gh * gw, S = Lt + 1 + np;
+    const long per = (long)(np + 1) * (H / 4);
+    hipLaunchKernelGGL(image_assemble_masked_kernel, dim3((unsigned)((per + 255) / 256), B), dim3(256), 0, stream, proj, cls,
+                       pos0, pos_grid, patch_mask, attention_mask, modality1, h, key_mask, B, Lt, gh, gw, g, S, H, nrep);
     FD_LAUNCH_RET();
 }
 

@@ -3,7 +3,7 @@
 // passes, the DAT loss, and the AdamW / scheduler bookkeeping (src/train/visionlanguage_tasks/task_trainer.py:280-330,
 // 477-504).  All exact fp32, ~0.2 GFLOP in total: the cost is LAUNCHES (round 3: 48 kernels of 2-10 us behind each other, a
 // fifth of the step's graph nodes), so this file fuses what used to be separate kernels:
-//   * ht_gemm_kernel: the strided exact-fp32 MFMA product of sgemm_f32.hip with the K range split over the 16 waves of a
+//   * ht_gemm_kernel: the strided exact-fp32 MFMA product of sgemm_f32.hip with the K range split over the 8 waves of a
 //     block (no split-K partials in HBM, no reduce launch), an optional A-side prologue (LayerNorm of the rows with the
 //     statistics computed in the block; multiply by 1 - y^2 = tanh'), an optional epilogue (bias, tanh, multiply by
 //     gelu'(aux)), the column sum that gives a weight-gradient job its bias gradient, and up to TWO independent products
@@ -18,8 +18,8 @@
 namespace {
 
 constexpr int HT_JT = 4;       // 16-column tiles per wave sharing one A operand (block tile: 16 rows x 64 columns)
-constexpr int HT_NW = 16;      // waves per block
-constexpr int HT_U = 4;        // k-steps (of 4) whose loads are in flight together
+constexpr int HT_NW = 8;       // waves per block
+constexpr int HT_U = 3;        // 16-deep k-chunks whose loads are in flight together per wave
 
 struct HtJob {
     const float* A; long sa_i, sa_k;
@@ -39,20 +39,83 @@ struct HtJob {
     int epi;                   // FEDDAT_HT_EPI_*
     const float* aux; long ld_aux;
     int itiles, jblocks;       // grid decomposition of this job
+    int avec, bvec;            // operand contiguous along k and 16-byte aligned: float4 loads
+    int jt;                    // 16-column tiles per wave (1 or HT_JT)
 };
 struct HtLaunch {
     HtJob job[2];
     int blocks0;               // blocks [0, blocks0) run job 0, the rest job 1
 };
 
-__global__ __launch_bounds__(HT_NW * 64) void ht_gemm_kernel(const HtLaunch L) {
-    extern __shared__ __attribute__((aligned(16))) float ht_smem[];
+// Main loop of one wave: k runs in chunks of 16; inside a chunk, MFMA step e (0..3) gives lane group g the index
+// k = chunk + 4 g + e -- for BOTH operands, which is all the instruction needs (its four k slots are summed).  An operand
+// that is contiguous along k is therefore fetched as ONE 16-byte load per lane and chunk (AV / BV; a product whose B is
+// [J, K] row-major used to issue 16 separate 64-byte segments per dword load and was bound by the CU's address path, not by
+// bytes: 44 us for the 64 x 1536 x 768 fc0 product); the other layout (contiguous along i / j) keeps dword loads, which
+// are 64-byte runs per lane group there.
+template <bool AV, bool BV, int JT>
+__device__ __forceinline__ void ht_mainloop(const HtJob& p, const float* ap, const float* yp, const float* const (&bp)[JT],
+                                            const bool iv, const bool (&jv)[JT], const int g, const float mean,
+                                            const float rstd, const int c_first, const int c_step, f32x4 (&acc)[JT],
+                                            float& asum) {
+    const int nchunk = (p.K + 15) >> 4;
+    for (int c0 = c_first; c0 < nchunk; c0 += c_step * HT_U) {
+        f32x4 a[HT_U], y[HT_U], ga[HT_U], be[HT_U], b[HT_U][JT];
+#pragma unroll
+        for (int u = 0; u < HT_U; ++u) {
+            const int k0 = (c0 + c_step * u) * 16 + 4 * g;           // this lane's four k of the chunk: k0 .. k0 + 3
+            const bool in = k0 < p.K;                                // (K % 4 == 0 where a vector load is used)
+            const int kc = in ? k0 : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ke = min(k0 + e, p.K - 1);
+                if (!AV) a[u][e] = ap[(size_t)ke * p.sa_k];
+                if (!AV && p.pro == FEDDAT_HT_PRO_TANH_BWD) y[u][e] = yp[(size_t)ke * p.sa_k];
+            }
+            if (AV) {
+                a[u] = *reinterpret_cast<const f32x4*>(ap + kc);
+                if (p.pro == FEDDAT_HT_PRO_TANH_BWD) y[u] = *reinterpret_cast<const f32x4*>(yp + kc);
+            }
+            if (p.pro == FEDDAT_HT_PRO_LN) {                         // (LN implies AV: checked on the host)
+                ga[u] = *reinterpret_cast<const f32x4*>(p.pro_a + kc);
+                be[u] = *reinterpret_cast<const f32x4*>(p.pro_b + kc);
+            }
+#pragma unroll
+            for (int t = 0; t < JT; ++t) {
+                if (BV) {
+                    b[u][t] = *reinterpret_cast<const f32x4*>(bp[t] + kc);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[u][t][e] = bp[t][(size_t)min(k0 + e, p.K - 1) * p.sb_k];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < HT_U; ++u) {
+            const int k0 = (c0 + c_step * u) * 16 + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool kv = (k0 + e) < p.K && (c0 + c_step * u) < nchunk;
+                float av = a[u][e];
+                if (p.pro == FEDDAT_HT_PRO_LN) av = (av - mean) * rstd * ga[u][e] + be[u][e];
+                if (p.pro == FEDDAT_HT_PRO_TANH_BWD) av = av * (1.f - y[u][e] * y[u][e]);
+                av = (iv && kv) ? av : 0.f;
+                asum += av;
+#pragma unroll
+                for (int t = 0; t < JT; ++t) acc[t] = mfma16x4_f32(av, (jv[t] && kv) ? b[u][t][e] : 0.f, acc[t]);
+            }
+        }
+    }
+}
+
+// JT = 16-column tiles per wave: 4 (64 columns per block) for the products with enough tiles to fill the chip, 1 for the
+// few-tile ones (fc1: 64 x 100; d(pooled): 32 x 768 -- their time is one wave's chain of dependent load batches, so more,
+// narrower blocks win).
+template <int JT>
+__device__ __forceinline__ void ht_body(const HtJob& p, const int wid, float* ht_smem) {
     float (*red)[64][HT_JT * 4 + 4] = reinterpret_cast<float (*)[64][HT_JT * 4 + 4]>(ht_smem);     // [HT_NW - 1]
     float (*srow)[2] = reinterpret_cast<float (*)[2]>(ht_smem + (HT_NW - 1) * 64 * (HT_JT * 4 + 4));     // [16]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool second = (int)blockIdx.x >= L.blocks0;
-    const HtJob& p = L.job[second ? 1 : 0];
-    const int wid = second ? blockIdx.x - L.blocks0 : blockIdx.x;
     const int itile = wid / p.jblocks, jb = wid - itile * p.jblocks;
     const int i16 = lane & 15, g = lane >> 4;
     const int i = itile * 16 + i16;
@@ -60,24 +123,39 @@ __global__ __launch_bounds__(HT_NW * 64) void ht_gemm_kernel(const HtLaunch L) {
     const float* ap = p.A + (size_t)(iv ? i : 0) * p.sa_i;
     const float* yp = p.pro == FEDDAT_HT_PRO_TANH_BWD ? p.pro_a + (size_t)(iv ? i : 0) * p.sa_i : nullptr;
 
-    // LayerNorm prologue: wave w computes the statistics of row 16 itile + w (two passes over the row, which stays in L1)
+    // LayerNorm prologue: wave w computes the statistics of rows 16 itile + w, + w + HT_NW
     float mean = 0.f, rstd = 0.f;
     if (p.pro == FEDDAT_HT_PRO_LN) {
-        const int r = itile * 16 + wave;
-        if (r < p.I) {
+        for (int rl = wave; rl < 16; rl += HT_NW) {
+            const int r = itile * 16 + rl;
+            if (r >= p.I) continue;
+            // (sa_k == 1, K % 4 == 0, K <= 2048: checked on the host) the row sits in registers: one pass of loads
             const float* xr = p.A + (size_t)r * p.sa_i;
+            const int nc = p.K >> 2;
+            f32x4 v[8];
             float s = 0.f;
-            for (int k = lane; k < p.K; k += 64) s += xr[(size_t)k * p.sa_k];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int q4 = lane + c * 64;
+                if (q4 < nc) {
+                    v[c] = *reinterpret_cast<const f32x4*>(xr + q4 * 4);
+                    s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+                }
+            }
             const float m = wave_sum(s) / (float)p.K;
             float q = 0.f;
-            for (int k = lane; k < p.K; k += 64) {
-                const float d = xr[(size_t)k * p.sa_k] - m;
-                q += d * d;
-            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (lane + c * 64 < nc)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[c][e] - m;
+                        q += d * d;
+                    }
             const float rs = rsqrtf(wave_sum(q) / (float)p.K + p.pro_eps);
             if (lane == 0) {
-                srow[wave][0] = m;
-                srow[wave][1] = rs;
+                srow[rl][0] = m;
+                srow[rl][1] = rs;
                 if (p.stats_out && jb == 0) {
                     p.stats_out[2 * r] = m;
                     p.stats_out[2 * r + 1] = rs;
@@ -90,55 +168,32 @@ __global__ __launch_bounds__(HT_NW * 64) void ht_gemm_kernel(const HtLaunch L) {
     }
 
     const int jgrp = p.mode == 0 ? jb : jb * HT_NW + wave;
-    int j[HT_JT];
-    bool jv[HT_JT];
-    const float* bp[HT_JT];
+    int j[JT];
+    bool jv[JT];
+    const float* bp[JT];
 #pragma unroll
-    for (int t = 0; t < HT_JT; ++t) {
-        j[t] = (jgrp * HT_JT + t) * 16 + i16;
+    for (int t = 0; t < JT; ++t) {
+        j[t] = (jgrp * JT + t) * 16 + i16;
         jv[t] = j[t] < p.J;
         bp[t] = p.B + (size_t)(jv[t] ? j[t] : 0) * p.sb_j;
     }
-    f32x4 acc[HT_JT];
+    f32x4 acc[JT];
 #pragma unroll
-    for (int t = 0; t < HT_JT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < JT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-    const int kmax = p.K - 1;
-    const int kstart = p.mode == 0 ? 4 * wave : 0, kstride = p.mode == 0 ? 4 * HT_NW : 4;
-    for (int kb = kstart; kb < p.K; kb += kstride * HT_U) {
-        float a[HT_U], y[HT_U], ga[HT_U], be[HT_U], b[HT_U][HT_JT];
-#pragma unroll
-        for (int u = 0; u < HT_U; ++u) {
-            const int kc = min(kb + kstride * u + g, kmax);
-            a[u] = ap[(size_t)kc * p.sa_k];
-            if (p.pro == FEDDAT_HT_PRO_TANH_BWD) y[u] = yp[(size_t)kc * p.sa_k];
-            if (p.pro == FEDDAT_HT_PRO_LN) {
-                ga[u] = p.pro_a[kc];
-                be[u] = p.pro_b[kc];
-            }
-#pragma unroll
-            for (int t = 0; t < HT_JT; ++t) b[u][t] = bp[t][(size_t)kc * p.sb_k];
-        }
-#pragma unroll
-        for (int u = 0; u < HT_U; ++u) {
-            const bool kv = (kb + kstride * u + g) < p.K;
-            float av = a[u];
-            if (p.pro == FEDDAT_HT_PRO_LN) av = (av - mean) * rstd * ga[u] + be[u];
-            if (p.pro == FEDDAT_HT_PRO_TANH_BWD) av = av * (1.f - y[u] * y[u]);
-            av = (iv && kv) ? av : 0.f;
-            asum += av;
-#pragma unroll
-            for (int t = 0; t < HT_JT; ++t) acc[t] = mfma16x4_f32(av, (jv[t] && kv) ? b[u][t] : 0.f, acc[t]);
-        }
-    }
+    const int c_first = p.mode == 0 ? wave : 0, c_step = p.mode == 0 ? HT_NW : 1;
+    if (p.avec && p.bvec) ht_mainloop<true, true, JT>(p, ap, yp, bp, iv, jv, g, mean, rstd, c_first, c_step, acc, asum);
+    else if (p.avec) ht_mainloop<true, false, JT>(p, ap, yp, bp, iv, jv, g, mean, rstd, c_first, c_step, acc, asum);
+    else if (p.bvec) ht_mainloop<false, true, JT>(p, ap, yp, bp, iv, jv, g, mean, rstd, c_first, c_step, acc, asum);
+    else ht_mainloop<false, false, JT>(p, ap, yp, bp, iv, jv, g, mean, rstd, c_first, c_step, acc, asum);
     asum += __shfl_xor(asum, 16, 64);
     asum += __shfl_xor(asum, 32, 64);
     if (p.mode == 0) {
         if (wave > 0) {
             float* dst = red[wave - 1][lane];
 #pragma unroll
-            for (int t = 0; t < HT_JT; ++t) *reinterpret_cast<f32x4*>(dst + 4 * t) = acc[t];
-            dst[HT_JT * 4] = asum;
+            for (int t = 0; t < JT; ++t) *reinterpret_cast<f32x4*>(dst + 4 * t) = acc[t];
+            dst[JT * 4] = asum;
         }
         __syncthreads();
         if (wave != 0) return;
@@ -146,12 +201,12 @@ __global__ __launch_bounds__(HT_NW * 64) void ht_gemm_kernel(const HtLaunch L) {
         for (int w = 0; w < HT_NW - 1; ++w) {
             const float* src = red[w][lane];
 #pragma unroll
-            for (int t = 0; t < HT_JT; ++t) acc[t] = acc[t] + *reinterpret_cast<const f32x4*>(src + 4 * t);
-            asum += src[HT_JT * 4];
+            for (int t = 0; t < JT; ++t) acc[t] = acc[t] + *reinterpret_cast<const f32x4*>(src + 4 * t);
+            asum += src[JT * 4];
         }
     }
 #pragma unroll
-    for (int t = 0; t < HT_JT; ++t) {
+    for (int t = 0; t < JT; ++t) {
         if (!jv[t]) continue;
         const float bj = p.bias_j ? p.bias_j[j[t]] : 0.f;
 #pragma unroll
@@ -165,6 +220,15 @@ __global__ __launch_bounds__(HT_NW * 64) void ht_gemm_kernel(const HtLaunch L) {
         }
     }
     if (p.colsum && jgrp == 0 && g == 0 && iv) p.colsum[i] = p.alpha * asum;
+}
+
+__global__ __launch_bounds__(HT_NW * 64) void ht_gemm_kernel(const HtLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float ht_smem[];
+    const bool second = (int)blockIdx.x >= L.blocks0;
+    const HtJob& p = L.job[second ? 1 : 0];
+    const int wid = second ? blockIdx.x - L.blocks0 : blockIdx.x;
+    if (p.jt == 1) ht_body<1>(p, wid, ht_smem);
+    else ht_body<HT_JT>(p, wid, ht_smem);
 }
 
 // y = LayerNorm(x) (fp32, stats), g = gelu(y): one wave per row, H <= 2048
@@ -292,41 +356,56 @@ __global__ __launch_bounds__(1024) void dat_loss_single_kernel(const float* __re
     extern __shared__ float terms[];       // [2 B]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float it = 1.0f / temp;
-    for (int b = wave; b < B; b += 16) {
-        const float* x = logits + (size_t)b * C;
-        const float* t = teacher + (size_t)b * C;
-        const float* y = target + (size_t)b * C;
-        float mx = -INFINITY, mt = -INFINITY;
-        for (int j = lane; j < C; j += 64) {
-            mx = fmaxf(mx, x[j] * it);
-            mt = fmaxf(mt, t[j] * it);
+    // C <= 128 (the VQA heads: 100 labels): two elements per lane, the rows of a wave are loaded up front (RPW at a time) so
+    // that their three passes run from registers -- the launch is a chain of dependent reductions, not bytes
+    constexpr int RPW = 4;
+    for (int b0 = wave; b0 < B; b0 += 16 * RPW) {
+        float xv[RPW][2], tv[RPW][2], yv[RPW][2];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int b = b0 + 16 * r;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                const bool ok = b < B && j < C;
+                xv[r][h] = ok ? logits[(size_t)b * C + j] : 0.f;
+                tv[r][h] = ok ? teacher[(size_t)b * C + j] : 0.f;
+                yv[r][h] = ok ? target[(size_t)b * C + j] : 0.f;
+            }
         }
-        mx = wave_max(mx);
-        mt = wave_max(mt);
-        float sx = 0.f, st = 0.f;
-        for (int j = lane; j < C; j += 64) {
-            sx += expf(x[j] * it - mx);
-            st += expf(t[j] * it - mt);
-        }
-        sx = wave_sum(sx);
-        st = wave_sum(st);
-        const float lsx = mx + logf(sx), lst = mt + logf(st);
-        float bce = 0.f, kl = 0.f;
-        for (int j = lane; j < C; j += 64) {
-            const float xv = x[j];
-            bce += fmaxf(xv, 0.f) - xv * y[j] + log1pf(expf(-fabsf(xv)));
-            const float logp = xv * it - lsx;
-            const float logq = t[j] * it - lst;
-            const float q = expf(logq);
-            kl += q * (logq - logp);
-            const float sig = 1.0f / (1.0f + expf(-xv));
-            dlogits[(size_t)b * C + j] = 0.5f / (float)B * ((sig - y[j]) + temp * (expf(logp) - q));
-        }
-        bce = wave_sum(bce);
-        kl = wave_sum(kl);
-        if (lane == 0) {
-            terms[2 * b] = bce;
-            terms[2 * b + 1] = kl;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int b = b0 + 16 * r;
+            if (b >= B) break;
+            const bool v0 = lane < C, v1 = lane + 64 < C;
+            float mx = fmaxf(v0 ? xv[r][0] * it : -INFINITY, v1 ? xv[r][1] * it : -INFINITY);
+            float mt = fmaxf(v0 ? tv[r][0] * it : -INFINITY, v1 ? tv[r][1] * it : -INFINITY);
+            mx = wave_max(mx);
+            mt = wave_max(mt);
+            float sx = (v0 ? expf(xv[r][0] * it - mx) : 0.f) + (v1 ? expf(xv[r][1] * it - mx) : 0.f);
+            float st = (v0 ? expf(tv[r][0] * it - mt) : 0.f) + (v1 ? expf(tv[r][1] * it - mt) : 0.f);
+            sx = wave_sum(sx);
+            st = wave_sum(st);
+            const float lsx = mx + logf(sx), lst = mt + logf(st);
+            float bce = 0.f, kl = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!(h ? v1 : v0)) continue;
+                const float x = xv[r][h];
+                bce += fmaxf(x, 0.f) - x * yv[r][h] + log1pf(expf(-fabsf(x)));
+                const float logp = x * it - lsx;
+                const float logq = tv[r][h] * it - lst;
+                const float q = expf(logq);
+                kl += q * (logq - logp);
+                const float sig = 1.0f / (1.0f + expf(-x));
+                dlogits[(size_t)b * C + lane + 64 * h] = 0.5f / (float)B * ((sig - yv[r][h]) + temp * (expf(logp) - q));
+            }
+            bce = wave_sum(bce);
+            kl = wave_sum(kl);
+            if (lane == 0) {
+                terms[2 * b] = bce;
+                terms[2 * b + 1] = kl;
+            }
         }
     }
     __syncthreads();
@@ -423,7 +502,9 @@ __global__ void step_tick_multi_kernel(const TickMulti t) {
 int ht_fill(HtJob& j, const feddat_ht_job& s) {
     if (!(s.A && s.B && s.out && s.I > 0 && s.J > 0 && s.K > 0 && s.ldo >= s.J && (s.mode == 0 || s.mode == 1)))
         return FEDDAT_EINVAL;
-    if (s.pro == FEDDAT_HT_PRO_LN && !(s.pro_a && s.pro_b && s.pro_eps > 0.f)) return FEDDAT_EINVAL;
+    if (s.pro == FEDDAT_HT_PRO_LN && !(s.pro_a && s.pro_b && s.pro_eps > 0.f && s.sa_k == 1 && s.K % 4 == 0 && s.K <= 2048 &&
+                                       s.sa_i % 4 == 0 && ((uintptr_t)s.A & 15) == 0))
+        return FEDDAT_EINVAL;
     if (s.pro == FEDDAT_HT_PRO_TANH_BWD && !s.pro_a) return FEDDAT_EINVAL;
     if (s.epi == FEDDAT_HT_EPI_MUL_DGELU && !(s.aux && s.ld_aux >= s.J)) return FEDDAT_EINVAL;
     if (s.pro < 0 || s.pro > FEDDAT_HT_PRO_TANH_BWD || s.epi < 0 || s.epi > FEDDAT_HT_EPI_MUL_DGELU) return FEDDAT_EINVAL;
@@ -431,8 +512,17 @@ int ht_fill(HtJob& j, const feddat_ht_job& s) {
     j.I = s.I; j.J = s.J; j.K = s.K; j.mode = s.mode; j.alpha = s.alpha; j.bias_j = s.bias_j; j.out = s.out; j.ldo = s.ldo;
     j.colsum = s.colsum; j.pro = s.pro; j.pro_a = s.pro_a; j.pro_b = s.pro_b; j.pro_eps = s.pro_eps;
     j.stats_out = s.stats_out; j.epi = s.epi; j.aux = s.aux; j.ld_aux = s.ld_aux;
+    j.avec = s.sa_k == 1 && s.K % 4 == 0 && s.sa_i % 4 == 0 && ((uintptr_t)s.A & 15) == 0 &&
+             (s.pro != FEDDAT_HT_PRO_TANH_BWD || ((uintptr_t)s.pro_a & 15) == 0);
+    j.bvec = s.sb_k == 1 && s.K % 4 == 0 && s.sb_j % 4 == 0 && ((uintptr_t)s.B & 15) == 0;
+    if (s.pro == FEDDAT_HT_PRO_LN && !(j.avec && (((uintptr_t)s.pro_a | (uintptr_t)s.pro_b) & 15) == 0)) return FEDDAT_EINVAL;
     j.itiles = (s.I + 15) / 16;
-    const int jgroups = (s.J + 16 * HT_JT - 1) / (16 * HT_JT);
+    int jgroups = (s.J + 16 * HT_JT - 1) / (16 * HT_JT);
+    j.jt = HT_JT;
+    if (s.mode == 0 && j.itiles * jgroups < 64) {      // too few 16 x 64 tiles: 16 x 16 tiles, four times the blocks
+        j.jt = 1;
+        jgroups = (s.J + 15) / 16;
+    }
     j.jblocks = s.mode == 0 ? jgroups : (jgroups + HT_NW - 1) / HT_NW;
     return FEDDAT_OK;
 }
@@ -475,7 +565,7 @@ extern "C" int feddat_head_ln_bwd_full(const float* dy, const float* x, const fl
 
 extern "C" int feddat_dat_loss_fwd_bwd_single(const float* logits, const float* teacher, const float* target, int B, int C,
                                               float temp, float* dlogits, float* scalars, hipStream_t stream) {
-    FD_CHECK_ARG(logits && teacher && target && dlogits && scalars && B > 0 && B <= 4096 && C > 0 && temp > 0.f);
+    FD_CHECK_ARG(logits && teacher && target && dlogits && scalars && B > 0 && B <= 4096 && C > 0 && C <= 128 && temp > 0.f);
     hipLaunchKernelGGL(dat_loss_single_kernel, dim3(1), dim3(1024), 2 * B * sizeof(float), stream, logits, teacher, target, B,
                        C, temp, dlogits, scalars);
     FD_LAUNCH_RET();

@@ -273,6 +273,9 @@ class ViltDatEngine:
         # fused kernels of csrc/head_tail.hip (20 launches); False: the round-3 sequence of 46 single-purpose launches (same
         # arithmetic up to fp32 summation order; tools/step_breakdown.py --unfused-tail, and the tests compare the two)
         self.fused_tail = True
+        # True: the last layer's attention computes the ONE query per (sample, head) the pooler consumes (token 0) and its
+        # rank-1 backward (feddat_attn_cls_fwd / _bwd); False: the dense kernels on all S queries (184 of 185 never read)
+        self.cls_attention = True
         self.sched = dict(warmup=1, total=2)
         self.opt_adapters = (0, 1)
         self.task = self.tasks[0]
@@ -379,6 +382,11 @@ class ViltDatEngine:
         # (self.patches was filled by set_batch: im2col of the caller's pixel_values)
         L.gemm_bf16_nt(self.patches, self.w_patch, L.EPI_F32, bias=e["patch_embeddings.projection.bias"],
                        out_f32=self.proj)
+        if self.fused_tail:      # key mask + per-sample position grid + assembly in one launch (bit-identical)
+            L.image_embed_assemble_masked(self.proj, self.cls, self.pos0, self.pos_grid, self.inp["patch_mask"],
+                                          self.inp["attention_mask"], self.mod1, self.h0, self.key_mask2, B, Lt, self.gh,
+                                          self.gw, self.g0, H, nrep=2)
+            return
         L.vilt_key_mask(self.inp["attention_mask"], self.inp["patch_mask"], self.key_mask2, B, Lt, self.gh, self.gw, 1,
                         nrep=2)
         L.pos_embed_resize_masked(self.pos_grid, self.inp["patch_mask"], self.pos_img, self.g0, B, self.gh, self.gw, 1,
@@ -497,7 +505,8 @@ class ViltDatEngine:
             L.gemm_fp8_nt(self.x8[:R2], self.xs[:R2], W["wqkv8"], W["sqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
         else:
             L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
-        L.attn_fwd(a["qkv"], a["ctx"], a["lse"], nb, self.S, self.heads, key_mask=mask)
+        (L.attn_cls_fwd if self.cls_attention else L.attn_fwd)(a["qkv"], a["ctx"], a["lse"], nb, self.S, self.heads,
+                                                                key_mask=mask)
         L.gemm_bf16_nt(self._cls_rows(a["ctx"], nb), W["wo"], L.EPI_RESID_F32, bias=W["bo"],
                        resid=self._cls_rows(a["h_in"], nb), out_f32=t["h2"], skinny_workspace=self._skinny_ws())
         L.layernorm_fwd(t["h2"], W["ln2g"], W["ln2b"], self.ln_eps, nb, H, y_bf16=t["x16"], stats=t["st2"])
@@ -699,9 +708,12 @@ class ViltDatEngine:
                            out_bf16=t["dh216"])
         L.gemm_bf16_nt(t["dh216"], W["woT"], L.EPI_F32, out_f32=t["dctx"], skinny_workspace=ws)
         # scatter the token-0 rows into the dense operands of the attention / LN1 backward
-        L.scatter_cls_rows(t["dctx"], None, self.dctx, nb, self.S, H)
         L.scatter_cls_rows(t["dh2"], cur, None, nb, self.S, H)
-        L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=mask)
+        if self.cls_attention:       # rank-1 backward straight from the fp32 token-0 gradient rows
+            L.attn_cls_bwd(a["qkv"], a["ctx"], a["lse"], t["dctx"], self.dqkv, nb, self.S, self.heads, key_mask=mask)
+        else:
+            L.scatter_cls_rows(t["dctx"], None, self.dctx, nb, self.S, H)
+            L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=mask)
         L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
         L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
 
@@ -783,7 +795,7 @@ class ViltDatEngine:
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.use_layer_calls, self.fp8,
-               self.fp8_ffn_chain, self.fused_tail)        # host-side switches that change the launch list are part of the signature
+               self.fp8_ffn_chain, self.fused_tail, self.cls_attention)        # host-side switches that change the launch list are part of the signature
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig

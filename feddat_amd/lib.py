@@ -95,6 +95,8 @@ _SIGS = {
                                    vp, i64, vp],
     "feddat_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "feddat_attn_cls_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "feddat_attn_cls_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn2_fwd": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, i32, i32, i32, i64, i64, i32, vp],
     "feddat_attn2_bwd": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32,
                          i32, i64, i64, i32, vp],
@@ -142,6 +144,7 @@ _SIGS = {
     "feddat_text_embed": [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, vp],
     "feddat_im2col_patches": [vp, vp, i32, i32, i32, i32, i32, vp],
     "feddat_image_embed_assemble": [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp],
+    "feddat_image_embed_assemble_masked": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "feddat_pos_embed_resize_masked": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "feddat_vilt_key_mask": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "feddat_vilt_image_workspace_bytes": [vp, vp, vp, vp, i32],
@@ -366,6 +369,20 @@ def attn_bwd(qkv, ctx, lse, dctx, dqkv, B, S, heads, key_mask=None):
     _dev(qkv, ctx, dctx, dqkv)
     _chk(load().feddat_attn_bwd(_p(qkv), _p(key_mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), B, S, heads, _stream()),
          "feddat_attn_bwd")
+
+
+def attn_cls_fwd(qkv, ctx, lse, B, S, heads, key_mask=None):
+    """Attention for token 0 of every sample only (the last layer): writes ctx rows b*S and lse[b, h, 0]."""
+    _dev(qkv, ctx)
+    _chk(load().feddat_attn_cls_fwd(_p(qkv), _p(key_mask), _p(ctx), _p(lse), B, S, heads, _stream()), "feddat_attn_cls_fwd")
+
+
+def attn_cls_bwd(qkv, ctx, lse, dctx0, dqkv, B, S, heads, key_mask=None):
+    """dctx0: fp32 [B, H] gradient of the token-0 context rows -> the complete dqkv."""
+    _dev(qkv, ctx, dctx0, dqkv)
+    assert dctx0.dtype == torch.float32 and dctx0.is_contiguous()
+    _chk(load().feddat_attn_cls_bwd(_p(qkv), _p(key_mask), _p(ctx), _p(lse), _p(dctx0), _p(dqkv), B, S, heads, _stream()),
+         "feddat_attn_cls_bwd")
 
 
 def attn2_fwd(q, k, v, ctx, lse, B, Sq, Skv, heads, *, key_mask=None, causal=False, q_rows=None, kv_rows=None, drop=None):
@@ -729,6 +746,15 @@ def text_embed(ids, tts, word, pos, typ, ln_g, ln_b, eps, mod0, h, B, Lt, S, H):
     _dev(ids, h)
     _chk(load().feddat_text_embed(_p(ids), _p(tts), _p(word), _p(pos), _p(typ), _p(ln_g), _p(ln_b), eps, _p(mod0),
                                   _p(h), B, Lt, S, H, _stream()), "feddat_text_embed")
+
+
+def image_embed_assemble_masked(proj, cls, pos0, pos_grid, patch_mask, attention_mask, mod1, h, key_mask, B, Lt, gh, gw, g, H,
+                                nrep=1):
+    """image_embed_assemble + pos_embed_resize_masked + vilt_key_mask in one launch (patch_mask: int64 [B, gh, gw])."""
+    _dev(proj, h, patch_mask)
+    _chk(load().feddat_image_embed_assemble_masked(_p(proj), _p(cls), _p(pos0), _p(pos_grid), _p(patch_mask),
+                                                   _p(attention_mask), _p(mod1), _p(h), _p(key_mask), B, Lt, gh, gw, g, H, nrep,
+                                                   _stream()), "feddat_image_embed_assemble_masked")
 
 
 def im2col_patches(pixels, patches, B, Cc, Hi, Wi, P):

@@ -30,7 +30,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_ELAUNCH 2
 #define FEDDAT_ETIMEOUT 3   /* feddat_comm_create_timeout only */
 
-#define FEDDAT_ABI_VERSION 6   /* 6: fused step tail (feddat_head_gemm, feddat_head_ln_gelu, feddat_head_ln_bwd_full, feddat_dat_loss_fwd_bwd_single, feddat_adamw_multi, feddat_step_tick_multi), feddat_vqa_score_accumulate, feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
+#define FEDDAT_ABI_VERSION 6   /* 6: feddat_attn_cls_fwd / _bwd (token-0-only attention of the last layer), fused step tail (feddat_head_gemm, feddat_head_ln_gelu, feddat_head_ln_bwd_full, feddat_dat_loss_fwd_bwd_single, feddat_adamw_multi, feddat_step_tick_multi), feddat_vqa_score_accumulate, feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -138,6 +138,15 @@ int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* 
 /* dX-only backward: dqkv (bf16 [B*S, 3*H]) from dctx (bf16 [B*S,H]), qkv, ctx, lse. */
 int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* dctx,
                     void* dqkv, int B, int S, int heads, hipStream_t stream);
+/* The same attention for a layer of which only token 0 of every sample is consumed (the LAST ViLT layer: HF ViltPooler
+ * reads hidden_states[:, 0]; vilt.py:127): one query per (sample, head).  feddat_attn_cls_fwd writes row b*S of ctx and
+ * lse[b, h, 0] only.  feddat_attn_cls_bwd takes dctx0 = fp32 [B, H], the gradient of those rows (all other rows of dctx
+ * are zero by construction), and writes the complete dqkv [B*S, 3*H] (dQ rows other than token 0 are zeros).  fp32 VALU on
+ * the bf16 operands, HBM-bound; S <= 320. */
+int feddat_attn_cls_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
+                        hipStream_t stream);
+int feddat_attn_cls_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const float* dctx0,
+                        void* dqkv, int B, int S, int heads, hipStream_t stream);
 
 /* General form (the ALBEF path): separate Q / K / V operands (bf16, head h at columns 64 h .. 64 h + 63 of each, row
  * strides ld* in elements, sample b's rows at b * rows_per_sample), any S_q and S_kv (K / V stream through LDS with an
@@ -352,7 +361,7 @@ int feddat_reduce_partials(const float* in, long stride, int nsplit, long n, flo
  * feddat_head_gemm: one or two INDEPENDENT small products in ONE launch, each
  *     out[i, j] = epi( alpha * sum_k pro(A)[i, k] * B[k, j] + bias_j[j] ),   colsum[i] = alpha * sum_k pro(A)[i, k]
  * with arbitrary element strides (A[i, k] at A + i sa_i + k sa_k, B[k, j] at B + k sb_k + j sb_j), fp32 MFMA, the K
- * range split over the 16 waves of a block and summed in wave order (mode 0: no split-K partials in HBM), or -- mode 1,
+ * range split over the waves of a block and summed in wave order (mode 0: no split-K partials in HBM), or -- mode 1,
  * for contractions over the batch (K ~ 32) -- the waves on consecutive 64-column groups.  Prologues on A: LN = LayerNorm
  * of row i over k with gamma = pro_a, beta = pro_b, eps (sa_k must make rows contiguous enough to re-read; statistics
  * {mean, rstd} computed in the block, optionally written to stats_out [I, 2]); TANH_BWD = A[i, k] * (1 - y^2), y = pro_a
@@ -468,6 +477,15 @@ int feddat_im2col_patches(const float* pixels, void* patches_bf16, int B, int C,
 int feddat_image_embed_assemble(const float* proj, const float* cls, const float* pos0, const float* pos_img,
                                 long pos_batch_stride, const float* modality1, float* h, int B, int Lt, int np, int S,
                                 int H, hipStream_t stream);
+/* feddat_image_embed_assemble + feddat_pos_embed_resize_masked + feddat_vilt_key_mask in ONE launch: the per-sample position
+ * grid (pos_grid [g, g, H] resized to the sample's valid patch rectangle, bilinear / align_corners, zero outside) is
+ * interpolated where it is added -- no [B, np, H] intermediate -- and key_mask (uint8 [nrep * B, S], optional) is written
+ * from attention_mask (int64 [B, Lt] or NULL = all valid) and patch_mask = pixel_mask sampled at the patch origins
+ * (int64 [B, gh, gw]).  Bit-identical with the three separate calls. */
+int feddat_image_embed_assemble_masked(const float* proj, const float* cls, const float* pos0, const float* pos_grid,
+                                       const long* patch_mask, const long* attention_mask, const float* modality1, float* h,
+                                       uint8_t* key_mask, int B, int Lt, int gh, int gw, int g, int H, int nrep,
+                                       hipStream_t stream);
 /* bilinear(align_corners=True) resize of the [g,g,H] position grid to [gh,gw,H] (HF visual_embed) */
 int feddat_pos_embed_resize(const float* pos_grid, float* out, int g, int gh, int gw, int H, hipStream_t stream);
 /* Padded images (HF ViltEmbeddings.visual_embed, transformers modeling_vilt.py, called from vilt.py:127): pixel_mask is
