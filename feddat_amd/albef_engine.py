@@ -180,6 +180,7 @@ class AlbefDatEngine:
         self.unsel_idx = torch.full((self.Ma,), -1, dtype=torch.int32, device=dev)
         self.labels = torch.zeros(self.R, dtype=torch.int64, device=dev)
         self.row_w = f32(self.R)
+        self.row_kl = torch.ones(self.R, device=dev)      # per-row factor on the MKD term (0 on rows that only padding created)
 
         def vit_set():
             Mi = self.Mi
@@ -300,43 +301,75 @@ class AlbefDatEngine:
 
     # ------------------------------------------------------------------------------------------ inputs
     def set_batch(self, batch: Dict):
-        """Reference batch after tokenisation: image [B,3,R,R] f32; question_ids / question_mask [B,Lq]; answer_ids /
-        answer_mask [N,La]; weights [N]; k = answers per question (host list, sum = N).
-        Shapes are the engine's (static buffers, one captured graph): the caller pads questions to Lq and answers to La with
-        [PAD] + mask 0 and keeps N answers per batch.  Padded KEYS are masked out exactly; padded answer POSITIONS are not
-        free, as in the reference: its MKD term runs over every row of logits[:, :-1] (task_trainer.py:506-516, batchmean over
-        the answers), pad positions included, so a batch padded to a longer La than the reference's `padding='longest'`
-        (albef.py:56-57) carries extra KL rows.  For a bit-for-bit comparable recipe tokenise with padding to the engine's
-        fixed lengths on both sides (what the parity fixtures do)."""
-        for k in ("image", "question_ids", "question_mask", "answer_ids", "answer_mask", "weights"):
-            src = batch[k]
-            if tuple(src.shape) != tuple(self.inp[k].shape):
-                raise L.FeddatHipError(f"engine built for {k} {tuple(self.inp[k].shape)}, got {tuple(src.shape)}")
-            self.inp[k].copy_(src, non_blocking=True)
-        for k in ("question_ids", "answer_ids"):        # an out-of-range id would fault in the embedding gather; host
-            if not batch[k].is_cuda and int(batch[k].max()) >= self.V:          # batches are checked (device ones: no sync)
+        """Reference batch after tokenisation (albef.py:52-60): image [B,3,R,R] f32; question_ids / question_mask [B, lq];
+        answer_ids / answer_mask [n, la]; weights [n]; k = answers per question (host list, sum = n).
+        The reference pads to the LONGEST question / answer of the batch and has as many answers as the batch brings
+        (vqa_dataset_crossvqa.py:377-422); the engine's buffers are one static frame [B, Lq], [N, La] (one captured graph).
+        Any lq <= Lq, la <= La, n <= N is accepted and embedded in the frame so that the RESULT is the reference's on the
+        unpadded batch: padded key positions are masked out of every attention; padded answer POSITIONS and padded ANSWERS get
+        label -100, weight 0 and factor 0 on their MKD rows (row_kl), and the MKD's batchmean divides by n, not N -- the
+        reference's KL runs over every row of logits[:, :-1] of ITS batch, i.e. [n, la - 1, V] (task_trainer.py:506-516)."""
+        B, N, Lq, La = self.B, self.N, self.Lq, self.La
+        img = batch["image"]
+        if tuple(img.shape) != tuple(self.inp["image"].shape):
+            raise L.FeddatHipError(f"engine built for image {tuple(self.inp['image'].shape)}, got {tuple(img.shape)}")
+        self.inp["image"].copy_(img, non_blocking=True)
+        qi, qm, ai, am, wt = (batch[k] for k in ("question_ids", "question_mask", "answer_ids", "answer_mask", "weights"))
+        lq, n, la = qi.shape[1], ai.shape[0], ai.shape[1]
+        if qi.shape[0] != B or tuple(qm.shape) != tuple(qi.shape) or tuple(am.shape) != tuple(ai.shape) or wt.shape[0] != n:
+            raise L.FeddatHipError("question / answer tensors of one batch disagree in shape")
+        if lq > Lq or la > La or n > N or n < 1 or la < 2:
+            raise L.FeddatHipError(f"batch ({lq} question tokens, {n} answers of {la} tokens) exceeds the engine's frame "
+                                   f"({Lq}, {N}, {La})")
+        for k, t in (("question_ids", qi), ("answer_ids", ai)):      # an out-of-range id would fault in the embedding gather;
+            if not t.is_cuda and int(t.max()) >= self.V:             # host batches are checked (device ones: no sync)
                 raise L.FeddatHipError("token id outside the vocabulary")
-        ks = list(batch["k"])
-        if len(ks) != self.B or sum(ks) != self.N:
-            raise L.FeddatHipError("k must list the answers per question and sum to the engine's n_answers")
-        if getattr(self, "_k", None) != ks:          # index maps depend on k only (host-built once per k pattern)
-            self._k = ks
-            Lq, La = self.Lq, self.La
-            qof = torch.repeat_interleave(torch.arange(self.B), torch.tensor(ks))
+        full = (lq, n, la) == (Lq, N, La)
+        if full:
+            for k, src in (("question_ids", qi), ("question_mask", qm), ("answer_ids", ai), ("answer_mask", am), ("weights", wt)):
+                self.inp[k].copy_(src, non_blocking=True)
+        else:
+            self.inp["question_ids"].fill_(self.pad_id)
+            self.inp["question_mask"].zero_()
+            self.inp["question_ids"][:, :lq].copy_(qi, non_blocking=True)
+            self.inp["question_mask"][:, :lq].copy_(qm, non_blocking=True)
+            self.inp["answer_ids"].fill_(self.pad_id)
+            self.inp["answer_mask"].zero_()
+            self.inp["answer_ids"][:n, :la].copy_(ai, non_blocking=True)
+            self.inp["answer_mask"][:n, :la].copy_(am, non_blocking=True)
+            if n < N:       # padded answers: one live [CLS] key so that no attention row is empty; they carry no loss
+                self.inp["answer_ids"][n:, 0] = self.inp["answer_ids"][0, 0]
+                self.inp["answer_mask"][n:, 0] = 1
+            self.inp["weights"].zero_()
+            self.inp["weights"][:n].copy_(wt, non_blocking=True)
+        ks = [int(x) for x in batch["k"]]
+        if len(ks) != B or sum(ks) != n:
+            raise L.FeddatHipError("k must list the answers per question and sum to the number of answers")
+        ks[-1] += N - n                              # padded answers ride with the last question (zero gradient rows)
+        shape_key = (tuple(ks), n, la)
+        if getattr(self, "_k", None) != shape_key:   # index maps depend on the batch's shape only (host-built once per pattern)
+            self._k = shape_key
+            qof = torch.repeat_interleave(torch.arange(B), torch.tensor(ks))
             self.qof = qof.to(self.dev)
             self.rep_idx.copy_((qof[:, None] * Lq + torch.arange(Lq)[None]).reshape(-1).int())
             self.seg_off.copy_(torch.tensor([0] + list(torch.tensor(ks).cumsum(0)), dtype=torch.int32))
-            sel = (torch.arange(self.N)[:, None] * La + torch.arange(La - 1)[None]).reshape(-1)
+            sel = (torch.arange(N)[:, None] * La + torch.arange(La - 1)[None]).reshape(-1)
             self.sel_idx.copy_(sel.int())
             un = torch.full((self.Ma,), -1, dtype=torch.int32)
             un[sel] = torch.arange(self.R, dtype=torch.int32)
             self.unsel_idx.copy_(un)
+            rk = torch.zeros(N, La - 1)
+            rk[:n, :la - 1] = float(N) / float(n)
+            self.row_kl.copy_(rk.reshape(-1))
         # masks, labels and per-row weights of this batch (tiny integer work on the device tensors)
         self.qmask8.copy_(self.inp["question_mask"])
         self.amask8.copy_(self.inp["answer_mask"])
         self.qmask8_rep.copy_(self.qmask8[self.qof])
         ids = self.inp["answer_ids"]
         lab = ids[:, 1:].masked_fill(ids[:, 1:] == self.pad_id, -100)
+        if not full:
+            lab[n:] = -100
+            lab[:, la - 1:] = -100
         self.labels.copy_(lab.reshape(-1))
         self.row_w.copy_((self.inp["weights"] / self.B)[:, None].expand(self.N, self.La - 1).reshape(-1))
 
@@ -547,7 +580,7 @@ class AlbefDatEngine:
         """Loss, LM head, decoder and text encoder backward of the pass `mode`; leaves d(image_embeds) in its scratch set."""
         S, g, hd, H = self.acts[mode], self.gs[mode], self.head, self.H
         L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
-                          S["loss"])
+                          S["loss"], row_kl=self.row_kl)
         R = self.R
         # LM head backward (frozen): logits = LN(gelu(dense(h))) W_emb^T
         L.gemm_bf16_nt(g["dlogits"], hd["wT"], L.EPI_BF16, out_bf16=g["b1"][:R])
@@ -627,7 +660,7 @@ class AlbefDatEngine:
                 self._backward("gating", logits_1, 2 if drop else None)   # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2
             else:        # adapter_0 left the optimizer (server flags after the first eval): only the loss values are needed
                 L.lm_loss_fwd_bwd(logits_g, logits_1, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, None,
-                                  self.acts["gating"]["loss"])
+                                  self.acts["gating"]["loss"], row_kl=self.row_kl)
         self._backward("adapter_1", logits_teacher, 1 if drop else None)  # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
         cur.wait_stream(side)
         if 1 in self.opt_adapters:
@@ -696,7 +729,8 @@ class AlbefDatEngine:
             if mode != key:
                 del self.acts[mode]
         L.lm_loss_fwd_bwd(logits, None, self.labels, self.row_w, self.V, 3.0, 0.0, None, S["loss"])
-        return S["loss"][0].clone(), logits[:, :self.V].reshape(self.N, self.La - 1, self.V).clone()
+        _, n, la = self._k             # the batch's own answer count / length inside the engine's frame
+        return S["loss"][0].clone(), logits[:, :self.V].reshape(self.N, self.La - 1, self.V)[:n, :la - 1].clone()
 
     @torch.no_grad()
     def rank_answer(self, batch: Dict, answer_ids: torch.Tensor, answer_mask: torch.Tensor, k: int, mode: str = "gating"):

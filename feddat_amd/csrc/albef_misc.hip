@@ -87,8 +87,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // of the LM-head backward GEMM), zeros in the padding columns [V, ldd).
 __global__ __launch_bounds__(256) void lm_loss_kernel(const float* __restrict__ logits, const float* __restrict__ teacher,
                                                       long ldl, const long* __restrict__ labels,
-                                                      const float* __restrict__ row_w, int V, float T, float kl_scale,
-                                                      bf16* __restrict__ dlogits, long ldd, float* __restrict__ row_terms) {
+                                                      const float* __restrict__ row_w, const float* __restrict__ row_kl,
+                                                      int V, float T, float kl_scale, bf16* __restrict__ dlogits, long ldd,
+                                                      float* __restrict__ row_terms) {
     __shared__ float red[4];
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* l = logits + (size_t)r * ldl;
@@ -123,14 +124,17 @@ __global__ __launch_bounds__(256) void lm_loss_kernel(const float* __restrict__ 
     const long lab = labels[r];
     const float w = lab >= 0 ? row_w[r] : 0.f;
     const float ce = lab >= 0 ? (m1 + __logf(z1) - l[lab]) : 0.f;
+    // row_kl: per-row factor on the MKD term (rows that exist only because the batch was padded to the engine's frame carry
+    // 0; the others N_frame / n_batch, which turns kl_scale = T^2 / N_frame into the reference's batchmean over n_batch)
+    const float rk = row_kl ? row_kl[r] : 1.f;
     if (tid == 0) {
         row_terms[2 * r] = w * ce;
-        row_terms[2 * r + 1] = kl;
+        row_terms[2 * r + 1] = kl * rk;
     }
     if (!dlogits) return;
     bf16* dl = dlogits + (size_t)r * ldd;
     const float i1 = 1.0f / z1, ip = t ? 1.0f / zp : 0.f, iq = t ? 1.0f / zq : 0.f;
-    const float ks = kl_scale * invT;
+    const float ks = kl_scale * rk * invT;
     for (int v = tid; v < (int)ldd; v += 256) {
         float gv = 0.f;
         if (v < V) {
@@ -303,12 +307,12 @@ extern "C" int feddat_segment_sum_rows(const float* src, const int* seg_offsets,
 }
 
 extern "C" int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
-                                      const float* row_weight, int R, int V, float temp, float kl_scale,
+                                      const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale,
                                       void* dlogits_bf16, long ldd, float* scalars, hipStream_t stream) {
     FD_CHECK_ARG(logits && labels && row_weight && scalars && R > 0 && V > 0 && ldl >= V && temp > 0.f);
     FD_CHECK_ARG(!dlogits_bf16 || ldd >= V);
     float* row_terms = scalars + 4;       // scalars: 4 + 2 R floats
-    hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(256), 0, stream, logits, teacher, ldl, labels, row_weight, V, temp,
+    hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(256), 0, stream, logits, teacher, ldl, labels, row_weight, row_kl, V, temp,
                        kl_scale, (bf16*)dlogits_bf16, ldd, row_terms);
     hipLaunchKernelGGL(lm_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, R, kl_scale, scalars);
     FD_LAUNCH_RET();

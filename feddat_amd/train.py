@@ -188,6 +188,11 @@ class AlbefTaskTrainer(TaskTrainer):
         return 0.0, model
 
     def train_step(self, model, step, batch, optimizer=None, scheduler=None, hooks=None, epoch=None):
+        if isinstance(batch, (list, tuple)):           # the reference's collated list (albef.py:275-286)
+            from .albef_modeling import convert_batch_to_albef_input_dict
+            batch = convert_batch_to_albef_input_dict(batch)
+        if "questions" in batch:                       # strings -> device tokenizer, once per batch (task_trainer.py:250-264)
+            batch = model.process_inputs(dict(batch, train=True))
         out = model.engine.train_step(batch, use_graph=self.use_graph)
         model.activate_gating()
         model.set_active_adapter("adapter_0")

@@ -431,11 +431,13 @@ int feddat_vqa_score_accumulate(const float* logits, const float* target, int B,
  * (task_trainer.py:300,320,506-516), and dL/dlogits of L = (loss + kl) / 2.
  * One row = one (answer, position) of logits[:, :-1]: logits / teacher fp32 [R, ldl] (V valid columns), labels int64 [R]
  * (-100 = ignored by the CE, still part of the KL, as in the reference), row_weight[r] = weights[n] / B,
- * kl_scale = temp^2 / N (N answers).  dlogits_bf16 [R, ldd] (may be NULL) gets zeros in columns [V, ldd) so that it can be
+ * kl_scale = temp^2 / N (N answers); row_kl (optional fp32 [R], NULL = all ones) multiplies a row's KL term and its gradient --
+ * 0 for rows that exist only because a batch was padded to a static frame (the reference pads to the longest of the batch:
+ * albef.py:56-57), N_frame / n_batch elsewhere.  dlogits_bf16 [R, ldd] (may be NULL) gets zeros in columns [V, ldd) so that it can be
  * the K-padded operand of the LM-head backward GEMM.  scalars: 4 + 2 R floats; [0] = loss, [1] = kl, [2] = L. */
 int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
-                           const float* row_weight, int R, int V, float temp, float kl_scale, void* dlogits_bf16, long ldd,
-                           float* scalars, hipStream_t stream);
+                           const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale,
+                           void* dlogits_bf16, long ldd, float* scalars, hipStream_t stream);
 /* ALBEF.rank_answer's selections (src/modeling/models/albef_model.py:171-228; eval loop task_trainer.py:159-204).
  * feddat_softmax_gather_rows: out[r, j] = softmax(logits[r * row_stride + 0 .. V))[ids[j * id_stride]]  -- the probability of
  *   every candidate answer's first token after [BOS] (albef_model.py:183-186: F.softmax(logits, 1).index_select(1, answer_ids[:, 1])).

@@ -281,3 +281,103 @@ def test_albef_api_mirror_and_federated_main(tmp_path):
     assert len(srv) == 28 and all(torch.equal(v, sd[k].cpu()) for k, v in srv.items())
     init = albef_spec.random_init(seed=42, image=64, **dims)
     assert max(float((sd[k].cpu() - init[k]).abs().max()) for k in srv) > 0       # the averaged adapter moved
+
+
+def test_batches_of_the_references_shape_inside_a_larger_frame(eng_mod):
+    """The reference pads questions / answers to the longest of the BATCH and brings as many answers as the batch has
+    (albef.py:56-57; vqa_dataset_crossvqa.py:377-422); the engine's frame is static.  An engine built for [B, 16] questions
+    and 9 answers of 7 tokens takes batches with 12-token questions, 6 (then 5) answers of 5 (then 4) tokens: losses, logits
+    and four train_steps (eager + hipGraph replay, shapes changing between steps) equal the oracle's on the UNPADDED
+    batches -- padded keys masked, padded answer positions / answers with label -100, weight 0, no MKD row, and the MKD mean
+    over the batch's own n answers."""
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    P0 = {k: v.clone() for k, v in P.items()}
+    eng = _small_engine(eng_mod, P, 3, 9, 16, 7)
+    shapes = [dict(q_len=12, a_len=5, k=[2, 1, 3]), dict(q_len=16, a_len=7, k=[3, 3, 3]), dict(q_len=9, a_len=4, k=[1, 2, 2]),
+              dict(q_len=12, a_len=5, k=[2, 1, 3])]
+    b0 = A.synthetic_batch(3, d, 1500, ragged=True, **shapes[0])
+    for mode in ("gating", "adapter_1"):
+        loss, logits = eng.forward_train_logits(_dev(b0), mode)
+        with torch.no_grad():
+            ol, olg = A.albef_train_forward(P, d, b0, mode)
+        assert logits.shape == olg.shape == (6, 4, SMALL["vocab"])
+        assert (logits.cpu() - olg).abs().max() < 5e-2 and abs(float(loss) - float(ol)) < 3e-3 * float(ol), mode
+    client = A.AlbefDatClient(P, d, lr=1e-4, steps_per_epoch=4)
+    eng.begin_local_update(steps_per_epoch=4)
+    for s, shp in enumerate(shapes):
+        b = A.synthetic_batch(3, d, 1510 + s, ragged=True, **shp)
+        ref = float(client.train_step(b))
+        out = eng.train_step(_dev(b), use_graph=(s >= 1))
+        torch.cuda.synchronize()
+        assert abs(float(out[0]) - ref) < 3e-3 * ref, (s, float(out[0]), ref)
+        assert abs(float(out[2]) - client.last_L0) < 3e-3 * abs(client.last_L0), (s, float(out[2]), client.last_L0)
+        assert abs(float(eng.acts["adapter_1"]["loss"][2]) - client.last_L1) < 3e-3 * abs(client.last_L1), s
+    sd = eng.state_dict()
+    worst = 0.0
+    for k in A.trainable_names(P, 0) + A.trainable_names(P, 1):
+        d_ref, d_got = P[k] - P0[k], sd[k].cpu() - P0[k]
+        err, move = (d_got - d_ref).abs(), float(d_ref.abs().mean())
+        assert float(err.max()) < 1e-3 and float(err.mean()) <= 0.1 * move, (k, float(err.max()), float(err.mean()), move)
+        worst = max(worst, float(err.mean()) / move)
+    print(f"ALBEF variable-shape batches in a [3, 16] / [9, 7] frame, 4 steps: worst mean ratio {worst:.3f}")
+    with pytest.raises(Exception):
+        eng.set_batch(_dev(A.synthetic_batch(3, d, 1, q_len=17, a_len=5, k=[2, 1, 3])))
+
+
+def test_model_takes_question_and_answer_strings(eng_mod, golden_dir):
+    """ALBEFContinualLearner.forward / AlbefTaskTrainer.train_step on the reference's batch (albef.py:275-286: images tensor,
+    questions, answers, weights, n): the device WordPiece tokenizer (G9 vocabulary) + the frame embedding give what the oracle
+    computes from the oracle tokenizer's (HF-pinned) encodings padded to the longest of the batch."""
+    import types
+    from feddat_amd import albef_modeling, train
+    from oracle import wordpiece_oracle as W
+    g9 = load(golden_dir, "g9_wordpiece.npz")
+    vocab = str(g9["vocab"]).split("\n")
+    index = {t: i for i, t in enumerate(vocab)}
+    texts = [t for t in str(g9["texts"]).split("\x1e") if t.isascii() and 0 < len(t) < 120]
+    dims = dict(SMALL, vocab=max(SMALL["vocab"], len(vocab)))
+    d = A.AlbefDims(**dims)
+    P = A.make_params(d)
+    P0 = {k: v.clone() for k, v in P.items()}
+    model = albef_modeling.create_albef_continual_learner_model(P, DEV, 3, 8, q_len=25, a_len=8, vocab=vocab,
+                                                                **{k: v for k, v in dims.items() if k != "max_pos"})
+    gen = torch.Generator().manual_seed(4)
+
+    def raw(i):
+        qs = texts[3 * i:3 * i + 3]
+        ans = [" ".join(t.split()[:2]) or "yes" for t in texts[30 + 6 * i:30 + 6 * i + 6]]
+        return {"images": torch.randn(3, 3, dims["image"], dims["image"], generator=gen), "questions": qs, "answers": ans,
+                "weights": torch.rand(6, generator=gen) + 0.5, "n": [2, 1, 3], "alpha": 0.0}
+
+    def oracle_batch(r):
+        qi, qm, _ = W.encode_batch(r["questions"], index, 25)
+        ai, am, _ = W.encode_batch(r["answers"], index, 64)
+        return {"image": r["images"], "question_ids": torch.from_numpy(qi).long(), "question_mask": torch.from_numpy(qm).long(),
+                "answer_ids": torch.from_numpy(ai).long(), "answer_mask": torch.from_numpy(am).long(), "weights": r["weights"],
+                "k": r["n"]}
+    r0 = raw(0)
+    enc = model.process_inputs(dict(r0, train=True))
+    ob = oracle_batch(r0)
+    for k in ("question_ids", "question_mask", "answer_ids", "answer_mask"):
+        assert torch.equal(enc[k].cpu(), ob[k]), k
+    model.deactivate_gating()
+    model.set_active_adapter("adapter_1")
+    loss, logits = model("art", dict(r0, train=True))
+    with torch.no_grad():
+        ol, olg = A.albef_train_forward(P, d, ob, "adapter_1")
+    assert logits.shape == olg.shape and (logits.cpu() - olg).abs().max() < 5e-2 and abs(float(loss) - float(ol)) < 3e-3 * float(ol)
+    args = types.SimpleNamespace(local_epochs=1, num_epochs=15, lr=1e-4, optimizer_mode="dat", debug=0, hip_graph=True)
+    raws = [raw(i) for i in range(1, 4)]
+    lists = [[r["images"], r["questions"], r["answers"], r["weights"], r["n"], 0.0] for r in raws]     # the collated form
+    tr = train.AlbefTaskTrainer(args, "art", lists, [])
+    tr.train(model)
+    torch.cuda.synchronize()
+    client = A.AlbefDatClient(P, d, lr=1e-4, steps_per_epoch=3)
+    for r in raws:
+        client.train_step(oracle_batch(r))
+    sd = model.state_dict()
+    for k in A.trainable_names(P, 0) + A.trainable_names(P, 1):
+        d_ref, d_got = P[k] - P0[k], sd[k].cpu() - P0[k]
+        err, move = (d_got - d_ref).abs(), float(d_ref.abs().mean())
+        assert float(err.max()) < 1e-3 and float(err.mean()) <= 0.1 * move, (k, float(err.max()), float(err.mean()), move)
