@@ -24,9 +24,9 @@ class ALBEFContinualLearner:
     BERT_LOCAL_PATH = "./models/bert-base-uncased"       # albef.py:38
 
     def __init__(self, params: Dict[str, torch.Tensor], device, batch_size: int, n_answers: int, q_len: int = 25,
-                 a_len: int = 4, lr: float = 1e-4, vocab=None, **dims):
+                 a_len: int = 4, lr: float = 1e-4, tokenizer_vocab=None, **dims):
         self.device = torch.device(device)
-        self._vocab, self._tokenizer = vocab, None
+        self._vocab, self._tokenizer = tokenizer_vocab, None
         self.engine = AlbefDatEngine(params, self.device, batch=batch_size, n_answers=n_answers, q_len=q_len, a_len=a_len,
                                      lr=lr, **dims)
         self.gating, self.active = False, "adapter_1"
@@ -75,8 +75,8 @@ class ALBEFContinualLearner:
                 vocab = os.path.join(self.BERT_LOCAL_PATH, "vocab.txt")
                 if not os.path.exists(vocab):
                     raise L.FeddatHipError(
-                        f"questions / answers were given as strings but there is no BERT vocabulary: pass vocab=<vocab.txt path "
-                        f"or token list>, or place bert-base-uncased at {self.BERT_LOCAL_PATH} as the reference does")
+                        f"questions / answers were given as strings but there is no BERT vocabulary: pass tokenizer_vocab=<vocab.txt "
+                        f"path or token list>, or place bert-base-uncased at {self.BERT_LOCAL_PATH} as the reference does")
             self._tokenizer = WordPieceTokenizer(vocab, self.device)
         return self._tokenizer
 
@@ -133,11 +133,11 @@ class ALBEFContinualLearner:
 
 
 def create_albef_continual_learner_model(params: Dict[str, torch.Tensor], device, batch_size: int, n_answers: int,
-                                         q_len: int = 25, a_len: int = 4, lr: float = 1e-4, vocab=None,
+                                         q_len: int = 25, a_len: int = 4, lr: float = 1e-4, tokenizer_vocab=None,
                                          **dims) -> ALBEFContinualLearner:
     """albef.py:255-273 (the ALBEF.pth checkpoint is passed in as a tensor dict: feddat_amd.weights.load_albef_pretrained
     reads it from a local file; there is no hub access here)."""
-    return ALBEFContinualLearner(params, device, batch_size, n_answers, q_len, a_len, lr, vocab=vocab, **dims)
+    return ALBEFContinualLearner(params, device, batch_size, n_answers, q_len, a_len, lr, tokenizer_vocab=tokenizer_vocab, **dims)
 
 
 def convert_batch_to_albef_input_dict(batch):

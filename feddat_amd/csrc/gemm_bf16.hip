@@ -1180,6 +1180,84 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(GemmArgs g, c
     }
 }
 
+// The same products in ONE launch (round 4): a block = 16 output columns x all (<= 64) rows, its up to 16 waves split K in
+// 64-deep slices and are summed through LDS in wave order, wave 0 applies the epilogue -- no fp32 partials in HBM, no
+// second kernel (the split-K pair cost 13-15 us per product in the step, 2 graph nodes; this form 6-8 us, 1 node).
+// N / 16 blocks (48 for N = 768, 192 for N = 3072) keep the weight stream spread over the chip.
+constexpr int SKF_NW = 16;
+__global__ __launch_bounds__(SKF_NW * 64) void gemm_skinny_fused_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[SKF_NW - 1][64][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fg = lane >> 4, i16 = lane & 15;
+    const int n0 = blockIdx.x * 16;
+    const int nslice = g.K / 64;                       // 64-deep k slices, dealt round-robin to the waves
+    const bf16* wrow = g.B + (size_t)(n0 + i16) * g.ldb + fg * 8;
+    const bf16* arow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) arow[mt] = g.A + (size_t)min(mt * 16 + i16, g.M - 1) * g.lda + fg * 8;
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sl = wave; sl < nslice; sl += SKF_NW) {
+        const int k = sl * 64;
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wrow + k);
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wrow + k + 32);
+        bf16x8 a0[4], a1[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            a0[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k);
+            a1[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k + 32);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            acc[mt] = mfma16x32(w0, a0[mt], acc[mt]);
+            acc[mt] = mfma16x32(w1, a1[mt], acc[mt]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(&red[wave - 1][lane][4 * mt]) = acc[mt];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int nw = min(SKF_NW, nslice);
+#pragma unroll 1
+    for (int w = 1; w < nw; ++w)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = acc[mt] + *reinterpret_cast<const f32x4*>(&red[w - 1][lane][4 * mt]);
+    // lane: n = n0 + 4 fg + (0..3), m = 16 mt + i16
+    const int n = n0 + 4 * fg;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = mt * 16 + i16;
+        if (m >= g.M) continue;
+        const f32x4 v = acc[mt] + b4;
+        switch (g.epi) {
+            case FEDDAT_EPI_BF16:
+                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(v);
+                break;
+            case FEDDAT_EPI_RESID_F32:
+                *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) =
+                    v + *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n);
+                break;
+            case FEDDAT_EPI_GELU:
+                if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(v);
+                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(gelu4_pk(v));
+                break;
+            case FEDDAT_EPI_MUL_DGELU: {
+                const bf16x4 u = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)m * g.ldaux + n);
+                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) =
+                    cvt4(v * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]}));
+                break;
+            }
+            default:
+                *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v;
+        }
+    }
+}
+
 // split factor: a multiple-of-64 K slice and about two blocks per CU
 int skinny_ksplit(int N, int K) {
     const int nb = N / 64, kt = K / 64;
@@ -1217,6 +1295,10 @@ extern "C" int feddat_gemm_bf16_nt_skinny(const void* A, int lda, const void* B,
     g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out2_bf16 = (bf16*)out2_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;
     g.ldo32 = ldo32; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
+    if (!(fd_debug_flags() & 128)) {       // one launch: K split over the waves of a block (debug flag 128: the split-K pair)
+        hipLaunchKernelGGL(gemm_skinny_fused_kernel, dim3(N / 16), dim3(SKF_NW * 64), 0, stream, g);
+        FD_LAUNCH_RET();
+    }
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(N / 64, ksplit), dim3(256), 0, stream, g, workspace, K / ksplit);
     hipLaunchKernelGGL(gemm_skinny_epilogue_kernel, dim3((M * (N / 4) + 255) / 256), dim3(256), 0, stream, g,
                        (const float*)workspace, ksplit);

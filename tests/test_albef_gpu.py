@@ -340,13 +340,13 @@ def test_model_takes_question_and_answer_strings(eng_mod, golden_dir):
     d = A.AlbefDims(**dims)
     P = A.make_params(d)
     P0 = {k: v.clone() for k, v in P.items()}
-    model = albef_modeling.create_albef_continual_learner_model(P, DEV, 3, 8, q_len=25, a_len=8, vocab=vocab,
+    model = albef_modeling.create_albef_continual_learner_model(P, DEV, 3, 8, q_len=25, a_len=16, tokenizer_vocab=vocab,
                                                                 **{k: v for k, v in dims.items() if k != "max_pos"})
     gen = torch.Generator().manual_seed(4)
 
     def raw(i):
-        qs = texts[3 * i:3 * i + 3]
-        ans = [" ".join(t.split()[:2]) or "yes" for t in texts[30 + 6 * i:30 + 6 * i + 6]]
+        qs = [texts[(3 * i + j) % len(texts)] for j in range(3)]
+        ans = [" ".join(texts[(7 + 6 * i + j) % len(texts)].split()[:2]) or "yes" for j in range(6)]
         return {"images": torch.randn(3, 3, dims["image"], dims["image"], generator=gen), "questions": qs, "answers": ans,
                 "weights": torch.rand(6, generator=gen) + 0.5, "n": [2, 1, 3], "alpha": 0.0}
 
@@ -370,6 +370,7 @@ def test_model_takes_question_and_answer_strings(eng_mod, golden_dir):
     args = types.SimpleNamespace(local_epochs=1, num_epochs=15, lr=1e-4, optimizer_mode="dat", debug=0, hip_graph=True)
     raws = [raw(i) for i in range(1, 4)]
     lists = [[r["images"], r["questions"], r["answers"], r["weights"], r["n"], 0.0] for r in raws]     # the collated form
+    model.adapter_requires_grad = {0: True, 1: True, 2: False}      # (set_active_adapter above froze adapter_0: adapter.py:79-85)
     tr = train.AlbefTaskTrainer(args, "art", lists, [])
     tr.train(model)
     torch.cuda.synchronize()

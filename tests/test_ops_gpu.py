@@ -901,6 +901,15 @@ def test_gemm_skinny_all_epilogues(L, M, N, K):
     assert (o16.float() - ref * u.grad).abs().max() < tol
     L.gemm_bf16_nt(A, Bw, L.EPI_F32, out_f32=o32, skinny_workspace=ws)
     assert (o32 - ref).abs().max() < 1e-3 * ref.abs().max().item() + 1e-4
+    # the one-launch form (K split over the waves of a block) against the split-K + epilogue pair it replaced (debug flag 128)
+    o32b = torch.zeros(M, N, device=DEV)
+    L.set_debug_flags(128)
+    try:
+        L.gemm_bf16_nt(A, Bw, L.EPI_RESID_F32, bias=bias, resid=resid, out_f32=o32b, skinny_workspace=ws)
+    finally:
+        L.set_debug_flags(0)
+    L.gemm_bf16_nt(A, Bw, L.EPI_RESID_F32, bias=bias, resid=resid, out_f32=o32, skinny_workspace=ws)
+    assert (o32 - o32b).abs().max() < 2e-5 * ref.abs().max().item() + 1e-5
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(11840, 3072, 768, 2), (11840, 768, 3072, 1), (5920, 2304, 768, 0)])
