@@ -267,11 +267,20 @@ def gather_ranks(tr, B, world, rank, dist, dev):
 
 
 def round_split(rows, dt):
+    """+ `hetero_bound`: with K = N heterogeneous clients every rank waits at the all-reduce for the one with the most steps,
+    so N ranks can deliver at most sum(steps) / max(steps) ranks' worth of work per round (SURVEY 8d config 3's
+    len(loader) in {40..80} on 8 ranks: 5.625 of 8 = 0.70; homogeneous: N) -- `scaling_x_bound` is what a reading of the
+    N-GPU value / the 1-GPU value has to be compared with, `efficiency_vs_bound` how much of it the run delivered."""
     if rows is None:
         return None
+    steps = [r["steps"] for r in rows]
+    bound = sum(steps) / max(steps)
+    busy = sum(r["compute_s"] for r in rows)
     return {"round_s": round(dt, 4), "compute_s_max": max(r["compute_s"] for r in rows),
             "compute_s_min": min(r["compute_s"] for r in rows), "wait_s_mean": round(sum(r["wait_s"] for r in rows) / len(rows), 4),
-            "allreduce_ms_max": max(r["allreduce_ms"] for r in rows)}
+            "allreduce_ms_max": max(r["allreduce_ms"] for r in rows),
+            "hetero_bound": {"scaling_x_bound": round(bound, 3), "round_efficiency_bound": round(bound / len(rows), 3),
+                             "efficiency_vs_bound": round(busy / (dt * bound), 3) if dt > 0 else None}}
 
 
 def albef_roofline(L, eng, batches):
