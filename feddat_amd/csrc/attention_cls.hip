@@ -3,7 +3,7 @@
 // live -- ONE query per (sample, head) in the forward, and in the backward a gradient that is non-zero on that one row of
 // dctx.  Everything is rank-1 then: scores s_k = q0 . K_k / 8, p = softmax(s + mask), ctx_0 = sum_k p_k V_k;
 //   D = dO . O,  dP_k = dO . V_k,  dS_k = p_k (dP_k - D),  dV_k = p_k dO,  dK_k = dS_k q0 / 8,  dQ_0 = sum_k dS_k K_k / 8,
-// dQ_k = 0 for k > 0.  No MFMA: one wave per (sample, head), fp32 VALU on the bf16 operands, HBM-bound (K and V of the pair
+// dQ_k = 0 for k > 0.  No MFMA: one block per (sample, head), 8 lanes per key row (whole 128-byte rows per instruction), fp32 VALU on the bf16 operands, HBM-bound (K and V of the pair
 // once in the forward; K, V once and the three dqkv slices once in the backward) -- against 21 / 41 us for the dense kernels
 // computing 185 queries of which 184 are never read.  Same operand layout as attention.hip: qkv bf16 [B*S, 3*H],
 // columns [Q | K | V], head h at columns 64 h of each part.
@@ -12,182 +12,188 @@
 namespace {
 
 constexpr int D = 64;
-constexpr int MAXK = 5;      // keys per lane: S <= 320
+constexpr int SMAX = 320;
 
-__device__ __forceinline__ void load_row64(const bf16* p, float (&o)[D]) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[c * 8 + e] = (float)v[e];
-    }
+// Lane layout of both kernels: 8 lanes per key row (lane & 7 = which 16-byte chunk of the 128-byte head slice), 8 keys per
+// wave-instruction (lane >> 3), so every load / store instruction moves 8 whole 128-byte rows; a dot product over the 64
+// features is 8 FMAs per lane + 3 shuffles.  4 waves per block = 32 keys per sweep; one block per (sample, head).
+__device__ __forceinline__ float sum8(float v) {        // over the 8 lanes of a key row
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+__device__ __forceinline__ float sum_keys(float v) {    // over the 8 key slots of a wave (same chunk lane)
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* red, int tid) {
+    v = wave_max(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
 }
 
-// 4 waves per block, one (sample, head) pair per wave
 __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask,
-                                                           bf16* __restrict__ ctx, float* __restrict__ lse, int npairs,
-                                                           int S, int heads) {
-    __shared__ float pbuf[4][MAXK * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pair = blockIdx.x * 4 + wave;
-    if (pair >= npairs) return;
-    const int b = pair / heads, h = pair - b * heads;
+                                                           bf16* __restrict__ ctx, float* __restrict__ lse, int S,
+                                                           int heads) {
+    __shared__ float pbuf[SMAX], red[4], part[4][D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = lane & 7, slot = tid >> 3;           // chunk of the row, key slot in the block (0..31)
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const int H = heads * D;
     const long ld = 3L * H;
-    const bf16* base = qkv + (size_t)b * S * ld + h * D;
-    float q[D];
-    load_row64(base, q);                    // token 0's query: every lane holds it
-    float s[MAXK];
+    const bf16* base = qkv + (size_t)b * S * ld + h * D + ch * 8;
+    float q[8];
+    {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(base);      // token 0's query, this lane's chunk
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = (float)v[e];
+    }
     float mx = -INFINITY;
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        const int k = k0 + slot;
+        float sc = -INFINITY;
+        if (k < S) {
+            const bf16x8 kr = *reinterpret_cast<const bf16x8*>(base + (size_t)k * ld + H);
+            float a = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < MAXK; ++kk) {
-        const int k = lane + 64 * kk;
-        s[kk] = -INFINITY;
-        if (k < S && (!kmask || kmask[(size_t)b * S + k])) {
-            float kr[D];
-            load_row64(base + (size_t)k * ld + H, kr);
-            float acc = 0.f;
-#pragma unroll
-            for (int d = 0; d < D; ++d) acc += q[d] * kr[d];
-            s[kk] = acc * 0.125f;
+            for (int e = 0; e < 8; ++e) a += q[e] * (float)kr[e];
+            a = sum8(a) * 0.125f;
+            if (!kmask || kmask[(size_t)b * S + k]) sc = a;
+            if (ch == 0) pbuf[k] = sc;
         }
-        mx = fmaxf(mx, s[kk]);
+        mx = fmaxf(mx, sc);
     }
-    mx = wave_max(mx);
+    mx = block_reduce_max(mx, red, tid);                // (its barriers publish pbuf)
     float sum = 0.f;
+    for (int k = tid; k < S; k += 256) {
+        const float e = __expf(pbuf[k] - mx);           // exp(-inf) = 0 for masked keys
+        pbuf[k] = e;
+        sum += e;
+    }
+    sum = block_reduce_sum(sum, red, tid);
+    float o[8];
 #pragma unroll
-    for (int kk = 0; kk < MAXK; ++kk) {
-        s[kk] = __expf(s[kk] - mx);         // exp(-inf) = 0 for masked / out-of-range keys
-        sum += s[kk];
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        const int k = k0 + slot;
+        if (k < S) {
+            const float p = pbuf[k];
+            const bf16x8 vr = *reinterpret_cast<const bf16x8*>(base + (size_t)k * ld + 2 * H);
 #pragma unroll
-    for (int kk = 0; kk < MAXK; ++kk) pbuf[wave][lane + 64 * kk] = s[kk] * inv;
-    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): the wave's own LDS writes before its reads (no other wave shares pbuf[wave])
-    __builtin_amdgcn_wave_barrier();
-    // ctx_0[d]: lane = (key parity, feature pair): 32 lanes x 4 bytes = one 128-byte V row per key
-    const int half = lane >> 5, dp = lane & 31;
-    float o0 = 0.f, o1 = 0.f;
-    const bf16* vb = base + 2 * H + 2 * dp;
-#pragma unroll 8
-    for (int k = half; k < S; k += 2) {
-        const float p = pbuf[wave][k];
-        const bf16x2 v = *reinterpret_cast<const bf16x2*>(vb + (size_t)k * ld);
-        o0 += p * (float)v[0];
-        o1 += p * (float)v[1];
+            for (int e = 0; e < 8; ++e) o[e] += p * (float)vr[e];
+        }
     }
-    o0 += __shfl_xor(o0, 32, 64);
-    o1 += __shfl_xor(o1, 32, 64);
-    if (half == 0) {
-        bf16x2 o = {(bf16)o0, (bf16)o1};
-        *reinterpret_cast<bf16x2*>(ctx + (size_t)b * S * H + h * D + 2 * dp) = o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = sum_keys(o[e]);
+        if (lane < 8) part[wave][lane * 8 + e] = t;
     }
-    if (lane == 0 && lse) lse[((size_t)b * heads + h) * S] = mx + __logf(sum);
+    __syncthreads();
+    if (tid < D) {
+        const float tot = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / sum;
+        ctx[(size_t)b * S * H + h * D + tid] = (bf16)tot;
+        if (tid == 0 && lse) lse[((size_t)b * heads + h) * S] = mx + __logf(sum);
+    }
 }
 
 // Backward: dctx0 fp32 [B, H] = gradient of token 0's context row; writes the pair's complete dqkv slices (dQ rows 1..S-1
 // are zeros: the dense QKV^T product that follows reads every row).
 __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask,
                                                            const bf16* __restrict__ ctx, const float* __restrict__ lse,
-                                                           const float* __restrict__ dctx0, bf16* __restrict__ dqkv,
-                                                           int npairs, int S, int heads) {
-    __shared__ float red[4][D][17];         // per-wave transpose buffer for the dQ_0 reduction over keys
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pair = blockIdx.x * 4 + wave;
-    if (pair >= npairs) return;
-    const int b = pair / heads, h = pair - b * heads;
+                                                           const float* __restrict__ dctx0, bf16* __restrict__ dqkv, int S,
+                                                           int heads) {
+    __shared__ float red[4], part[4][D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = lane & 7, slot = tid >> 3;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const int H = heads * D;
     const long ld = 3L * H;
-    const bf16* base = qkv + (size_t)b * S * ld + h * D;
-    bf16* dbase = dqkv + (size_t)b * S * ld + h * D;
-    float q[D], g[D];
-    load_row64(base, q);
-    float Dv = 0.f;
+    const bf16* base = qkv + (size_t)b * S * ld + h * D + ch * 8;
+    bf16* dbase = dqkv + (size_t)b * S * ld + h * D + ch * 8;
+    float q[8], g[8], dpart = 0.f;
     {
-        float o[D];
-        load_row64(ctx + (size_t)b * S * H + h * D, o);
-        const float* gp = dctx0 + (size_t)b * H + h * D;
+        const bf16x8 qv = *reinterpret_cast<const bf16x8*>(base);
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(ctx + (size_t)b * S * H + h * D + ch * 8);
+        const float* gp = dctx0 + (size_t)b * H + h * D + ch * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
-        for (int c = 0; c < D / 4; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(gp + 4 * c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                g[4 * c + e] = v[e];
-                Dv += v[e] * o[4 * c + e];
-            }
+        for (int e = 0; e < 8; ++e) {
+            q[e] = (float)qv[e];
+            g[e] = e < 4 ? g0[e] : g1[e - 4];
+            dpart += g[e] * (float)ov[e];
         }
     }
+    const float Dv = sum8(dpart);                       // D = dO . O (every 8-lane group holds the whole row)
     const float l0 = lse[((size_t)b * heads + h) * S];
-    float dq[D];
+    float dq[8];
 #pragma unroll
-    for (int d = 0; d < D; ++d) dq[d] = 0.f;
+    for (int e = 0; e < 8; ++e) dq[e] = 0.f;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-    for (int kk = 0; kk < MAXK; ++kk) {
-        const int k = lane + 64 * kk;
-        if (k >= S) break;
-        float kr[D], vr[D];
-        load_row64(base + (size_t)k * ld + H, kr);
-        load_row64(base + (size_t)k * ld + 2 * H, vr);
-        float sc = 0.f, dp = 0.f;
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        const int k = k0 + slot;
+        if (k < S) {
+            const bf16x8 kr = *reinterpret_cast<const bf16x8*>(base + (size_t)k * ld + H);
+            const bf16x8 vr = *reinterpret_cast<const bf16x8*>(base + (size_t)k * ld + 2 * H);
+            float sc = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            sc += q[d] * kr[d];
-            dp += g[d] * vr[d];
-        }
-        const bool ok = !kmask || kmask[(size_t)b * S + k];
-        const float p = ok ? __expf(sc * 0.125f - l0) : 0.f;
-        const float ds = p * (dp - Dv) * 0.125f;
-        bf16* ok_ = dbase + (size_t)k * ld + H;
-        bf16* ov_ = dbase + (size_t)k * ld + 2 * H;
-        bf16* oq_ = dbase + (size_t)k * ld;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
+            for (int e = 0; e < 8; ++e) {
+                sc += q[e] * (float)kr[e];
+                dp += g[e] * (float)vr[e];
+            }
+            sc = sum8(sc);
+            dp = sum8(dp);
+            const bool ok = !kmask || kmask[(size_t)b * S + k];
+            const float p = ok ? __expf(sc * 0.125f - l0) : 0.f;
+            const float ds = p * (dp - Dv) * 0.125f;
             bf16x8 dk8, dv8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                dk8[e] = (bf16)(ds * q[c * 8 + e]);
-                dv8[e] = (bf16)(p * g[c * 8 + e]);
-                dq[c * 8 + e] += ds * kr[c * 8 + e];
+                dk8[e] = (bf16)(ds * q[e]);
+                dv8[e] = (bf16)(p * g[e]);
+                dq[e] += ds * (float)kr[e];
             }
-            *reinterpret_cast<bf16x8*>(ok_ + c * 8) = dk8;
-            *reinterpret_cast<bf16x8*>(ov_ + c * 8) = dv8;
-            if (k > 0) *reinterpret_cast<bf16x8*>(oq_ + c * 8) = zero8;
+            *reinterpret_cast<bf16x8*>(dbase + (size_t)k * ld + H) = dk8;
+            *reinterpret_cast<bf16x8*>(dbase + (size_t)k * ld + 2 * H) = dv8;
+            if (k > 0) *reinterpret_cast<bf16x8*>(dbase + (size_t)k * ld) = zero8;
         }
     }
-    // dQ_0[d] = sum over lanes of dq[d]: 16-lane partial sums by shuffles, then 4 partials per d through LDS
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        float v = dq[d];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        if ((lane & 15) == 0) red[wave][d][lane >> 4] = v;
+    for (int e = 0; e < 8; ++e) {
+        const float t = sum_keys(dq[e]);
+        if (lane < 8) part[wave][lane * 8 + e] = t;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const float tot = (red[wave][lane][0] + red[wave][lane][1]) + (red[wave][lane][2] + red[wave][lane][3]);
-    dbase[lane] = (bf16)tot;                // row 0, feature d = lane
+    __syncthreads();
+    if (tid < D) dqkv[(size_t)b * S * ld + h * D + tid] = (bf16)((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
 }
 
 }  // namespace
 
 extern "C" int feddat_attn_cls_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
                                    hipStream_t stream) {
-    FD_CHECK_ARG(qkv && ctx && B > 0 && S > 0 && S <= 64 * MAXK && heads > 0);
-    const int np = B * heads;
-    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3((np + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, key_mask, (bf16*)ctx,
-                       lse, np, S, heads);
+    FD_CHECK_ARG(qkv && ctx && B > 0 && S > 0 && S <= SMAX && heads > 0);
+    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * heads), dim3(256), 0, stream, (const bf16*)qkv, key_mask, (bf16*)ctx, lse, S,
+                       heads);
     FD_LAUNCH_RET();
 }
 
 extern "C" int feddat_attn_cls_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse,
                                    const float* dctx0, void* dqkv, int B, int S, int heads, hipStream_t stream) {
-    FD_CHECK_ARG(qkv && ctx && lse && dctx0 && dqkv && B > 0 && S > 0 && S <= 64 * MAXK && heads > 0);
-    const int np = B * heads;
-    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3((np + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, key_mask,
-                       (const bf16*)ctx, lse, dctx0, (bf16*)dqkv, np, S, heads);
+    FD_CHECK_ARG(qkv && ctx && lse && dctx0 && dqkv && B > 0 && S > 0 && S <= SMAX && heads > 0);
+    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * heads), dim3(256), 0, stream, (const bf16*)qkv, key_mask,
+                       (const bf16*)ctx, lse, dctx0, (bf16*)dqkv, S, heads);
     FD_LAUNCH_RET();
 }

@@ -60,3 +60,43 @@ if out:
                 continue
             w.writerow([n, nd] + [round(sum(c[k]) / len(c[k]), 1) if k in c else "" for k in keys])
     print("wrote", f"profiles/{tag}_pmc_per_kernel.csv")
+
+
+# 3. ALBEF (configs[3]): kernel-trace summary + PMC passes of `bench.py --workload albef`
+st = f"gpurun_out/prof_{tag}/albef_trace/step_kernel_stats.csv"
+if os.path.exists(st):
+    rows = list(csv.DictReader(open(st)))
+    with open(f"profiles/{tag}_albef_kernel_stats.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"])
+        for r in rows:
+            if float(r["Percentage"]) < 0.05:
+                continue
+            w.writerow([short(r["Name"]), r["Calls"], round(float(r["TotalDurationNs"]) / 1e6, 3),
+                        round(float(r["AverageNs"]) / 1e3, 2), round(float(r["MinNs"]) / 1e3, 2),
+                        round(float(r["MaxNs"]) / 1e3, 2), r["Percentage"]])
+    print("wrote", f"profiles/{tag}_albef_kernel_stats.csv")
+out = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("albef_pmc_fetch_size", "albef_pmc_write_size"):
+    p = f"gpurun_out/prof_{tag}/{d}/p_counter_collection.csv"
+    if not os.path.exists(p):
+        continue
+    per_dispatch = collections.defaultdict(lambda: collections.defaultdict(float))
+    names = {}
+    for r in csv.DictReader(open(p)):
+        per_dispatch[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+    for did, c in per_dispatch.items():
+        for k, v in c.items():
+            out[names[did]][k].append(v)
+if out:
+    keys = sorted({k for c in out.values() for k in c})
+    with open(f"profiles/{tag}_albef_pmc_per_kernel.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches"] + [k + "_avg" for k in keys])
+        for n, c in sorted(out.items(), key=lambda x: -len(next(iter(x[1].values())))):
+            nd = max(len(v) for v in c.values())
+            if nd < 2:
+                continue
+            w.writerow([n, nd] + [round(sum(c[k]) / len(c[k]), 1) if k in c else "" for k in keys])
+    print("wrote", f"profiles/{tag}_albef_pmc_per_kernel.csv")
