@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(GemmArgs g, c
 // 64-deep slices and are summed through LDS in wave order, wave 0 applies the epilogue -- no fp32 partials in HBM, no
 // second kernel (the split-K pair cost 13-15 us per product in the step, 2 graph nodes; this form 6-8 us, 1 node).
 // N / 16 blocks (48 for N = 768, 192 for N = 3072) keep the weight stream spread over the chip.
-constexpr int SKF_NW = 16;
+constexpr int SKF_NW = 16, SKF_MAXSL = 3;
 __global__ __launch_bounds__(SKF_NW * 64) void gemm_skinny_fused_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float red[SKF_NW - 1][64][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1198,20 +1198,29 @@ __global__ __launch_bounds__(SKF_NW * 64) void gemm_skinny_fused_kernel(GemmArgs
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int sl = wave; sl < nslice; sl += SKF_NW) {
-        const int k = sl * 64;
-        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wrow + k);
-        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wrow + k + 32);
-        bf16x8 a0[4], a1[4];
+    // a wave's slices (<= SKF_MAXSL for K <= 3072; the loop covers longer K): ALL their loads are issued before the first MFMA
+    // -- these products are one chain of dependent load batches, so the batches must overlap, not follow each other
+    for (int sl0 = wave; sl0 < nslice; sl0 += SKF_NW * SKF_MAXSL) {
+        bf16x8 w0[SKF_MAXSL], w1[SKF_MAXSL], a0[SKF_MAXSL][4], a1[SKF_MAXSL][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            a0[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k);
-            a1[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k + 32);
+        for (int u = 0; u < SKF_MAXSL; ++u) {
+            const int k = min(sl0 + u * SKF_NW, nslice - 1) * 64;           // (clamped: the surplus loads are not used)
+            w0[u] = *reinterpret_cast<const bf16x8*>(wrow + k);
+            w1[u] = *reinterpret_cast<const bf16x8*>(wrow + k + 32);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                a0[u][mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k);
+                a1[u][mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k + 32);
+            }
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            acc[mt] = mfma16x32(w0, a0[mt], acc[mt]);
-            acc[mt] = mfma16x32(w1, a1[mt], acc[mt]);
+        for (int u = 0; u < SKF_MAXSL; ++u) {
+            if (sl0 + u * SKF_NW >= nslice) break;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc[mt] = mfma16x32(w0[u], a0[u][mt], acc[mt]);
+                acc[mt] = mfma16x32(w1[u], a1[u][mt], acc[mt]);
+            }
         }
     }
     if (wave > 0) {
