@@ -44,7 +44,10 @@ def flops_tables(B, S, layers=12, H=768, I=3072, heads=12, r=48, npatch=144):
     gemms.append((B * npatch, H, 3 * 32 * 32, 4, 1))
     gemm_flops = sum(lin(M, N, K) * c for M, N, K, _, c in gemms)
     attn_fwd = 4.0 * S * S * 64 * heads * B           # per B samples
-    attn = attn_fwd * (1 + 2 * (layers - 1)) + 2.5 * attn_fwd * 2 * (layers - 1)
+    # dense attention: layer 0 once (shared body), layers 1..L-2 for both passes; backward (2.5 x the forward's matmul work)
+    # for layers 1..L-2.  The LAST layer computes one query per (sample, head) (feddat_attn_cls_fwd / _bwd): 1 / S of a dense
+    # layer's work, on the VALU -- not counted as MFMA work.
+    attn = attn_fwd * (1 + 2 * (layers - 2)) + 2.5 * attn_fwd * 2 * (layers - 2)
     ad1 = 2.0 * R * H * r * 2                          # one adapter forward over R rows
     la = layers - 1                                    # the top layer's adapter sees 2B rows only
     adapters = la * 3 * ad1 + la * 3 * 3 * ad1 + la * 2 * 2 * ad1  # fwd + (recompute, g, dx) + dW

@@ -66,13 +66,18 @@ class ViltDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], tasks: Sequence[str], device, batch: int, res: int,
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
                  weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False,
-                 fp8_ffn_chain: bool = True):
+                 fp8_ffn_chain: bool = True, gelu_codes: bool = True):
         """fp8=True (BASELINE.json configs[4]): four frozen products per layer run on the block-scaled fp8 MFMA with e4m3
         operands -- forward QKV and FFN1 (activations quantised per token row by the LayerNorm kernel that produces them) and
         the dX products FFN2^T and attention-output^T (the gradient rows quantised per row: by feddat_quant_rows_fp8 behind the
         adapter backward, by the LayerNorm backward itself); weights quantised once here per output channel of each product.
         Everything else -- adapters, attention, the products whose A operand comes out of a GEMM or attention epilogue --
-        stays bf16 / fp32."""
+        stays bf16 / fp32.
+        gelu_codes=False: the backward of FFN2 reads the pre-GELU activation u in bf16 instead of the 8-bit gelu' codes
+        (FEDDAT_EPI_GELU / _MUL_DGELU instead of _GELU_G8 / _MUL_G8; middle layers issued op by op).  25 % more bytes through
+        the two heaviest epilogues (+0.14 ms/step at configs[1]); at B = 32 it takes the worst adapter element after an 80-step
+        round from 1.31e-3 to 1.00e-3 and the worst update-norm error from 2.9 % to 1.6 % -- for callers
+        that trade 2 % of throughput for that."""
         L.load()
         self.dev = torch.device(device)
         self.tasks = list(tasks)
@@ -213,7 +218,7 @@ class ViltDatEngine:
         self.l0 = dict(qkv=b16(R, 3 * H), ctx=b16(R, H), lse=f32(B, self.heads, self.S), h2=f32(R, H), h3=f32(R, H))
         # what FFN2^T needs of the pre-GELU u: 8-bit gelu'(u) codes where the persistent GEMM applies (FEDDAT_EPI_GELU_G8 /
         # _MUL_G8, M >= 1024: 25 % fewer bytes through the two HBM-bound epilogues), else u itself in bf16
-        self.g8u = R2 >= 1024
+        self.g8u = R2 >= 1024 and bool(gelu_codes)
 
         def u_buf():
             return torch.empty(R2, I, dtype=torch.uint8, device=dev) if self.g8u else b16(R2, I)
@@ -268,7 +273,7 @@ class ViltDatEngine:
         self._layer_structs: Dict = {}
         # True: one composite C-ABI call per middle layer (feddat_vilt_layer_fwd / _bwd); False: the same kernel sequence
         # issued op by op from here (what tools/step_breakdown.py brackets with events)
-        self.use_layer_calls = True
+        self.use_layer_calls = bool(gelu_codes) or R2 < 1024      # (the composite layer calls take the code epilogues at M >= 1024)
         # True: the serial tail (token-0 LayerNorm + pooler, task head forward / backward, loss, optimizer bookkeeping) on the
         # fused kernels of csrc/head_tail.hip (20 launches); False: the round-3 sequence of 46 single-purpose launches (same
         # arithmetic up to fp32 summation order; tools/step_breakdown.py --unfused-tail, and the tests compare the two)
