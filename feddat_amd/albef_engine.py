@@ -41,7 +41,7 @@ class AlbefDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], device, batch: int, n_answers: int, q_len: int = 25, a_len: int = 4,
                  vit_depth: int = 12, enc_layers: int = 12, fusion_layer: int = 6, dec_layers: int = 6, image: int = 384,
                  vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0,
-                 max_pos: int = 512, dropout: float = 0.0, seed: int = 0):
+                 max_pos: int = 512, dropout: float = 0.0, seed: int = 0, stack_text: bool = False):
         L.load()
         if not 0.0 <= dropout < 1.0:
             raise L.FeddatHipError("dropout must be in [0, 1)")
@@ -148,7 +148,19 @@ class AlbefDatEngine:
         # into the flat gradient buffers (feddat_adapter_wgrad_partial / _reduce) instead of one reduce launch per module
         self.wpart_stride = L.adapter_wgrad_workspace_elems(1)
         self.wpart = {m: torch.empty(len(self.modules) * self.wpart_stride, device=dev) for m in ("gating", "adapter_1")}
-        self._wg_done = {m: [] for m in ("gating", "adapter_1")}
+        self._wg_done = {m: [] for m in ("gating", "adapter_1", "both")}
+        # stack_text (round 4, OFF by default -- measured slower): with dropout = 0 the text towers of the gated and the
+        # adapter_1 pass are the same launches on different rows, so they can run ONCE on 2x the rows (rows [0, M) gated,
+        # [M, 2M) adapter_1 -- the ViLT engine's 2R-row batching; adapters, weight gradients and the two losses take
+        # two-segment descriptors): 366 -> 183 text-side GEMM launches per step, results equal to the two-pass form
+        # (tests/test_albef_gpu.py::test_stacked_text_towers_equal_the_two_separate_passes).  Under hipGraph replay it LOSES:
+        # 34.6 against 32.6 ms / step at B = 32 (same box, tools/albef_stack_ab.py) -- the two passes' small kernels already
+        # overlap each other on two streams, and a stacked launch of twice the rows costs more than one of the pair.  It
+        # stays as a switch because it halves the host launches of the eager (no-graph) step.
+        self.batch_text = bool(stack_text) and self.dropout <= 0
+        if self.batch_text:
+            self.wpart_stride2 = L.adapter_wgrad_workspace_elems(2)
+            self.wpart["both"] = torch.empty(len(self.modules) * self.wpart_stride2, device=dev)
         self.side = None           # second stream of train_step (created lazily on the engine's device)
         self.drop_ctr = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] = train_steps since begin_local_update
         self._alloc()
@@ -212,6 +224,16 @@ class AlbefDatEngine:
                         hsel=f32(self.R, H), hsel16=b16(self.R, H), tu=f32(self.R, H), tg=f32(self.R, H), tst=f32(self.R, 2),
                         ty16=b16(self.R, H), logits=f32(self.R, self.Vp), loss=f32(4 + 2 * self.R))
         self.acts = {"gating": act_set(), "adapter_1": act_set()}
+        # image_embeds of the two passes back to back: one K / V source for the batched text encoder's cross-attention
+        self.emb16_both = b16(2 * self.Mi, H)
+        self.acts["gating"]["vit"]["emb16"] = self.emb16_both[:self.Mi]
+        self.acts["adapter_1"]["vit"]["emb16"] = self.emb16_both[self.Mi:]
+        if self.batch_text:
+            R2 = 2 * self.R
+            self.acts["both"] = dict(enc=bert_set(2 * self.Mq, 2 * B, Lq, self.el, self.fl, 2 * self.Mi),
+                                     dec=bert_set(2 * self.Ma, 2 * N, La, self.dl, 0, 2 * N * Lq), enc_rep16=b16(2 * N * Lq, H),
+                                     hsel=f32(R2, H), hsel16=b16(R2, H), tu=f32(R2, H), tg=f32(R2, H), tst=f32(R2, 2),
+                                     ty16=b16(R2, H), logits=f32(R2, self.Vp))
         # backward scratch: one set per pass (their text-side backward passes run on two streams)
         Mmax = max(self.Mi, self.Mq, self.Ma, N * Lq, self.R)
 
@@ -221,6 +243,26 @@ class AlbefDatEngine:
                       z=f32(Mmax, self.r), dz=f32(Mmax, self.r), dsum=f32(max(B, N), self.heads, max(self.Ni, Lq, La)),
                       d_img=f32(self.Mi, H), d_qs=f32(self.Mq, H), d_rep=f32(N * Lq, H), d_dec=f32(self.Ma, H))
         self.gs = {"gating": scratch(), "adapter_1": scratch()}
+        if self.batch_text:
+            M2 = 2 * max(self.Mq, self.Ma, N * Lq, self.R)
+            self.gs["both"] = dict(dlogits=b16(2 * self.R, self.Vp), d1=f32(M2, H), d2=f32(M2, H), d3=f32(M2, H), d4=f32(M2, H),
+                                   b1=b16(M2, H), b2=b16(M2, H), bI=b16(M2, I), b3=b16(M2, 3 * H), bkv=b16(2 * max(self.Mi, N * Lq), 2 * H),
+                                   z=f32(M2, self.r), dz=f32(M2, self.r),
+                                   dsum=f32(2 * max(B, N), self.heads, max(self.Ni, Lq, La)), d_img=f32(2 * self.Mi, H),
+                                   d_qs=f32(2 * self.Mq, H), d_rep=f32(2 * N * Lq, H), d_dec=f32(2 * self.Ma, H))
+        # text-side inputs / index maps, per form: "single" = one pass (B questions, N answers), "both" = the two passes stacked
+        self.tx = {"single": dict(nq=B, na=N, Mq=self.Mq, Ma=self.Ma, R=self.R, q_ids=self.inp["question_ids"], q_tt=self.zero_tt_q,
+                                  a_ids=self.inp["answer_ids"], a_tt=self.zero_tt_a, qmask8=self.qmask8, amask8=self.amask8,
+                                  qmask8_rep=self.qmask8_rep, rep_idx=self.rep_idx, seg_off=self.seg_off, sel_idx=self.sel_idx,
+                                  unsel_idx=self.unsel_idx)}
+        if self.batch_text:
+            i64 = lambda *s_: torch.zeros(*s_, dtype=torch.int64, device=dev)      # noqa: E731
+            u8 = lambda *s_: torch.ones(*s_, dtype=torch.uint8, device=dev)        # noqa: E731
+            i32 = lambda *s_: torch.zeros(*s_, dtype=torch.int32, device=dev)      # noqa: E731
+            self.tx["both"] = dict(nq=2 * B, na=2 * N, Mq=2 * self.Mq, Ma=2 * self.Ma, R=2 * self.R, q_ids=i64(2 * B, Lq),
+                                   q_tt=i64(2 * B, Lq), a_ids=i64(2 * N, La), a_tt=i64(2 * N, La), qmask8=u8(2 * B, Lq),
+                                   amask8=u8(2 * N, La), qmask8_rep=u8(2 * N, Lq), rep_idx=i32(2 * N * Lq), seg_off=i32(2 * B + 1),
+                                   sel_idx=i32(2 * self.R), unsel_idx=i32(2 * self.Ma))
 
     # ------------------------------------------------------------------------------------------ adapters
     def _pack(self, a: int, m: int):
@@ -238,6 +280,12 @@ class AlbefDatEngine:
 
     def _segs(self, m: int, mode: str, rows: int, bwd: bool):
         key = (m, mode, rows, bwd)
+        if key not in self._segs_cache and mode == "both":       # rows [0, rows / 2) gated, [rows / 2, rows) adapter_1
+            h = rows // 2
+            ts = 0 if bwd else -1
+            self._segs_cache[key] = L.make_segs([
+                dict(row_begin=0, row_end=h, train_slot=ts, adapters=[dict(self._pack(0, m), scale=0.5), dict(self._pack(2, m), scale=0.5)]),
+                dict(row_begin=h, row_end=rows, train_slot=ts, adapters=[dict(self._pack(1, m), scale=1.0)])])
         if key not in self._segs_cache:
             if mode == "gating":
                 ads = [dict(self._pack(0, m), scale=0.5), dict(self._pack(2, m), scale=0.5)]
@@ -247,6 +295,17 @@ class AlbefDatEngine:
         return self._segs_cache[key]
 
     def _wgrad(self, m: int, mode: str, x, dy, rows: int):
+        if mode == "both":       # adapter_0 from the gated half (scale 0.5), adapter_1 from the other; both are optimised here
+            key = ("wg2", m, x.data_ptr(), dy.data_ptr(), rows)
+            if key not in self._segs_cache:
+                n, h, g = self.ad_numel, rows // 2, self.gs["both"]
+                self._segs_cache[key] = L.make_wgrad_segs([
+                    dict(x=x, dy=dy, z=g["z"], dz=g["dz"], grad=self.ad[0].g[m * n:(m + 1) * n], rows=h, scale=0.5),
+                    dict(x=x[h:], dy=dy[h:], z=g["z"][h:], dz=g["dz"][h:], grad=self.ad[1].g[m * n:(m + 1) * n], rows=h, scale=1.0)])
+            ws = self.wpart_stride2
+            L.adapter_wgrad_partial(self._segs_cache[key], self.wpart["both"][m * ws:(m + 1) * ws])
+            self._wg_done["both"].append(m)
+            return
         a = 0 if mode == "gating" else int(mode.split("_")[1])
         if a not in self.opt_adapters:
             return
@@ -264,6 +323,17 @@ class AlbefDatEngine:
         """Fold the partial sums of every module this backward pass produced into the adapter's gradient buffer (one launch)."""
         done, self._wg_done[mode] = self._wg_done[mode], []
         if not done:
+            return
+        if mode == "both":
+            ms = tuple(sorted(done))
+            key = ("wg-reduce2", ms)
+            if key not in self._segs_cache:
+                n = self.ad_numel
+                assert ms == tuple(range(ms[0], ms[0] + len(ms)))
+                ptrs = [self.ad[a].g[m * n:(m + 1) * n].data_ptr() for m in ms for a in (0, 1)]
+                self._segs_cache[key] = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
+            ws = self.wpart_stride2
+            L.adapter_wgrad_reduce(self._segs_cache[key], len(ms), 2, self.wpart["both"][ms[0] * ws:], ws)
             return
         a = 0 if mode == "gating" else int(mode.split("_")[1])
         ms = tuple(sorted(done))
@@ -361,10 +431,22 @@ class AlbefDatEngine:
             rk = torch.zeros(N, La - 1)
             rk[:n, :la - 1] = float(N) / float(n)
             self.row_kl.copy_(rk.reshape(-1))
+            if self.batch_text:       # the same maps for the stacked passes: the second pass's rows sit behind the first's
+                tb = self.tx["both"]
+                rep, off = self.rep_idx.cpu(), self.seg_off.cpu()
+                tb["rep_idx"].copy_(torch.cat([rep, rep + self.Mq]))
+                tb["seg_off"].copy_(torch.cat([off[:B], off + N]))
+                tb["sel_idx"].copy_(torch.cat([sel, sel + self.Ma]).int())
+                tb["unsel_idx"].copy_(torch.cat([un, torch.where(un >= 0, un + self.R, un)]))
         # masks, labels and per-row weights of this batch (tiny integer work on the device tensors)
         self.qmask8.copy_(self.inp["question_mask"])
         self.amask8.copy_(self.inp["answer_mask"])
         self.qmask8_rep.copy_(self.qmask8[self.qof])
+        if self.batch_text:
+            tb = self.tx["both"]
+            for dst, src in ((tb["q_ids"], self.inp["question_ids"]), (tb["a_ids"], self.inp["answer_ids"]), (tb["qmask8"], self.qmask8),
+                             (tb["amask8"], self.amask8), (tb["qmask8_rep"], self.qmask8_rep)):
+                dst.view(2, *src.shape).copy_(src.unsqueeze(0).expand(2, *src.shape))
         ids = self.inp["answer_ids"]
         lab = ids[:, 1:].masked_fill(ids[:, 1:] == self.pad_id, -100)
         if not full:
@@ -464,26 +546,27 @@ class AlbefDatEngine:
         return self._forward_text(mode, pass_id)
 
     def _forward_text(self, mode: str, pass_id=None):
-        """Everything behind the image encoder: text encoder with cross-attention, answer decoder, LM head."""
+        """Everything behind the image encoder: text encoder with cross-attention, answer decoder, LM head.  mode "both":
+        the gated and the adapter_1 pass stacked (rows of the gated pass first) over the stacked image_embeds."""
         S = self.acts[mode]
-        B, N, Lq, La, H = self.B, self.N, self.Lq, self.La, self.H
+        t = self.tx["both" if mode == "both" else "single"]
+        emb16 = self.emb16_both if mode == "both" else S["vit"]["emb16"]
+        Lq, La, H = self.Lq, self.La, self.H
         E, D = S["enc"], S["dec"]
-        self._embed(self.enc, self.inp["question_ids"], self.zero_tt_q, B, Lq, E["h"], E["h16"],
-                    self._drop(pass_id, 0, 0, "emb"))
-        qs, _ = self._bert_fwd(self.enc, E, self.vd, mode, self.Mq, B, Lq, self.qmask8, False, S["vit"]["emb16"], self.Ni,
+        self._embed(self.enc, t["q_ids"], t["q_tt"], t["nq"], Lq, E["h"], E["h16"], self._drop(pass_id, 0, 0, "emb"))
+        qs, _ = self._bert_fwd(self.enc, E, self.vd, mode, t["Mq"], t["nq"], Lq, t["qmask8"], False, emb16, self.Ni,
                                self.Ni, None, pass_id, 0)
         # one question's states for each of its k answers (albef_model.py:93-98)
-        L.gather_rows(qs, self.rep_idx, dst_bf16=S["enc_rep16"])
-        self._embed(self.dec, self.inp["answer_ids"], self.zero_tt_a, N, La, D["h"], D["h16"],
-                    self._drop(pass_id, 1, 0, "emb"))
-        out, _ = self._bert_fwd(self.dec, D, self.vd + self.el, mode, self.Ma, N, La, self.amask8, True, S["enc_rep16"], Lq,
-                                Lq, self.qmask8_rep, pass_id, 1)
+        L.gather_rows(qs, t["rep_idx"], dst_bf16=S["enc_rep16"])
+        self._embed(self.dec, t["a_ids"], t["a_tt"], t["na"], La, D["h"], D["h16"], self._drop(pass_id, 1, 0, "emb"))
+        out, _ = self._bert_fwd(self.dec, D, self.vd + self.el, mode, t["Ma"], t["na"], La, t["amask8"], True, S["enc_rep16"], Lq,
+                                Lq, t["qmask8_rep"], pass_id, 1)
         # BertOnlyMLMHead on the positions that predict a next token (logits[:, :-1])
         hd = self.head
-        L.gather_rows(out, self.sel_idx, dst_f32=S["hsel"], dst_bf16=S["hsel16"])
+        L.gather_rows(out, t["sel_idx"], dst_f32=S["hsel"], dst_bf16=S["hsel16"])
         L.gemm_bf16_nt(S["hsel16"], hd["t"]["w"], L.EPI_F32, bias=hd["t"]["b"], out_f32=S["tu"])
         L.gelu_fwd(S["tu"], S["tg"])
-        L.layernorm_fwd(S["tg"], hd["lng"], hd["lnb"], 1e-12, self.R, H, y_bf16=S["ty16"], stats=S["tst"])
+        L.layernorm_fwd(S["tg"], hd["lng"], hd["lnb"], 1e-12, t["R"], H, y_bf16=S["ty16"], stats=S["tst"])
         L.gemm_bf16_nt(S["ty16"], hd["w"], L.EPI_F32, bias=hd["b"], out_f32=S["logits"])
         return S["logits"]
 
@@ -577,25 +660,35 @@ class AlbefDatEngine:
         self._wgrad_reduce(mode)
 
     def _backward_text(self, mode: str, teacher_logits, pass_id=None):
-        """Loss, LM head, decoder and text encoder backward of the pass `mode`; leaves d(image_embeds) in its scratch set."""
+        """Loss, LM head, decoder and text encoder backward of the pass `mode`; leaves d(image_embeds) in its scratch set.
+        mode "both": the two passes stacked, each half's MKD teacher the OTHER half's logits (teacher_logits unused)."""
         S, g, hd, H = self.acts[mode], self.gs[mode], self.head, self.H
-        L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
-                          S["loss"], row_kl=self.row_kl)
-        R = self.R
+        t = self.tx["both" if mode == "both" else "single"]
+        R, R1 = t["R"], self.R
+        if mode == "both":       # L_0 = (loss_0 + KL(logits_0 || logits_1)) / 2 on rows [0, R), L_1 likewise on rows [R, 2R)
+            lg = S["logits"]
+            for half, own in ((0, "gating"), (1, "adapter_1")):
+                L.lm_loss_fwd_bwd(lg[half * R1:(half + 1) * R1], lg[(1 - half) * R1:(2 - half) * R1], self.labels, self.row_w, self.V,
+                                  3.0, 9.0 / self.N, g["dlogits"][half * R1:(half + 1) * R1], self.acts[own]["loss"],
+                                  row_kl=self.row_kl)
+        else:
+            L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
+                              S["loss"], row_kl=self.row_kl)
         # LM head backward (frozen): logits = LN(gelu(dense(h))) W_emb^T
         L.gemm_bf16_nt(g["dlogits"], hd["wT"], L.EPI_BF16, out_bf16=g["b1"][:R])
         L.layernorm_bwd_dx(S["tg"], S["tst"], hd["lng"], R, H, dy_bf16=g["b1"][:R], out_f32=g["d1"][:R])
         L.gelu_bwd(S["tu"], g["d1"][:R], g["d2"][:R])
         L.cvt_f32_bf16(g["d2"][:R], g["b1"][:R])
         L.gemm_bf16_nt(g["b1"][:R], hd["t"]["wT"], L.EPI_F32, out_f32=g["d1"][:R])
-        L.gather_rows(g["d1"][:R], self.unsel_idx, dst_f32=g["d_dec"])          # zero rows at the last position of each answer
+        L.gather_rows(g["d1"][:R], t["unsel_idx"], dst_f32=g["d_dec"])          # zero rows at the last position of each answer
         g["d_rep"].zero_()
-        self._bert_bwd(self.dec, S["dec"], self.vd + self.el, mode, self.Ma, self.N, self.La, self.amask8, True,
-                       S["enc_rep16"], self.Lq, self.Lq, self.qmask8_rep, g["d_dec"], g["d_rep"], pass_id, 1)
+        emb16 = self.emb16_both if mode == "both" else S["vit"]["emb16"]
+        self._bert_bwd(self.dec, S["dec"], self.vd + self.el, mode, t["Ma"], t["na"], self.La, t["amask8"], True,
+                       S["enc_rep16"], self.Lq, self.Lq, t["qmask8_rep"], g["d_dec"], g["d_rep"], pass_id, 1)
         # question states were repeated per answer: sum the answers of each question back (rows = [N, Lq * H])
-        L.segment_sum_rows(g["d_rep"].view(self.N, self.Lq * H), self.seg_off, g["d_qs"].view(self.B, self.Lq * H))
+        L.segment_sum_rows(g["d_rep"].view(t["na"], self.Lq * H), t["seg_off"], g["d_qs"].view(t["nq"], self.Lq * H))
         g["d_img"].zero_()
-        self._bert_bwd(self.enc, S["enc"], self.vd, mode, self.Mq, self.B, self.Lq, self.qmask8, False, S["vit"]["emb16"],
+        self._bert_bwd(self.enc, S["enc"], self.vd, mode, t["Mq"], t["nq"], self.Lq, t["qmask8"], False, emb16,
                        self.Ni, self.Ni, None, g["d_qs"], g["d_img"], pass_id, 0)
 
     # ------------------------------------------------------------------------------------------ train step
@@ -619,7 +712,7 @@ class AlbefDatEngine:
         self.drop_ctr.copy_(torch.tensor([(int(dropout_epoch) << 16) & 0x7FFFFFFF, 0], dtype=torch.int32))
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
-        sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.dropout)
+        sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.dropout, self.batch_text)
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig
@@ -641,6 +734,27 @@ class AlbefDatEngine:
             self.side = torch.cuda.Stream(device=self.dev)
         side = self.side
         drop = self.dropout > 0
+        if self.batch_text and self.opt_adapters == (0, 1):
+            # dropout = 0: the image encoders of the two passes side by side, then ONE text-side forward / backward over both
+            # passes' rows, then the two image-encoder backward passes side by side
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._vit_fwd(self.acts["gating"], "gating")
+            self._vit_fwd(self.acts["adapter_1"], "adapter_1")
+            cur.wait_stream(side)
+            self._forward_text("both")
+            self._backward_text("both", None)
+            d_img = self.gs["both"]["d_img"]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._vit_bwd(self.acts["gating"], "gating", d_img[:self.Mi])
+                self._wgrad_reduce("gating")
+            self._vit_bwd(self.acts["adapter_1"], "adapter_1", d_img[self.Mi:])
+            self._wgrad_reduce("adapter_1")
+            self._wgrad_reduce("both")
+            cur.wait_stream(side)
+            self._optimizer_tail(False)
+            return
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             if drop:
@@ -663,6 +777,9 @@ class AlbefDatEngine:
                                   self.acts["gating"]["loss"], row_kl=self.row_kl)
         self._backward("adapter_1", logits_teacher, 1 if drop else None)  # L_1 = (loss_1 + KL(logits_1 || logits_all)) / 2
         cur.wait_stream(side)
+        self._optimizer_tail(drop)
+
+    def _optimizer_tail(self, drop: bool):
         if 1 in self.opt_adapters:
             self._adamw(self.ad[1])
             self.repack_adapter(1)

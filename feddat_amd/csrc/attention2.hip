@@ -12,6 +12,8 @@
 // operand layout of the next product.
 #include "common.hip.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int D = 64;
@@ -64,6 +66,54 @@ __device__ __forceinline__ void chunk_commit(char* dst, int tid, const bf16x8 (&
         *reinterpret_cast<bf16x8*>(dst + sw_off(row, chunk)) = v[i];
     }
 }
+// The streamed side of a kernel: two operands (K and V, or Q and dO) of one head, 64-row chunks, two 16-byte pieces per
+// lane and operand.  The lane's row pointers ADVANCE chunk by chunk (no per-chunk address arithmetic), and only a chunk that
+// crosses the operand's last row takes the bounds-checked path (block-uniform branch): the loop around the products is
+// VALU-issue bound (three waves per SIMD share one VALU port), so every instruction outside the softmax counts.
+struct Stream2 {
+    const bf16 *pa, *pb;          // this lane's piece 0 of the NEXT chunk to fetch (piece 1: 32 rows further)
+    long step_a, step_b;          // elements per 32 rows
+    int next_row;                 // first row of that chunk
+    __device__ __forceinline__ void init(const bf16* A, long lda, const bf16* B, long ldb, int r0, int tid) {
+        const int row = tid >> 3, chunk = tid & 7;
+        pa = A + (size_t)(r0 + row) * lda + chunk * 8;
+        pb = B + (size_t)(r0 + row) * ldb + chunk * 8;
+        step_a = 32 * lda;
+        step_b = 32 * ldb;
+        next_row = r0;
+    }
+    __device__ __forceinline__ void fetch(int S, int tid, bf16x8 (&va)[2], bf16x8 (&vb)[2]) {
+        if (next_row + BLK <= S) {
+            va[0] = *reinterpret_cast<const bf16x8*>(pa);
+            va[1] = *reinterpret_cast<const bf16x8*>(pa + step_a);
+            vb[0] = *reinterpret_cast<const bf16x8*>(pb);
+            vb[1] = *reinterpret_cast<const bf16x8*>(pb + step_b);
+        } else {
+            const int row = next_row + (tid >> 3);
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            va[0] = va[1] = vb[0] = vb[1] = z;
+            if (row < S) {
+                va[0] = *reinterpret_cast<const bf16x8*>(pa);
+                vb[0] = *reinterpret_cast<const bf16x8*>(pb);
+            }
+            if (row + 32 < S) {
+                va[1] = *reinterpret_cast<const bf16x8*>(pa + step_a);
+                vb[1] = *reinterpret_cast<const bf16x8*>(pb + step_b);
+            }
+        }
+        pa += 2 * step_a;
+        pb += 2 * step_b;
+        next_row += BLK;
+    }
+};
+// LDS side: rows tid / 8 and tid / 8 + 32 of the chunk tile ((row + 32) & 7 == row & 7: one swizzled offset + 32 rows)
+__device__ __forceinline__ void chunk_commit2(char* da, char* db, int tid, const bf16x8 (&va)[2], const bf16x8 (&vb)[2]) {
+    const int off = sw_off(tid >> 3, tid & 7);
+    *reinterpret_cast<bf16x8*>(da + off) = va[0];
+    *reinterpret_cast<bf16x8*>(da + off + 32 * ROWB) = va[1];
+    *reinterpret_cast<bf16x8*>(db + off) = vb[0];
+    *reinterpret_cast<bf16x8*>(db + off + 32 * ROWB) = vb[1];
+}
 // a wave's [16][64] result tile in accumulator layout (row rowbase + i16, cols 16 dt + 4 g ..) goes to the staging tile,
 // which then leaves LDS row-contiguously
 __device__ __forceinline__ void put_acc(char* stg, int rowbase, int lane, const f32x4 (&o)[4], float mul) {
@@ -87,6 +137,23 @@ __device__ __forceinline__ void store_rows(bf16* __restrict__ dst, long ld, int 
     }
 }
 
+// XCD-aware work order.  The blocks of one (sample, head) -- its 64 QT-row blocks, 5 at 577 tokens -- all stream the SAME
+// K / V (or Q / dO) through LDS, and consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2:
+// in launch order the 5 blocks of a head sat on 5 different L2s and the streamed operand was fetched from HBM / MALL five
+// times.  Workgroup i (XCD i % 8, that XCD's (i / 8)-th workgroup) therefore takes work item start(i % 8) + i / 8, so every
+// XCD owns a contiguous range of (sample, head, block) items and the blocks of a head run back to back on one L2.
+__device__ __forceinline__ void xcd_work_item(int& x, int& y, int& z) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * (int)gridDim.z;
+    const int i = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int c = i & 7, q = total >> 3, r = total & 7;
+    const int w = c * q + (c < r ? c : r) + (i >> 3);
+    x = w % gx;
+    const int t = w / gx;
+    y = t % gy;
+    z = t / gy;
+}
+
 struct Attn2Args {
     const bf16 *q, *k, *v;
     long ldq, ldk, ldv;          // row strides (elements); head h at column 64 h
@@ -108,14 +175,16 @@ struct Attn2Args {
 // fragment of the streamed side read from LDS feeds QT MFMAs.  With QT = 1 a chunk costs the CU's one LDS pipe ~2x the
 // cycles its four MFMA pipes need (4 waves x (8 ds_read_b128 + 16 ds_read_b64_tr) against 16 MFMAs per wave); QT = 2 is
 // used for long sequences (577 image tokens), QT = 1 for the <= 64-row text streams.
-template <int QT, bool CAUSAL, bool DROP>
+template <int QT, bool CAUSAL, bool DROP, bool MASK = true>
 __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
+    static_assert(MASK || (!CAUSAL && !DROP), "the mask-free form is the plain one");
     constexpr int QB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
     __shared__ float mask_add[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qb, h, b;
+    xcd_work_item(qb, h, b);
     const int q0 = qb * QB;
     const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
@@ -123,8 +192,9 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
     const int kend = CAUSAL ? min(a.Skv, q0 + QB) : a.Skv;
     const FdDrop drop = DROP ? fd_drop_make(a.drop_p, a.dkey0, a.dkey1, a.dstep) : FdDrop{};
     bf16x8 kpre[2], vpre[2];
-    chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
-    chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
+    Stream2 kv;
+    kv.init(K, a.ldk, V, a.ldv, 0, tid);
+    kv.fetch(a.Skv, tid, kpre, vpre);
     load_rows<QB>(Q, a.ldq, q0, a.Sq, Qs, tid);
     __syncthreads();
     bf16x8 qf0[QT], qf1[QT];
@@ -142,48 +212,47 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int k0 = 0; k0 < kend; k0 += BLK) {
-        __syncthreads();
-        chunk_commit(Ks, tid, kpre);
-        chunk_commit(Vs, tid, vpre);
-        if (tid < BLK) {
-            const int kk = k0 + tid;
-            mask_add[tid] = (kk < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + kk])) ? 0.f : -INFINITY;
-        }
-        if (k0 + BLK < kend) {
-            chunk_fetch(K, a.ldk, k0 + BLK, a.Skv, tid, kpre);
-            chunk_fetch(V, a.ldv, k0 + BLK, a.Skv, tid, vpre);
-        }
-        __syncthreads();
-        f32x4 s[QT][4];
+    // One streamed chunk.  NKT = 16-key tiles of the chunk that hold keys at all (4; fewer on the LAST chunk: 577 image tokens
+    // = 9 chunks + 1 key, whose chunk costs a quarter), MASK = some key of the chunk may be hidden (key-padding mask, causal,
+    // or beyond S_kv).  Scores stay raw until the exponent: p = exp2(x * SC - m) is one FMA per element (packed pairs), the
+    // running maximum is taken on the raw scores (SC > 0) and scaled once per row.
+    auto do_chunk = [&](auto nkt_tag, auto mask_tag, const int k0) {
+        constexpr int NKT = decltype(nkt_tag)::value;
+        constexpr bool CMASK = decltype(mask_tag)::value;        // this chunk applies mask_add
+        constexpr int NST = (NKT + 1) / 2;
+        f32x4 s[QT][NKT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
             const bf16x8 kf0 = row_frag(Ks, kt * 16 + i16, g), kf1 = row_frag(Ks, kt * 16 + i16, 4 + g);
-            const f32x4 ma = *reinterpret_cast<const f32x4*>(mask_add + kt * 16 + 4 * g);
+            f32x4 ma = {0.f, 0.f, 0.f, 0.f};
+            if (CMASK) ma = *reinterpret_cast<const f32x4*>(mask_add + kt * 16 + 4 * g);
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x4 x = {0.f, 0.f, 0.f, 0.f};
                 x = mfma16x32(kf0, qf0[t], x);            // S^T: rows = keys kt*16 + 4g + e, col = query i16
                 x = mfma16x32(kf1, qf1[t], x);
+                if (CMASK) {
+                    x = x + ma;                            // 0 or -inf
+                    if (CAUSAL) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float y = x[e] * SC + ma[e];
-                    if (CAUSAL && k0 + kt * 16 + 4 * g + e > qi[t]) y = -INFINITY;
-                    x[e] = y;
+                        for (int e = 0; e < 4; ++e)
+                            if (k0 + kt * 16 + 4 * g + e > qi[t]) x[e] = -INFINITY;
+                    }
                 }
                 s[t][kt] = x;
             }
         }
-        bf16x8 pb[QT][2];
+        bf16x8 pb[QT][NST];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float cmx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cmx = fmaxf(cmx, s[t][kt][e]);
             cmx = fmaxf(cmx, __shfl_xor(cmx, 16, 64));
             cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
+            cmx *= SC;                                                      // log2 domain, like m
             // lazy running maximum: the reference point m only moves when the chunk's maximum exceeds it by more than 2^8
             // (probabilities stay <= 256, exact in fp32 / same relative rounding in bf16), so the rescale of l and of the 16
             // accumulator registers is skipped (wave-uniformly) in most chunks; o / l and the LSE do not depend on m
@@ -196,37 +265,56 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[t][dt] = o[t][dt] * f32x4{alpha, alpha, alpha, alpha};
             }
-            const float m_use = m[t] == -INFINITY ? 0.f : m[t];           // a fully masked prefix contributes nothing
-            float csum = 0.f;
+            const float nm = m[t] == -INFINITY ? 0.f : -m[t];             // a fully masked prefix contributes nothing
+            const f32x4 nm4 = {nm, nm, nm, nm}, sc4 = {SC, SC, SC, SC};
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < NKT; ++kt) {
+                const f32x4 y = s[t][kt] * sc4 + nm4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[t][kt][e] = __builtin_amdgcn_exp2f(s[t][kt][e] - m_use);
-                    csum += s[t][kt][e];
-                }
+                for (int e = 0; e < 4; ++e) s[t][kt][e] = __builtin_amdgcn_exp2f(y[e]);
+                cs = cs + s[t][kt];
+            }
+            float csum = (cs[0] + cs[1]) + (cs[2] + cs[3]);
             csum += __shfl_xor(csum, 16, 64);
             csum += __shfl_xor(csum, 32, 64);
             l[t] += csum;
             if (DROP) {      // softmax normalises over ALL keys (l above); the dropped, rescaled probabilities meet V
                 const uint32_t base = (uint32_t)(((size_t)(b * a.heads + h) * a.Sq + qi[t]) * a.Skv + k0 + 4 * g);
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         s[t][kt][e] = fd_drop_keep(drop, base + kt * 16 + e) ? s[t][kt][e] * drop.scale : 0.f;
             }
-            pb[t][0] = cvt8(s[t][0], s[t][1]);
-            pb[t][1] = cvt8(s[t][2], s[t][3]);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            pb[t][0] = cvt8(s[t][0], NKT > 1 ? s[t][NKT > 1 ? 1 : 0] : z4);
+            if (NST == 2) pb[t][NST - 1] = cvt8(s[t][NKT > 2 ? 2 : 0], NKT > 3 ? s[t][NKT > 3 ? 3 : 0] : z4);
         }
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < NST; ++st)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {                             // O^T[d][q] += V^T[d][key] P^T[key][q]
                 const bf16x8 vt = tr_frag8(Vs, st * 32 + 4 * g, st * 32 + 16 + 4 * g, dt * 16, lane);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) o[t][dt] = mfma16x32(vt, pb[t][st], o[t][dt]);
             }
+    };
+    // MASK = false (launcher: no key-padding mask, not causal, S_kv % 64 in [0, 16]): full chunks run without any masking and
+    // only the short last chunk looks at mask_add.  Two chunk bodies per kernel (more instantiations cost registers).
+    for (int k0 = 0; k0 < kend; k0 += BLK) {
+        __syncthreads();
+        chunk_commit2(Ks, Vs, tid, kpre, vpre);
+        const int rem = kend - k0;                 // keys of this chunk (block-uniform)
+        if ((MASK || rem < BLK) && tid < BLK) {
+            const int kk = k0 + tid;
+            mask_add[tid] = (kk < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + kk])) ? 0.f : -INFINITY;
+        }
+        if (k0 + BLK < kend) kv.fetch(a.Skv, tid, kpre, vpre);
+        __syncthreads();
+        using std::integral_constant;
+        if (rem <= 16) do_chunk(integral_constant<int, 1>{}, std::true_type{}, k0);
+        else do_chunk(integral_constant<int, 4>{}, integral_constant<bool, MASK>{}, k0);
     }
     __syncthreads();                                                     // Qs is reused as the output staging tile
 #pragma unroll
@@ -241,14 +329,16 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2Args a) {
 }
 
 // dQ (and D = rowsum(dO * O)) of one 64 QT-query block: K / V stream through LDS.
-template <int QT, bool CAUSAL, bool DROP>
+template <int QT, bool CAUSAL, bool DROP, bool MASK = true>
 __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
+    static_assert(MASK || (!CAUSAL && !DROP), "the mask-free form is the plain one");
     constexpr int QB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Qs[QB * ROWB], Gs[QB * ROWB], Ks[BLK * ROWB], Vs[BLK * ROWB];
     __shared__ float Dv[QB], kvalid[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qb, h, b;
+    xcd_work_item(qb, h, b);
     const int q0 = qb * QB;
     const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
@@ -258,8 +348,9 @@ __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
     const int kend = CAUSAL ? min(a.Skv, q0 + QB) : a.Skv;
     const FdDrop drop = DROP ? fd_drop_make(a.drop_p, a.dkey0, a.dkey1, a.dstep) : FdDrop{};
     bf16x8 kpre[2], vpre[2];
-    chunk_fetch(K, a.ldk, 0, a.Skv, tid, kpre);
-    chunk_fetch(V, a.ldv, 0, a.Skv, tid, vpre);
+    Stream2 kv;
+    kv.init(K, a.ldk, V, a.ldv, 0, tid);
+    kv.fetch(a.Skv, tid, kpre, vpre);
     load_rows<QB>(Q, a.ldq, q0, a.Sq, Qs, tid);
 #pragma unroll
     for (int idx = tid; idx < QB * 8; idx += 256) {          // dO -> LDS, D[q] = sum_d dO[q][d] O[q][d]
@@ -299,28 +390,28 @@ __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // MASK = false (no key-padding mask, not causal): no validity factor at all -- keys beyond S_kv are zero rows of the K
+    // tile, so whatever dS they get meets a zero row in dQ += dS K.  A last chunk of <= 32 keys (577 = 9 x 64 + 1) runs one
+    // of its two 32-key halves.
     for (int k0 = 0; k0 < kend; k0 += BLK) {
         __syncthreads();
-        chunk_commit(Ks, tid, kpre);
-        chunk_commit(Vs, tid, vpre);
-        if (tid < BLK) {
+        chunk_commit2(Ks, Vs, tid, kpre, vpre);
+        if (MASK && tid < BLK) {
             const int kk = k0 + tid;
             kvalid[tid] = (kk < a.Skv && (!a.kmask || a.kmask[(size_t)b * a.Skv + kk])) ? 1.f : 0.f;
         }
-        if (k0 + BLK < kend) {
-            chunk_fetch(K, a.ldk, k0 + BLK, a.Skv, tid, kpre);
-            chunk_fetch(V, a.ldv, k0 + BLK, a.Skv, tid, vpre);
-        }
+        if (k0 + BLK < kend) kv.fetch(a.Skv, tid, kpre, vpre);
         __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        const int nks = kend - k0 <= 32 ? 1 : 2;
+        for (int ks = 0; ks < nks; ++ks) {
             f32x4 ds[QT][2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int krow = (2 * ks + tt) * 16;
                 const bf16x8 kf0 = row_frag(Ks, krow + i16, g), kf1 = row_frag(Ks, krow + i16, 4 + g);
                 const bf16x8 vf0 = row_frag(Vs, krow + i16, g), vf1 = row_frag(Vs, krow + i16, 4 + g);
-                const f32x4 kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
+                f32x4 kv4 = {1.f, 1.f, 1.f, 1.f};
+                if (MASK) kv4 = *reinterpret_cast<const f32x4*>(kvalid + krow + 4 * g);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -330,7 +421,8 @@ __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
                     dp = mfma16x32(vf1, gf1[t], dp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float pe = kv4[e] * __builtin_amdgcn_exp2f(sc[e] * SC - lq[t]);
+                        float pe = __builtin_amdgcn_exp2f(sc[e] * SC - lq[t]);
+                        if (MASK) pe *= kv4[e];
                         if (CAUSAL && k0 + krow + 4 * g + e > qi[t]) pe = 0.f;
                         float dpe = dp[e];
                         if (DROP)      // dP = mask / (1 - p) . (dO V^T); D = rowsum(dO . O) already holds the dropped O
@@ -360,14 +452,16 @@ __global__ __launch_bounds__(256, 3) void attn2_bwd_dq_kernel(Attn2Args a) {
 }
 
 // dK, dV of one 64 QT-key block: Q / dO (and their LSE / D) stream through LDS.
-template <int QT, bool CAUSAL, bool DROP>
+template <int QT, bool CAUSAL, bool DROP, bool MASK = true>
 __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
+    static_assert(MASK || (!CAUSAL && !DROP), "the mask-free form is the plain one");
     constexpr int KB = BLK * QT;
     __shared__ __attribute__((aligned(16))) char Ks[KB * ROWB], Vs[KB * ROWB], Qs[BLK * ROWB], Gs[BLK * ROWB];
     __shared__ float Ls[BLK], Dv[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
-    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int kb, h, b;
+    xcd_work_item(kb, h, b);
     const int k0 = kb * KB;
     const bf16* Q = a.q + (size_t)b * a.sq_b * a.ldq + h * D;
     const bf16* K = a.k + (size_t)b * a.skv_b * a.ldk + h * D;
@@ -376,8 +470,9 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
     const int qstart = CAUSAL ? k0 : 0;                    // queries before the block's first key see none of it
     const FdDrop drop = DROP ? fd_drop_make(a.drop_p, a.dkey0, a.dkey1, a.dstep) : FdDrop{};
     bf16x8 qpre[2], gpre[2];
-    chunk_fetch(Q, a.ldq, qstart, a.Sq, tid, qpre);
-    chunk_fetch(G, a.lddo, qstart, a.Sq, tid, gpre);
+    Stream2 qg;
+    qg.init(Q, a.ldq, G, a.lddo, qstart, tid);
+    qg.fetch(a.Sq, tid, qpre, gpre);
     load_rows<KB>(K, a.ldk, k0, a.Skv, Ks, tid);
     load_rows<KB>(V, a.ldv, k0, a.Skv, Vs, tid);
     __syncthreads();
@@ -402,21 +497,17 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
     }
     for (int q0 = qstart; q0 < a.Sq; q0 += BLK) {
         __syncthreads();
-        chunk_commit(Qs, tid, qpre);
-        chunk_commit(Gs, tid, gpre);
+        chunk_commit2(Qs, Gs, tid, qpre, gpre);
         if (tid < BLK) {
             const int qq = q0 + tid;
             const size_t si = ((size_t)b * a.heads + h) * a.Sq + qq;
             Ls[tid] = qq < a.Sq ? a.lse[si] * LOG2E : INFINITY;          // rows past Sq: p = exp2(-inf) = 0
             Dv[tid] = qq < a.Sq ? a.dsum[si] : 0.f;
         }
-        if (q0 + BLK < a.Sq) {
-            chunk_fetch(Q, a.ldq, q0 + BLK, a.Sq, tid, qpre);
-            chunk_fetch(G, a.lddo, q0 + BLK, a.Sq, tid, gpre);
-        }
+        if (q0 + BLK < a.Sq) qg.fetch(a.Sq, tid, qpre, gpre);
         __syncthreads();
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
+        const int nqs = a.Sq - q0 <= 32 ? 1 : 2;                          // a last chunk of <= 32 queries: its second half is empty
+        for (int qs = 0; qs < nqs; ++qs) {
             f32x4 p[QT][2], ds[QT][2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -434,7 +525,8 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(Attn2Args a) {
                     dp = mfma16x32(gb2, vf1[t], dp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float pe = kv[t] * __builtin_amdgcn_exp2f(sc[e] * SC - l4[e]);
+                        float pe = __builtin_amdgcn_exp2f(sc[e] * SC - l4[e]);
+                        if (MASK) pe *= kv[t];                           // (without a mask: rows beyond S_kv are never stored)
                         if (CAUSAL && key[t] > q0 + qrow + 4 * g + e) pe = 0.f;
                         float mk = 1.0f;
                         if (DROP)
@@ -500,6 +592,11 @@ static int attn2_fwd_launch(Attn2Args& a, int B, hipStream_t stream) {
     if (rc) return rc;
     FD_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (size_t)B * a.heads * a.Sq * a.Skv < (1ull << 32));
     const dim3 grid2((a.Sq + 2 * BLK - 1) / (2 * BLK), a.heads, B), grid1((a.Sq + BLK - 1) / BLK, a.heads, B);
+    if (!a.kmask && !a.causal && !(a.drop_p > 0.f) && a.Skv % BLK <= 16) {      // the ViT's case: the mask-free instantiations
+        if (a.Sq > BLK) hipLaunchKernelGGL((attn2_fwd_kernel<2, false, false, false>), grid2, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_fwd_kernel<1, false, false, false>), grid1, dim3(256), 0, stream, a);
+        FD_LAUNCH_RET();
+    }
     if (a.Sq > BLK) FD_ATTN2_LAUNCH(attn2_fwd_kernel, 2, grid2);
     else FD_ATTN2_LAUNCH(attn2_fwd_kernel, 1, grid1);
     FD_LAUNCH_RET();
@@ -514,6 +611,14 @@ static int attn2_bwd_launch(Attn2Args& a, int B, hipStream_t stream) {
     const int Sq = a.Sq, Skv = a.Skv, heads = a.heads;
     const dim3 gq2((Sq + 2 * BLK - 1) / (2 * BLK), heads, B), gk2((Skv + 2 * BLK - 1) / (2 * BLK), heads, B),
         g1((Sq + BLK - 1) / BLK, heads, B), g1k((Skv + BLK - 1) / BLK, heads, B);
+    const bool plain = !a.kmask && !a.causal && !(a.drop_p > 0.f);      // the ViT's case: the mask-free instantiations
+    if (plain) {
+        if (Sq > BLK) hipLaunchKernelGGL((attn2_bwd_dq_kernel<2, false, false, false>), gq2, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_bwd_dq_kernel<1, false, false, false>), g1, dim3(256), 0, stream, a);
+        if (Skv > BLK) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<2, false, false, false>), gk2, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<1, false, false, false>), g1k, dim3(256), 0, stream, a);
+        FD_LAUNCH_RET();
+    }
     if (Sq > BLK) FD_ATTN2_LAUNCH(attn2_bwd_dq_kernel, 2, gq2);
     else FD_ATTN2_LAUNCH(attn2_bwd_dq_kernel, 1, g1);
     if (Skv > BLK) FD_ATTN2_LAUNCH(attn2_bwd_dkv_kernel, 2, gk2);

@@ -669,6 +669,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     using Cfg = V2Cfg<WM>;
     constexpr int NP = Cfg::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FEDDAT_ABLATE
+    // tools/gemm_dephase.py (timing probe): blocks start (bid / 8) % 4 x q x 2 us apart, so that the CUs' epilogues (HBM write
+    // bursts) stop coinciding
+    if (const int q = (a.dbg >> 24) & 7) {
+        const long t0 = wall_clock64(), d = (long)((blockIdx.x >> 3) & 3) * q * 200;
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const GemmArgs& g = a.g;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -926,6 +934,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     constexpr int NP = Cfg::NP, NM = 6 * RT;                  // MFMAs per k-half
     static_assert(3 * NP <= NM, "one filler per MFMA");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FEDDAT_ABLATE
+    // tools/gemm_dephase.py (timing probe): blocks start (bid / 8) % 4 x q x 2 us apart, so that the CUs' epilogues (HBM write
+    // bursts) stop coinciding
+    if (const int q = (a.dbg >> 24) & 7) {
+        const long t0 = wall_clock64(), d = (long)((blockIdx.x >> 3) & 3) * q * 200;
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const GemmArgs& g = a.g;
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -26,10 +26,10 @@ def eng_mod():
     return albef_engine
 
 
-def _small_engine(eng_mod, P, B, N, q_len, a_len):
+def _small_engine(eng_mod, P, B, N, q_len, a_len, **kw):
     return eng_mod.AlbefDatEngine(P, DEV, batch=B, n_answers=N, q_len=q_len, a_len=a_len, vit_depth=SMALL["vit_depth"],
                                   enc_layers=SMALL["enc_layers"], fusion_layer=SMALL["fusion_layer"],
-                                  dec_layers=SMALL["dec_layers"], image=SMALL["image"], vocab=SMALL["vocab"])
+                                  dec_layers=SMALL["dec_layers"], image=SMALL["image"], vocab=SMALL["vocab"], **kw)
 
 
 def test_small_forward_three_modes_vs_reference_and_oracle(eng_mod, golden_dir):
@@ -323,6 +323,44 @@ def test_batches_of_the_references_shape_inside_a_larger_frame(eng_mod):
     print(f"ALBEF variable-shape batches in a [3, 16] / [9, 7] frame, 4 steps: worst mean ratio {worst:.3f}")
     with pytest.raises(Exception):
         eng.set_batch(_dev(A.synthetic_batch(3, d, 1, q_len=17, a_len=5, k=[2, 1, 3])))
+
+
+def test_stacked_text_towers_equal_the_two_separate_passes(eng_mod):
+    """AlbefDatEngine(stack_text=True): the text encoder / decoder / LM head of the gated and the adapter_1 pass run once over
+    both passes' rows (two-segment adapters, weight gradients and losses).  Same launches on the same numbers per row, so the
+    result must equal the default two-stream form's up to the split-K / atomics order of a few kernels:
+    losses to 1e-5 relative, every trainable tensor's 3-step update to 2e-5 abs and 1 % of its mean move (variable-shape
+    batches inside a larger frame, eager then hipGraph)."""
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    engs = [_small_engine(eng_mod, P, 3, 9, 16, 7, stack_text=st) for st in (True, False)]
+    assert engs[0].batch_text and not engs[1].batch_text
+    shapes = [dict(q_len=12, a_len=5, k=[2, 1, 3]), dict(q_len=16, a_len=7, k=[3, 3, 3]), dict(q_len=9, a_len=4, k=[1, 2, 2])]
+    for e in engs:
+        e.begin_local_update(steps_per_epoch=3)
+    P0 = {k: v.clone() for k, v in engs[0].state_dict().items()}
+    for s, shp in enumerate(shapes):
+        b = _dev(A.synthetic_batch(3, d, 1700 + s, ragged=True, **shp))
+        outs = []
+        for e in engs:
+            out = e.train_step(b, use_graph=(s >= 1))
+            torch.cuda.synchronize()
+            outs.append((out.clone(), e.acts["adapter_1"]["loss"].clone()))
+        for j in range(2):
+            a, r = outs[0][j][:3], outs[1][j][:3]            # {loss, kl, L}
+            assert ((a - r).abs() <= 1e-5 * r.abs() + 1e-7).all(), (s, j, a, r)
+    sa, sb = engs[0].state_dict(), engs[1].state_dict()
+    worst = 0.0
+    for k in sa:
+        if "adapter_2" in k:
+            assert torch.equal(sa[k], sb[k])
+            continue
+        da, db = sa[k] - P0[k], sb[k] - P0[k]
+        err = (da - db).abs()
+        assert float(db.abs().max()) > 0, k
+        assert float(err.max()) < 2e-5 and float(err.mean()) <= 0.01 * float(db.abs().mean()), (k, float(err.max()), float(err.mean()))
+        worst = max(worst, float(err.max()))
+    print(f"stacked vs separate text passes, 3 steps: worst |ddW| {worst:.2e}")
 
 
 def test_model_takes_question_and_answer_strings(eng_mod, golden_dir):

@@ -1,0 +1,25 @@
+"""Same-box A/B of the ALBEF engine's stack_text switch (text towers of the two passes as one 2x-row launch list vs two
+streams): ms per hipGraph-replayed train_step at B = 32."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from feddat_amd import albef_engine, albef_spec
+B = 32
+params = albef_spec.random_init(seed=0, image=384)
+batches = [albef_spec.synthetic_batch(B, 1234 + i, image=384, device="cuda") for i in range(2)]
+res = {}
+for name, bt in (("stacked", True), ("separate", False), ("stacked", True), ("separate", False)):
+    eng = albef_engine.AlbefDatEngine(params, "cuda", batch=B, n_answers=B, image=384, stack_text=bt)
+    eng.begin_local_update(steps_per_epoch=100)
+    for i in range(5):
+        eng.train_step(batches[i % 2], use_graph=True)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for i in range(30):
+        eng.train_step(batches[i % 2], use_graph=True)
+    torch.cuda.synchronize()
+    print(name, f"{(time.perf_counter() - t) / 30 * 1e3:.3f} ms/step", flush=True)
+    del eng
