@@ -85,40 +85,82 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // kl = sum_v q_v (log q_v - log p_v), p = softmax(l / T), q = softmax(teacher / T);
 // dlogits = 0.5 * ( row_w * (softmax(l) - onehot) [label >= 0]  +  kl_scale / T * (p - q) ), stored as bf16 (the operand
 // of the LM-head backward GEMM), zeros in the padding columns [V, ldd).
-__global__ __launch_bounds__(256) void lm_loss_kernel(const float* __restrict__ logits, const float* __restrict__ teacher,
-                                                      long ldl, const long* __restrict__ labels,
-                                                      const float* __restrict__ row_w, const float* __restrict__ row_kl,
-                                                      int V, float T, float kl_scale, bf16* __restrict__ dlogits, long ldd,
-                                                      float* __restrict__ row_terms) {
-    __shared__ float red[4];
+// 1024 threads per row, 16-byte loads (rows are 16-byte aligned: ldl % 4 == 0 is checked by the launcher): with 256 threads
+// and scalar loads the three passes over 30 522 columns were 360 dependent load -> exp iterations per thread (206 us for
+// the 96 rows of the bench configuration, on the critical path between the forward and the backward pass).
+constexpr int LM_NT = 1024;
+__device__ __forceinline__ float block_max16(float v, float* red) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < LM_NT / 64; ++i) r = fmaxf(r, red[i]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_sum16(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < LM_NT / 64; ++i) r += red[i];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(LM_NT) void lm_loss_kernel(const float* __restrict__ logits, const float* __restrict__ teacher,
+                                                        long ldl, const long* __restrict__ labels,
+                                                        const float* __restrict__ row_w, const float* __restrict__ row_kl,
+                                                        int V, float T, float kl_scale, bf16* __restrict__ dlogits, long ldd,
+                                                        float* __restrict__ row_terms) {
+    __shared__ float red[LM_NT / 64];
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* l = logits + (size_t)r * ldl;
     const float* t = teacher ? teacher + (size_t)r * ldl : nullptr;
     const float invT = 1.0f / T;
+    const int V4 = V & ~3;                      // whole 4-column groups; columns [V4, V) go to threads 0 .. V - V4 - 1
+    const int vt = V4 + tid;                    // this thread's tail column (if < V)
     float m1 = -INFINITY, mt = -INFINITY;
-    for (int v = tid; v < V; v += 256) {
-        m1 = fmaxf(m1, l[v]);
-        if (t) mt = fmaxf(mt, t[v]);
+    for (int v = 4 * tid; v < V4; v += 4 * LM_NT) {
+        const f32x4 lv = *reinterpret_cast<const f32x4*>(l + v);
+        m1 = fmaxf(fmaxf(m1, fmaxf(lv[0], lv[1])), fmaxf(lv[2], lv[3]));
+        if (t) {
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(t + v);
+            mt = fmaxf(fmaxf(mt, fmaxf(tv[0], tv[1])), fmaxf(tv[2], tv[3]));
+        }
     }
-    m1 = block_max(m1, red);
-    if (t) mt = block_max(mt, red);
+    if (vt < V) {
+        m1 = fmaxf(m1, l[vt]);
+        if (t) mt = fmaxf(mt, t[vt]);
+    }
+    m1 = block_max16(m1, red);
+    if (t) mt = block_max16(mt, red);
     float z1 = 0.f, zp = 0.f, zq = 0.f, a = 0.f;
-    for (int v = tid; v < V; v += 256) {
-        const float d = l[v] - m1;
+    auto acc1 = [&](const float lv, const float tv) {
+        const float d = lv - m1;
         z1 += __expf(d);
         if (t) {
             zp += __expf(d * invT);
-            const float eq = __expf((t[v] - mt) * invT);
+            const float eq = __expf((tv - mt) * invT);
             zq += eq;
-            a += eq * (t[v] - l[v]) * invT;
+            a += eq * (tv - lv) * invT;
         }
+    };
+    for (int v = 4 * tid; v < V4; v += 4 * LM_NT) {
+        const f32x4 lv = *reinterpret_cast<const f32x4*>(l + v);
+        f32x4 tv = {0.f, 0.f, 0.f, 0.f};
+        if (t) tv = *reinterpret_cast<const f32x4*>(t + v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc1(lv[e], tv[e]);
     }
-    z1 = block_sum(z1, red);
+    if (vt < V) acc1(l[vt], t ? t[vt] : 0.f);
+    z1 = block_sum16(z1, red);
     float kl = 0.f;
     if (t) {
-        zp = block_sum(zp, red);
-        zq = block_sum(zq, red);
-        a = block_sum(a, red);
+        zp = block_sum16(zp, red);
+        zq = block_sum16(zq, red);
+        a = block_sum16(a, red);
         kl = a / zq - (mt - m1) * invT - __logf(zq) + __logf(zp);
     }
     const long lab = labels[r];
@@ -135,16 +177,23 @@ __global__ __launch_bounds__(256) void lm_loss_kernel(const float* __restrict__ 
     bf16* dl = dlogits + (size_t)r * ldd;
     const float i1 = 1.0f / z1, ip = t ? 1.0f / zp : 0.f, iq = t ? 1.0f / zq : 0.f;
     const float ks = kl_scale * rk * invT;
-    for (int v = tid; v < (int)ldd; v += 256) {
-        float gv = 0.f;
-        if (v < V) {
-            const float d = l[v] - m1;
-            gv = w * (__expf(d) * i1 - (v == lab ? 1.f : 0.f));
-            if (t) gv += ks * (__expf(d * invT) * ip - __expf((t[v] - mt) * invT) * iq);
-            gv *= 0.5f;
-        }
-        dl[v] = (bf16)gv;
+    auto grad1 = [&](const int v, const float lv, const float tv) {
+        const float d = lv - m1;
+        float gv = w * (__expf(d) * i1 - (v == lab ? 1.f : 0.f));
+        if (t) gv += ks * (__expf(d * invT) * ip - __expf((tv - mt) * invT) * iq);
+        return 0.5f * gv;
+    };
+    for (int v = 4 * tid; v < V4; v += 4 * LM_NT) {          // (ldd % 4 == 0 and dlogits 8-byte aligned: launcher)
+        const f32x4 lv = *reinterpret_cast<const f32x4*>(l + v);
+        f32x4 tv = {0.f, 0.f, 0.f, 0.f};
+        if (t) tv = *reinterpret_cast<const f32x4*>(t + v);
+        f32x4 gv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = grad1(v + e, lv[e], tv[e]);
+        *reinterpret_cast<bf16x4*>(dl + v) = cvt4(gv);
     }
+    for (int v = V4 + tid; v < (int)ldd; v += LM_NT)         // the last columns of the vocabulary, zeros in the padding
+        dl[v] = (bf16)(v < V ? grad1(v, l[v], t ? t[v] : 0.f) : 0.f);
 }
 
 // scalars[0] = sum_r w_r ce_r (the loss ALBEF.forward returns), [1] = kl_scale * sum_r kl_r, [2] = ([0] + [1]) / 2
@@ -312,7 +361,9 @@ extern "C" int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher,
     FD_CHECK_ARG(logits && labels && row_weight && scalars && R > 0 && V > 0 && ldl >= V && temp > 0.f);
     FD_CHECK_ARG(!dlogits_bf16 || ldd >= V);
     float* row_terms = scalars + 4;       // scalars: 4 + 2 R floats
-    hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(256), 0, stream, logits, teacher, ldl, labels, row_weight, row_kl, V, temp,
+    FD_CHECK_ARG(ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0 && (!teacher || ((uintptr_t)teacher & 15) == 0));
+    FD_CHECK_ARG(!dlogits_bf16 || (ldd % 4 == 0 && ((uintptr_t)dlogits_bf16 & 7) == 0));
+    hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(LM_NT), 0, stream, logits, teacher, ldl, labels, row_weight, row_kl, V, temp,
                        kl_scale, (bf16*)dlogits_bf16, ldd, row_terms);
     hipLaunchKernelGGL(lm_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, R, kl_scale, scalars);
     FD_LAUNCH_RET();

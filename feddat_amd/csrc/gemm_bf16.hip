@@ -207,7 +207,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mid_kernel(GemmArgs g) {
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    // every XCD owns a contiguous range of work items, i.e. whole rows of one operand's tiles and ALL tiles of the other, which
+    // it pulls through its own L2: let that be the SMALLER operand (few rows against a 768..3072-row weight: an XCD owns a
+    // range of N tiles and every M tile, so the weight matrix is fetched once per launch, not once per XCD)
+    const int tiles_m = (g.M + 63) / 64;
+    int tm, tn;
+    if (g.M < g.N) {
+        tn = wg / tiles_m;
+        tm = wg - tn * tiles_m;
+    } else {
+        tm = wg / tiles_n;
+        tn = wg - tm * tiles_n;
+    }
     const int m0 = tm * 64, n0 = tn * 64;
 
     // this thread's four 16-byte pieces of a k-tile: rows r0, r0 + 32 of A and of B, logical chunk c

@@ -1129,3 +1129,47 @@ def test_gemm_fp8_vs_fp32_on_the_dequantised_operands(L, M, N, K, epi):
     full = A @ W.t() + bias
     print(f"fp8 ({M},{N},{K}): rel err vs fp32 operands {rel_err(ref, full):.4f}")
     assert rel_err(ref, full) < 0.08
+
+
+@pytest.mark.parametrize("R,V,ldl,with_teacher", [(96, 30522, 30592, True), (7, 1001, 1024, True), (5, 3072, 3072, False)])
+def test_lm_loss_fwd_bwd_vs_torch(L, R, V, ldl, with_teacher):
+    """feddat_lm_loss_fwd_bwd against autograd on the reference's formula (albef_model.py:142-143: per-row weighted CE with
+    ignore_index -100; task_trainer.py:506-516: T^2 * KL(softmax(t / T) || softmax(l / T)), batchmean folded into kl_scale;
+    L = (ce + kl) / 2): V not a multiple of 4 (the vocabulary's own 30 522), padded row stride, labels -100, per-row KL
+    factors.  Loss terms 1e-5 relative; dlogits (stored in bf16) 2^-8 relative + 1e-9."""
+    g = torch.Generator().manual_seed(R + V)
+    lg = torch.zeros(R, ldl)
+    lg[:, :V] = torch.randn(R, V, generator=g) * 3
+    tc = torch.zeros(R, ldl)
+    tc[:, :V] = torch.randn(R, V, generator=g) * 3
+    labels = torch.randint(0, V, (R,), generator=g)
+    labels[::3] = -100
+    labels[1] = V - 1                                   # a label in the scalar tail columns
+    rw = torch.rand(R, generator=g) + 0.1
+    rk = torch.ones(R)
+    rk[2] = 0.0
+    rk[3] = 1.5
+    T, ks = 3.0, 9.0 / R
+    l32 = lg[:, :V].clone().requires_grad_(True)
+    logp = F.log_softmax(l32, -1)
+    ce_rows = torch.where(labels >= 0, -logp.gather(1, labels.clamp(min=0)[:, None])[:, 0] * rw, torch.zeros(R))
+    ce = ce_rows.sum()
+    if with_teacher:
+        q = F.softmax(tc[:, :V] / T, -1)
+        kl_rows = (q * (torch.log(q) - F.log_softmax(l32 / T, -1))).sum(-1) * rk
+        kl = ks * kl_rows.sum()
+    else:
+        kl = torch.zeros(())
+    (0.5 * (ce + kl)).backward()
+    dl = torch.full((R, ldl), 7.0, dtype=torch.bfloat16, device=DEV)
+    sc = torch.zeros(4 + 2 * R, device=DEV)
+    L.lm_loss_fwd_bwd(lg.to(DEV), tc.to(DEV) if with_teacher else None, labels.to(DEV), rw.to(DEV), V, T,
+                      ks if with_teacher else 0.0, dl, sc, row_kl=rk.to(DEV))
+    sc = sc.cpu()
+    assert abs(float(sc[0]) - float(ce)) <= 1e-5 * abs(float(ce)) + 1e-6
+    assert abs(float(sc[1]) - float(kl)) <= 2e-5 * abs(float(kl)) + 1e-6
+    assert abs(float(sc[2]) - 0.5 * float(ce + kl)) <= 2e-5 * abs(float(ce + kl)) + 1e-6
+    got = dl.float().cpu()
+    assert torch.equal(got[:, V:], torch.zeros(R, ldl - V))
+    err = (got[:, :V] - l32.grad).abs()
+    assert bool((err <= 2.0 ** -8 * l32.grad.abs() + 1e-9).all()), float(err.max())
