@@ -41,13 +41,13 @@ int fd_set_max_lds(const void* kernel, int bytes);     // hipFuncAttributeMaxDyn
 // feddat_set_debug_flags rejects every bit outside FD_DEBUG_SELECT_BITS, which only choose among kernels that give the same
 // (bit-identical) results: 1 / 2 everything on the two-group / one-wave-per-SIMD GEMM kernel (2 in attention.hip: the
 // two-role backward), 32 / 64 force 192- / 256-row tiles, 128 no small-tile kernel, 256 the K = 32 fp8 MFMA, bit 23 one
-// attention-backward block per pair, bits 28..31 cap the persistent GEMM grid at 16 x value workgroups.
+// attention-backward block per pair, bit 27 no 160-row GEMM tiles, bits 28..31 cap the persistent GEMM grid at 16 x value workgroups.
 #ifdef FEDDAT_ABLATE
 #define FD_ABL(x) (x)
 #else
 #define FD_ABL(x) 0
 #endif
-constexpr unsigned FD_DEBUG_SELECT_BITS = 1u | 2u | 32u | 64u | 128u | 256u | (1u << 23) | (0xfu << 28);
+constexpr unsigned FD_DEBUG_SELECT_BITS = 1u | 2u | 32u | 64u | 128u | 256u | (1u << 23) | (1u << 27) | (0xfu << 28);
 int fd_debug_flags();                                  // ablation flags (feddat_set_debug_flags), 0 in production
 int fd_prepare_all_kernels();                          // sets every kernel's LDS attribute on the current device
 int fd_prepare_gemm_kernels();

@@ -943,7 +943,11 @@ template <int EPI, int RT, int FAKE = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     using Cfg = V3Cfg<RT>;
     constexpr int NP = Cfg::NP, NM = 6 * RT;                  // MFMAs per k-half
-    static_assert(3 * NP <= NM, "one filler per MFMA");
+    // one filler per MFMA.  Half 0 has NM slots: the NP fragment reads of half 1, then every piece's write into the other
+    // stage (all NP of them: the stage must be complete at the barrier) and as many reloads as still fit (LH0); the
+    // remaining NP - LH0 reloads (RT = 5: 3 of 11) follow behind the first MFMAs of half 1
+    constexpr int LH0 = (NM - 2 * NP) < NP ? (NM - 2 * NP) : NP;
+    static_assert(LH0 >= 0 && NP - LH0 <= 12, "writes fit half 0, deferred reloads fit ahead of half 1's fragment reads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef FEDDAT_ABLATE
     // tools/gemm_dephase.py (timing probe): blocks start (bid / 8) % 4 x q x 2 us apart, so that the CUs' epilogues (HBM write
@@ -1072,14 +1076,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (f < NP) {                              // fragments of k-half 1
                     read_frag(st, 1, f);
-                } else if (f < 3 * NP) {                   // k-tile j+1 -> the other stage, piece by piece, each register
+                } else if (f < NP + 2 * LH0) {             // k-tile j+1 -> the other stage, piece by piece, each register
                     const int q = f - NP;                  // refilled with k-tile j+2 right behind its write (all writes in a
                     if ((q & 1) == 0) lwrite_piece(q >> 1, st ^ 1);   // row, then the loads, with the barrier pulled forward:
                     else gload_piece(q >> 1);              // 10 % slower -- the four waves' writes collide)
+                } else if (f < 2 * NP + LH0) {             // (RT = 5) the last pieces' writes; their reloads wait for half 1
+                    lwrite_piece(f - NP - LH0, st ^ 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        stream_advance();
+        if (LH0 == NP) stream_advance();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // ---- half 1: the fragments of the next k-tile's half 0 behind the first two MFMA rows
@@ -1090,6 +1096,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
                 mfma_agpr(acc[i][j], fb[1][j], fa[1][i]);
                 const int f = 6 * i + j;
                 __builtin_amdgcn_sched_barrier(0);
+                if (LH0 < NP && f < NP - LH0) {            // deferred reloads (same stream position as half 0's), then advance
+                    gload_piece(LH0 + f);
+                    if (f == NP - LH0 - 1) stream_advance();
+                }
                 if (f >= 12 && f < 12 + NP) read_frag(st ^ 1, 0, f - 12);
                 if (FAKE && RT == 6 && (f == 28 || f == 30 || f == 32) && kt < 12) fake_slice((f - 28) / 2, kt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1358,20 +1368,22 @@ static const V2Kernel (*v2_kernel_table())[7] {
     return kernels;
 }
 
-static const V2Kernel (*v3_kernel_table())[5] {
-    static const V2Kernel kernels[2][5] = {
+static const V2Kernel (*v3_kernel_table())[5] {        // [0]: 192-row tiles (RT = 6), [1]: 256 (RT = 8), [2]: 160 (RT = 5)
+    static const V2Kernel kernels[3][5] = {
         {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 6>,
          gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 6>},
         {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 8>,
-         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 8>}};
+         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 8>},
+        {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 5>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 5>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 5>,
+         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 5>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 5>}};
     return kernels;
 }
+static int v3_lds(int which) { return which == 1 ? V3Cfg<8>::LDS : which == 2 ? V3Cfg<5>::LDS : V3Cfg<6>::LDS; }
 
 int fd_prepare_gemm_kernels() {
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 3; ++w)
         for (int e = 0; e < 5; ++e)
-            if (fd_set_max_lds((const void*)v3_kernel_table()[w][e], w ? V3Cfg<8>::LDS : V3Cfg<6>::LDS) != FEDDAT_OK)
-                return FEDDAT_ELAUNCH;
+            if (fd_set_max_lds((const void*)v3_kernel_table()[w][e], v3_lds(w)) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     for (int w = 0; w < 2; ++w)
         for (int e = 0; e < 7; ++e)
             if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
@@ -1548,8 +1560,8 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             o.tn_per = tiles_n / o.nx;
             return (o.tiles_m * tiles_n + n_cu - 1) / n_cu;     // rounds of the persistent grid
         };
-        GemmArgsV2 a3 = a2, a4 = a2;
-        const int rounds3 = plan(192, a3), rounds4 = plan(256, a4);
+        GemmArgsV2 a3 = a2, a4 = a2, a5 = a2;
+        const int rounds3 = plan(192, a3), rounds4 = plan(256, a4), rounds5 = plan(160, a5);
         // a 256-row tile costs about 1.2x a 192-row tile (48 vs 36 MFMAs per k-tile and wave, L phase 20 vs 18 reads)
         bool wm4 = rounds4 * 12 < rounds3 * 10;
         if (epi == FEDDAT_EPI_MUL_DGELU) wm4 = false;      // its 256-row instantiation spills (180 B of scratch per lane and tile)
@@ -1577,9 +1589,14 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
 #endif
         if (((dbg & 2) || v3_pick) && !(dbg & 1)) {
             const bool rt8 = (dbg & 64) ? true : (dbg & 32) ? false : wm4;
-            const V2Kernel k3 = v3_kernel_table()[rt8 ? 1 : 0][epi];
-            a2 = rt8 ? a4 : a3;
-            const int lds3 = rt8 ? V3Cfg<8>::LDS : V3Cfg<6>::LDS;
+            // 160-row tiles (RT = 5, ~0.87 of a 192-row tile's time) where they fill the rounds better: 18 464 rows x N = 768
+            // (ALBEF's ViT) = 388 tiles of 192 rows = 1.52 rounds of the 256 CUs, paid as 2; 464 tiles of 160 rows = 1.81 rounds,
+            // paid as 2 x 0.87.  configs[1]'s 11 840 rows (64 x 185) keep their exact rounds of 192-row tiles.
+            const bool rt5 = !(dbg & (32 | 64 | (1 << 27))) && rounds5 * 87 < (rt8 ? rounds4 * 120 : rounds3 * 100);
+            const int which = rt5 ? 2 : rt8 ? 1 : 0;
+            const V2Kernel k3 = v3_kernel_table()[which][epi];
+            a2 = rt5 ? a5 : rt8 ? a4 : a3;
+            const int lds3 = v3_lds(which);
             if (fd_set_max_lds((const void*)k3, lds3) != FEDDAT_OK) return FEDDAT_ELAUNCH;
             const int total3 = a2.tiles_m * (N / V2_BN);
             hipLaunchKernelGGL(k3, dim3(total3 < n_cu ? total3 : n_cu), dim3(256), lds3, stream, a2);

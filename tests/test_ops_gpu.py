@@ -94,11 +94,13 @@ def test_gemm_epilogues(L, M, N, K):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("M,N,K", [(11849, 3072, 768), (5920, 2304, 768), (11840, 768, 3072), (1030, 192, 64)])
+@pytest.mark.parametrize("M,N,K", [(11849, 3072, 768), (5920, 2304, 768), (11840, 768, 3072), (1030, 192, 64), (18464, 768, 768)])
 def test_gemm_kernel_variants_bit_identical(L, M, N, K):
     """The two persistent kernels (v2: two wave groups per SIMD; v3: one wave per SIMD, inline-asm MFMAs with AGPR
-    accumulators) and both tile heights of each accumulate in the same order and share the epilogues: every epilogue's
-    output must be bit-identical across them (the production dispatch mixes them per launch)."""
+    accumulators) and the tile heights of each (192 / 256 rows; v3 also 160 rows where they fill the rounds of the 256 CUs
+    better -- 5920 x 2304 and ALBEF's 18464 x 768 here; flag 1 << 27 switches them off) accumulate in the same order and
+    share the epilogues: every epilogue's output must be bit-identical across them (the production dispatch mixes them per
+    launch)."""
     g = torch.Generator(device="cpu").manual_seed(M + N)
     A = bf(torch.randn(M, K, generator=g)).to(DEV)
     B = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
@@ -123,7 +125,7 @@ def test_gemm_kernel_variants_bit_identical(L, M, N, K):
         return [o0, o1, o2, u2, o3, o4]
     ref = run(1 | 32)                      # v2, 192-row tiles
     assert rel_err(ref[0], A.float() @ B.float().t() + bias) < 1.5e-2
-    for flags in (1 | 64, 2 | 32, 2 | 64, 0):      # v2 256-row, v3 192 / 256-row, production dispatch
+    for flags in (1 | 64, 2 | 32, 2 | 64, 2, 1 << 27, 0):      # v2 256-row, v3 192 / 256 / best-fit rows, no 160-row tiles, production
         for a_, b_ in zip(ref, run(flags)):
             assert torch.equal(a_, b_), flags
 
