@@ -113,6 +113,19 @@ class AlbefDatEngine:
                                         cross=attn_block(Lp + "crossattention.", True) if i >= fusion else None,
                                         fc1=lin(Lp + "intermediate.dense"), fc2=lin(Lp + "output.dense"),
                                         lng=Pm(Lp + "output.LayerNorm.weight"), lnb=Pm(Lp + "output.LayerNorm.bias")))
+            # The cross-attention K | V projections of ALL fusion layers read the same encoder-side states (image_embeds for
+            # the text encoder, the repeated question states for the decoder): ONE product with the layers' weights stacked
+            # along N in the forward ([rows, n_cross * 1536], each layer's K | V a column slice), and ONE product over the
+            # stacked dK | dV columns (K = n_cross * 1536) for the gradient of those states in the backward -- instead of six
+            # 18 464-row launches of N = 1536 and six read-modify-write passes over the fp32 gradient.
+            cross = [i for i, Ly in enumerate(t["layers"]) if Ly["cross"] is not None]
+            t["cross_layers"] = cross
+            if cross:
+                t["kv_all"] = dict(w=torch.cat([t["layers"][i]["cross"]["kv"]["w"] for i in cross], 0).contiguous(),
+                                   b=torch.cat([t["layers"][i]["cross"]["kv"]["b"] for i in cross], 0).contiguous(),
+                                   wT=torch.cat([t["layers"][i]["cross"]["kv"]["wT"] for i in cross], 1).contiguous())
+                for i in cross:          # the per-layer copies are not used any more
+                    t["layers"][i]["cross"]["kv"] = None
             return t
         self.enc = tower("text_encoder.", enc_layers, fusion_layer)
         self.dec = tower("text_decoder.bert.", dec_layers, 0)
@@ -207,15 +220,19 @@ class AlbefDatEngine:
                         out=f32(Mi, H), stf=f32(Mi, 2), emb16=b16(Mi, H))
 
         def bert_set(M, nb, Sq, layers, cross_from, kv_rows):
+            nc = max(layers - cross_from, 0)
+            kvc_all = b16(kv_rows, nc * 2 * H) if nc else None      # K | V of every cross-attention layer, one product
+
             def layer(i):
                 d = dict(qkv=b16(M, 3 * H), ctx=b16(M, H), lse=f32(nb, self.heads, Sq), t1=f32(M, H), st_a=f32(M, 2),
                          a=f32(M, H), a16=b16(M, H), u=b16(M, I), s1=f32(M, H), st_x=f32(M, 2), x=f32(M, H),
                          zs=f32(M, 2, self.r), s2=f32(M, H), st_o=f32(M, 2), out=f32(M, H), out16=b16(M, H))
                 if i >= cross_from:
-                    d.update(qc=b16(M, H), kvc=b16(kv_rows, 2 * H), ctx2=b16(M, H), lse2=f32(nb, self.heads, Sq),
-                             t2=f32(M, H), st_c=f32(M, 2), c=f32(M, H), c16=b16(M, H))
+                    j = i - cross_from
+                    d.update(qc=b16(M, H), kvc=kvc_all[:, j * 2 * H:(j + 1) * 2 * H], ctx2=b16(M, H),
+                             lse2=f32(nb, self.heads, Sq), t2=f32(M, H), st_c=f32(M, 2), c=f32(M, H), c16=b16(M, H))
                 return d
-            return dict(h=f32(M, H), h16=b16(M, H), f16=b16(M, I), tA=f32(M, H), td=f32(M, H),
+            return dict(h=f32(M, H), h16=b16(M, H), f16=b16(M, I), tA=f32(M, H), td=f32(M, H), kvc_all=kvc_all,
                         layers=[layer(i) for i in range(layers)])
 
         def act_set():
@@ -239,14 +256,16 @@ class AlbefDatEngine:
 
         def scratch():
             return dict(dlogits=b16(self.R, self.Vp), d1=f32(Mmax, H), d2=f32(Mmax, H), d3=f32(Mmax, H), d4=f32(Mmax, H),
-                      b1=b16(Mmax, H), b2=b16(Mmax, H), bI=b16(Mmax, I), b3=b16(Mmax, 3 * H), bkv=b16(Mmax, 2 * H),
+                      b1=b16(Mmax, H), b2=b16(Mmax, H), bI=b16(Mmax, I), b3=b16(Mmax, 3 * H),
+                      bkv=b16(max(self.Mi, N * Lq), max(self.el - self.fl, self.dl) * 2 * H),
                       z=f32(Mmax, self.r), dz=f32(Mmax, self.r), dsum=f32(max(B, N), self.heads, max(self.Ni, Lq, La)),
                       d_img=f32(self.Mi, H), d_qs=f32(self.Mq, H), d_rep=f32(N * Lq, H), d_dec=f32(self.Ma, H))
         self.gs = {"gating": scratch(), "adapter_1": scratch()}
         if self.batch_text:
             M2 = 2 * max(self.Mq, self.Ma, N * Lq, self.R)
             self.gs["both"] = dict(dlogits=b16(2 * self.R, self.Vp), d1=f32(M2, H), d2=f32(M2, H), d3=f32(M2, H), d4=f32(M2, H),
-                                   b1=b16(M2, H), b2=b16(M2, H), bI=b16(M2, I), b3=b16(M2, 3 * H), bkv=b16(2 * max(self.Mi, N * Lq), 2 * H),
+                                   b1=b16(M2, H), b2=b16(M2, H), bI=b16(M2, I), b3=b16(M2, 3 * H),
+                                   bkv=b16(2 * max(self.Mi, N * Lq), max(self.el - self.fl, self.dl) * 2 * H),
                                    z=f32(M2, self.r), dz=f32(M2, self.r),
                                    dsum=f32(2 * max(B, N), self.heads, max(self.Ni, Lq, La)), d_img=f32(2 * self.Mi, H),
                                    d_qs=f32(2 * self.Mq, H), d_rep=f32(2 * N * Lq, H), d_dec=f32(2 * self.Ma, H))
@@ -512,6 +531,8 @@ class AlbefDatEngine:
                   pass_id=None, tower: int = 0):
         H = self.H
         h, h16 = S["h"], S["h16"]
+        if T["cross_layers"]:         # K | V of every cross-attention layer of the tower in one product (see tower())
+            L.gemm_bf16_nt(enc16, T["kv_all"]["w"], L.EPI_BF16, bias=T["kv_all"]["b"], out_bf16=S["kvc_all"])
         for i, W in enumerate(T["layers"]):
             A = S["layers"][i]
             dk = lambda kind: self._drop(pass_id, tower, i, kind)      # noqa: E731
@@ -523,7 +544,6 @@ class AlbefDatEngine:
             if W["cross"] is not None:
                 Wc = W["cross"]
                 L.gemm_bf16_nt(A["a16"], Wc["q"]["w"], L.EPI_BF16, bias=Wc["q"]["b"], out_bf16=A["qc"])
-                L.gemm_bf16_nt(enc16, Wc["kv"]["w"], L.EPI_BF16, bias=Wc["kv"]["b"], out_bf16=A["kvc"])
                 L.attn2_fwd(A["qc"], A["kvc"][:, :H], A["kvc"][:, H:], A["ctx2"], A["lse2"], nb, Sq, Skv, self.heads,
                             key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows, drop=dk("cross_probs"))
                 self._attn_out(Wc, A["ctx2"], A["a"], M, A["t2"], A["st_c"], A["c"], A["c16"], S["td"], dk("cross_out"))
@@ -573,9 +593,11 @@ class AlbefDatEngine:
     # ------------------------------------------------------------------------------------------ backward
     def _bert_bwd(self, T, S, m0: int, mode: str, M, nb, Sq, self_mask, causal, enc16, enc_rows, Skv, enc_mask, d_out,
                   d_enc, pass_id=None, tower: int = 0):
-        """d_out: fp32 [M,768] gradient of the tower's output (consumed); d_enc: fp32 accumulator for the encoder-side
-        states (zeroed by the caller); returns the gradient wrt the tower's embedding output (unused: embeddings frozen)."""
+        """d_out: fp32 [M,768] gradient of the tower's output (consumed); d_enc: fp32 gradient of the encoder-side states
+        (written: one product over all cross-attention layers' dK | dV); returns the gradient wrt the tower's embedding output
+        (unused: embeddings frozen)."""
         H, g = self.H, self.gs[mode]
+        cross0 = T["cross_layers"][0] if T["cross_layers"] else 0
         for i in range(len(T["layers"]) - 1, -1, -1):
             W, A = T["layers"][i], S["layers"][i]
             dk = lambda kind: self._drop(pass_id, tower, i, kind)      # noqa: E731
@@ -604,14 +626,13 @@ class AlbefDatEngine:
                 dt2 = ds2
                 ln_bwd_to_operand(A["t2"], A["st_c"], Wc["lng"], dc, None, dt2, "cross_out")
                 L.gemm_bf16_nt(g["b1"][:M], Wc["o"]["wT"], L.EPI_BF16, out_bf16=g["b2"][:M])
-                kv_rows = A["kvc"].shape[0]
-                dq, dkv = g["b1"][:M], g["bkv"][:kv_rows]
+                kv_rows, j = A["kvc"].shape[0], i - cross0
+                dq, dkv = g["b1"][:M], g["bkv"][:kv_rows, j * 2 * H:(j + 1) * 2 * H]
                 L.attn2_bwd(A["qc"], A["kvc"][:, :H], A["kvc"][:, H:], A["ctx2"], A["lse2"], g["b2"][:M], g["dsum"], dq,
                             dkv[:, :H], dkv[:, H:], nb, Sq, Skv, self.heads, key_mask=enc_mask, q_rows=Sq, kv_rows=enc_rows,
                             drop=dk("cross_probs"))
                 da = dc
                 L.gemm_bf16_nt(dq, Wc["q"]["wT"], L.EPI_RESID_F32, resid=dt2, out_f32=da)
-                L.gemm_bf16_nt(dkv, Wc["kv"]["wT"], L.EPI_RESID_F32, resid=d_enc, out_f32=d_enc)
             else:
                 da = dc
             dt1 = ds2
@@ -622,6 +643,9 @@ class AlbefDatEngine:
                         g["dsum"], dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], nb, Sq, Sq, self.heads, key_mask=self_mask,
                         causal=causal, drop=dk("self_probs"))
             L.gemm_bf16_nt(dqkv, W["att"]["qkv"]["wT"], L.EPI_RESID_F32, resid=dt1, out_f32=d_out)
+        if T["cross_layers"]:         # d(encoder-side states) = sum over the layers of [dK | dV]_l Wkv_l: one product, K = n 1536
+            nc = len(T["cross_layers"])
+            L.gemm_bf16_nt(g["bkv"][:enc16.shape[0], :nc * 2 * H], T["kv_all"]["wT"], L.EPI_F32, out_f32=d_enc)
         return d_out
 
     def _vit_bwd(self, S, mode: str, d_img):
@@ -681,13 +705,11 @@ class AlbefDatEngine:
         L.cvt_f32_bf16(g["d2"][:R], g["b1"][:R])
         L.gemm_bf16_nt(g["b1"][:R], hd["t"]["wT"], L.EPI_F32, out_f32=g["d1"][:R])
         L.gather_rows(g["d1"][:R], t["unsel_idx"], dst_f32=g["d_dec"])          # zero rows at the last position of each answer
-        g["d_rep"].zero_()
         emb16 = self.emb16_both if mode == "both" else S["vit"]["emb16"]
         self._bert_bwd(self.dec, S["dec"], self.vd + self.el, mode, t["Ma"], t["na"], self.La, t["amask8"], True,
                        S["enc_rep16"], self.Lq, self.Lq, t["qmask8_rep"], g["d_dec"], g["d_rep"], pass_id, 1)
         # question states were repeated per answer: sum the answers of each question back (rows = [N, Lq * H])
         L.segment_sum_rows(g["d_rep"].view(t["na"], self.Lq * H), t["seg_off"], g["d_qs"].view(t["nq"], self.Lq * H))
-        g["d_img"].zero_()
         self._bert_bwd(self.enc, S["enc"], self.vd, mode, t["Mq"], t["nq"], self.Lq, t["qmask8"], False, emb16,
                        self.Ni, self.Ni, None, g["d_qs"], g["d_img"], pass_id, 0)
 
