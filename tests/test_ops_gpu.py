@@ -994,6 +994,11 @@ def test_fedavg_allreduce_through_the_c_abi_single_rank(L):
     (1, 130, 200, 2, True, False),       # causal across chunk boundaries
     (2, 300, 130, 2, True, True),        # 128-row blocks, ragged last block, causal + mask, Sq > Skv
     (2, 64, 65, 3, False, True),         # Sq on the 64-row kernel, Skv just over it
+    # the mask-free instantiations (no key mask, not causal) and their short last chunks
+    (2, 200, 130, 3, False, False),      # last key chunk of 2 (a quarter / half chunk), last query chunk of 8
+    (2, 128, 192, 2, False, False),      # whole chunks only: nothing is ever masked
+    (2, 100, 100, 2, False, False),      # last chunk of 36 keys: forward on the masking kernel, backward mask-free
+    (1, 70, 90, 2, False, False),        # last chunks of 26 keys / 6 queries
 ])
 def test_attn2_fwd_bwd_vs_fp32_reference(L, B, Sq, Skv, heads, causal, masked):
     g = torch.Generator().manual_seed(Sq * 1000 + Skv)
