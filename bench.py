@@ -153,6 +153,27 @@ def profiled_traffic(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel"), 
             "note": "mean over the launches of one step (all shapes and epilogues)"}
 
 
+def profiled_kernel_time(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel", "gemm_skinny", "gemm_nt_mid_kernel", "gemm_nt_kernel"),
+                         pattern="r[0-9][0-9]_kernel_stats.csv", step_marker="step_tick_multi"):
+    """Per-step time of the dominant kernel's launches in the committed `rocprofv3 --kernel-trace --stats` summary of this
+    command (profiles/*_kernel_stats.csv: the hipGraph-replayed steps under the profiler), next to the live event-bracket
+    figure: the two must agree (the brackets sit around an EAGER replay, whose launches run a few per cent longer)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None
+    ms, steps = 0.0, 0
+    for r in csv.DictReader(open(files[-1])):
+        if any(k in r["kernel"] for k in kernel_substrs):
+            ms += float(r["total_ms"])
+        if step_marker in r["kernel"]:
+            steps = int(r["calls"])
+    if not steps or not ms:
+        return None
+    return {"ms_per_step": round(ms / steps, 3), "steps": steps, "source": os.path.basename(files[-1])}
+
+
 def cpu_baseline(params_cpu, batches_cpu, B, res, task, timed_steps=3):
     """The CPU restatement of the reference path (oracle/, pinned to the reference's goldens incl. a 40-step round) timed
     on this node's host cores on a BOUNDED sample of the SAME workload: same model, the same seeded B=32 batches the GPU
@@ -414,7 +435,11 @@ def roofline_block(L, eng, batches, gemms):
     ach, tsum, rows, alg_bytes, launches, in_step_info = measure_gemms_in_step(L, eng, batches)
     ach_iso, tsum_iso, rows_iso = measure_gemms(L, gemms)
     tr = profiled_traffic()
-    return {"kernel": "gemm_nt_v3_kernel / gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one train_step, "
+    kt = profiled_kernel_time()
+    if kt:       # the same FLOPs over the kernel-trace durations of the committed profile (another run, maybe another box)
+        kt["frac"] = round(ach * tsum / (kt["ms_per_step"] * 1e-3) / PEAK_BF16, 4)
+    return {"kernel_trace": kt,
+            "kernel": "gemm_nt_v3_kernel / gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one train_step, "
                       "FLOP-weighted, durations measured in-step)",
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16, 4), "frac_in_step": round(ach / PEAK_BF16, 4),
