@@ -46,3 +46,18 @@ def test_bench_round_split_reports_the_heterogeneity_bound():
     rs = bench.round_split(rows, 0.8)
     assert rs["hetero_bound"]["scaling_x_bound"] == pytest.approx(5.625) and rs["hetero_bound"]["round_efficiency_bound"] == pytest.approx(0.703, abs=1e-3)
     assert rs["hetero_bound"]["efficiency_vs_bound"] == pytest.approx(1.0)
+
+
+def test_bench_reads_the_committed_profile_summaries():
+    """bench.py's roofline object carries two figures from the committed rocprofv3 summaries (profiles/rNN_*.csv): HBM bytes per
+    launch of the dominant kernel (PMC: FETCH_SIZE x 2 + WRITE_SIZE, KiB) and the same kernels' per-step time in the kernel
+    trace.  Both parsers on the files of the latest round: plausible magnitudes, and None for a pattern that matches nothing."""
+    import bench
+    tr = bench.profiled_traffic()
+    assert tr is not None and tr["source"].endswith("_pmc_per_kernel.csv")
+    assert 50e6 < tr["bytes_per_launch"] < 400e6              # the step's K1 launches move ~100-150 MB each
+    kt = bench.profiled_kernel_time()
+    assert kt is not None and kt["steps"] >= 5 and 2.0 < kt["ms_per_step"] < 8.0
+    assert bench.profiled_traffic(pattern="r[0-9][0-9]_nothing.csv") is None
+    assert bench.profiled_kernel_time(pattern="r[0-9][0-9]_nothing.csv") is None
+    assert bench.profiled_kernel_time(step_marker="no_such_kernel") is None
