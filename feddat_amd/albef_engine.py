@@ -241,6 +241,14 @@ class AlbefDatEngine:
                         hsel=f32(self.R, H), hsel16=b16(self.R, H), tu=f32(self.R, H), tg=f32(self.R, H), tst=f32(self.R, 2),
                         ty16=b16(self.R, H), logits=f32(self.R, self.Vp), loss=f32(4 + 2 * self.R))
         self.acts = {"gating": act_set(), "adapter_1": act_set()}
+        # Everything in the image encoder AHEAD of block 0's adapter (patch embedding, block 0's attention and MLP) is frozen
+        # and sees the same image in both passes: train_step computes it once (_vit_fwd(..., part="prefix")), both activation
+        # sets point at the same buffers (read-only in the backward: block 0's adapter input h3 for its weight gradient).
+        vg, v1 = self.acts["gating"]["vit"], self.acts["adapter_1"]["vit"]
+        for k in ("patches", "proj", "h0", "st0"):
+            v1[k] = vg[k]
+        for k in ("st1", "qkv", "ctx", "lse", "h2", "st2", "u", "h3"):
+            v1["blocks"][0][k] = vg["blocks"][0][k]
         # image_embeds of the two passes back to back: one K / V source for the batched text encoder's cross-attention
         self.emb16_both = b16(2 * self.Mi, H)
         self.acts["gating"]["vit"]["emb16"] = self.emb16_both[:self.Mi]
@@ -475,26 +483,32 @@ class AlbefDatEngine:
         self.row_w.copy_((self.inp["weights"] / self.B)[:, None].expand(self.N, self.La - 1).reshape(-1))
 
     # ------------------------------------------------------------------------------------------ forward
-    def _vit_fwd(self, S, mode: str):
+    def _vit_fwd(self, S, mode: str, part: str = "all"):
+        """part: "prefix" = patch embedding + block 0 up to (not including) its adapter -- the same for every adapter mode;
+        "suffix" = from block 0's adapter on; "all" = both."""
         B, H, Ni, vt = self.B, self.H, self.Ni, self.vit
         V = S["vit"]
-        L.im2col_patches(self.inp["image"], V["patches"], B, 3, self.img, self.img, self.P)
-        L.gemm_bf16_nt(V["patches"], vt["wp"], L.EPI_F32, bias=vt["bp"], out_f32=V["proj"])
-        # x = cat(cls, patches) + pos_embed  (vit.py:179-184): row 0 = cls + pos[0], rows 1.. = proj + pos[1..]
-        L.image_embed_assemble(V["proj"], vt["cls"], vt["pos"][0], vt["pos"][1:], self.zero_h, V["h0"], B, 0, Ni - 1, Ni, H)
+        if part != "suffix":
+            L.im2col_patches(self.inp["image"], V["patches"], B, 3, self.img, self.img, self.P)
+            L.gemm_bf16_nt(V["patches"], vt["wp"], L.EPI_F32, bias=vt["bp"], out_f32=V["proj"])
+            # x = cat(cls, patches) + pos_embed  (vit.py:179-184): row 0 = cls + pos[0], rows 1.. = proj + pos[1..]
+            L.image_embed_assemble(V["proj"], vt["cls"], vt["pos"][0], vt["pos"][1:], self.zero_h, V["h0"], B, 0, Ni - 1, Ni, H)
+            b0 = vt["blocks"][0]
+            L.layernorm_fwd(V["h0"], b0["n1g"], b0["n1b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=V["blocks"][0]["st1"])
         h = V["h0"]
-        b0 = vt["blocks"][0]
-        L.layernorm_fwd(h, b0["n1g"], b0["n1b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=V["blocks"][0]["st1"])
         for i, W in enumerate(vt["blocks"]):
             A = V["blocks"][i]
-            L.gemm_bf16_nt(V["x16"], W["qkv"]["w"], L.EPI_BF16, bias=W["qkv"]["b"], out_bf16=A["qkv"])
-            q, k, v = A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:]
-            L.attn2_fwd(q, k, v, A["ctx"], A["lse"], B, Ni, Ni, self.heads)
-            L.gemm_bf16_nt(A["ctx"], W["proj"]["w"], L.EPI_RESID_F32, bias=W["proj"]["b"], resid=h, out_f32=A["h2"])
-            L.layernorm_fwd(A["h2"], W["n2g"], W["n2b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=A["st2"])
-            L.gemm_bf16_nt(V["x16"], W["fc1"]["w"], L.EPI_GELU_G8 if A["u"].dtype == torch.uint8 else L.EPI_GELU,
-                           bias=W["fc1"]["b"], out_bf16=V["f16"], out2_bf16=A["u"])
-            L.gemm_bf16_nt(V["f16"], W["fc2"]["w"], L.EPI_RESID_F32, bias=W["fc2"]["b"], resid=A["h2"], out_f32=A["h3"])
+            if i > 0 or part != "suffix":
+                L.gemm_bf16_nt(V["x16"], W["qkv"]["w"], L.EPI_BF16, bias=W["qkv"]["b"], out_bf16=A["qkv"])
+                q, k, v = A["qkv"][:, :H], A["qkv"][:, H:2 * H], A["qkv"][:, 2 * H:]
+                L.attn2_fwd(q, k, v, A["ctx"], A["lse"], B, Ni, Ni, self.heads)
+                L.gemm_bf16_nt(A["ctx"], W["proj"]["w"], L.EPI_RESID_F32, bias=W["proj"]["b"], resid=h, out_f32=A["h2"])
+                L.layernorm_fwd(A["h2"], W["n2g"], W["n2b"], 1e-6, self.Mi, H, y_bf16=V["x16"], stats=A["st2"])
+                L.gemm_bf16_nt(V["x16"], W["fc1"]["w"], L.EPI_GELU_G8 if A["u"].dtype == torch.uint8 else L.EPI_GELU,
+                               bias=W["fc1"]["b"], out_bf16=V["f16"], out2_bf16=A["u"])
+                L.gemm_bf16_nt(V["f16"], W["fc2"]["w"], L.EPI_RESID_F32, bias=W["fc2"]["b"], resid=A["h2"], out_f32=A["h3"])
+            if part == "prefix":
+                return
             last = i == self.vd - 1
             nxt = V["out"] if last else V["blocks"][i + 1]["h_in"]
             g_, b_ = (vt["ng"], vt["nb"]) if last else (vt["blocks"][i + 1]["n1g"], vt["blocks"][i + 1]["n1b"])
@@ -759,10 +773,11 @@ class AlbefDatEngine:
         if self.batch_text and self.opt_adapters == (0, 1):
             # dropout = 0: the image encoders of the two passes side by side, then ONE text-side forward / backward over both
             # passes' rows, then the two image-encoder backward passes side by side
+            self._vit_fwd(self.acts["gating"], "gating", "prefix")
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                self._vit_fwd(self.acts["gating"], "gating")
-            self._vit_fwd(self.acts["adapter_1"], "adapter_1")
+                self._vit_fwd(self.acts["gating"], "gating", "suffix")
+            self._vit_fwd(self.acts["adapter_1"], "adapter_1", "suffix")
             cur.wait_stream(side)
             self._forward_text("both")
             self._backward_text("both", None)
@@ -777,17 +792,20 @@ class AlbefDatEngine:
             cur.wait_stream(side)
             self._optimizer_tail(False)
             return
+        # the image encoder ahead of block 0's adapter: once for both passes (frozen, adapter-free, no dropout)
+        self._vit_fwd(self.acts["gating"], "gating", "prefix")
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            self._vit_fwd(self.acts["gating"], "gating", "suffix")
             if drop:
                 # P0 (task_trainer.py:283-287): no-grad gated forward under its own masks.  The image encoder has no dropout,
                 # so its gated forward is shared with P2; the text towers run again for P2 below (other masks).
-                self._vit_fwd(self.acts["gating"], "gating")
                 self.logits_all.copy_(self._forward_text("gating", 0))
                 logits_teacher = self.logits_all
             else:
-                logits_teacher = self._forward("gating")     # P0 == P2 forward (task_trainer.py:283-287,311-315)
-        logits_1 = self._forward("adapter_1", 1 if drop else None)       # P1 (task_trainer.py:290-295)
+                logits_teacher = self._forward_text("gating")     # P0 == P2 forward (task_trainer.py:283-287,311-315)
+        self._vit_fwd(self.acts["adapter_1"], "adapter_1", "suffix")
+        logits_1 = self._forward_text("adapter_1", 1 if drop else None)       # P1 (task_trainer.py:290-295)
         cur.wait_stream(side)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
