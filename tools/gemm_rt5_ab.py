@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""160-row tiles of the one-wave-per-SIMD GEMM kernel (RT = 5) against the 192 / 256-row choice (debug flag 1 << 27 = off):
+"""160- / 224-row tiles of the one-wave-per-SIMD GEMM kernel (RT = 5 / 7) against the 192 / 256-row choice (debug flag 1 << 27 = off):
 the launches where the tile count fills the 256 CUs' rounds better."""
 import os
 import sys
@@ -13,7 +13,7 @@ dev = "cuda:0"
 SHAPES = [(18464, 768, 768, L.EPI_RESID_F32), (18464, 768, 3072, L.EPI_RESID_F32), (18464, 768, 3072, L.EPI_BF16),
           (18464, 768, 2304, L.EPI_BF16), (18464, 768, 768, L.EPI_BF16), (18464, 2304, 768, L.EPI_BF16),
           (5920, 2304, 768, L.EPI_BF16), (5920, 768, 3072, L.EPI_RESID_F32), (11840, 768, 768, L.EPI_RESID_F32),
-          (11840, 2304, 768, L.EPI_BF16)]
+          (11840, 2304, 768, L.EPI_BF16), (18464, 9216, 768, L.EPI_BF16), (18464, 768, 9216, L.EPI_F32)]
 for M, N, K, epi in SHAPES:
     A = torch.randn(M, K, device=dev).bfloat16()
     B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
@@ -28,6 +28,8 @@ for M, N, K, epi in SHAPES:
         def run():
             if epi == L.EPI_RESID_F32:
                 L.gemm_bf16_nt(A, B, epi, bias=bias, resid=resid, out_f32=o32)
+            elif epi == L.EPI_F32:
+                L.gemm_bf16_nt(A, B, epi, bias=bias, out_f32=o32)
             else:
                 L.gemm_bf16_nt(A, B, epi, bias=bias, out_bf16=o)
         for _ in range(5):
@@ -41,4 +43,4 @@ for M, N, K, epi in SHAPES:
         torch.cuda.synchronize()
         outs.append(e0.elapsed_time(e1) / 40 * 1e3)
     L.set_debug_flags(0)
-    print(f"M={M} N={N} K={K} epi={epi}: without 160-row tiles {outs[0]:6.1f} us   with {outs[1]:6.1f} us   ratio {outs[1] / outs[0]:.3f}", flush=True)
+    print(f"M={M} N={N} K={K} epi={epi}: without 160/224-row tiles {outs[0]:6.1f} us   with {outs[1]:6.1f} us   ratio {outs[1] / outs[0]:.3f}", flush=True)
