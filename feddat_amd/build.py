@@ -26,16 +26,19 @@ def _stale(target, deps):
 
 
 ABLATE_LIB = os.path.join(PKG, "libfeddat_hip_ablate.so")
+F16_LIB = os.path.join(PKG, "libfeddat_hip_f16.so")
 
 
-def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, ablate: bool = False, f16: bool = False) -> str:
     """ablate=True: the -DFEDDAT_ABLATE build with the timing-only (wrong-result) probes of tools/ compiled in, written to
-    libfeddat_hip_ablate.so; the production library has none of them (csrc/common.hip.h: FD_ABL)."""
+    libfeddat_hip_ablate.so; the production library has none of them (csrc/common.hip.h: FD_ABL).
+    f16=True: the same sources with IEEE-half operands (-DFEDDAT_OPERANDS_F16: v_mfma_f32_16x16x32_f16, csrc/common.hip.h) ->
+    libfeddat_hip_f16.so, the same C ABI (feddat_operand_format() tells them apart)."""
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "feddat_hip.h")]
-    objdir = os.path.join(PKG, "build_ablate" if ablate else "build")
-    LIB = ABLATE_LIB if ablate else globals()["LIB"]
-    FLAGS = globals()["FLAGS"] + (["-DFEDDAT_ABLATE"] if ablate else [])
+    objdir = os.path.join(PKG, "build_ablate" if ablate else "build_f16" if f16 else "build")
+    LIB = ABLATE_LIB if ablate else F16_LIB if f16 else globals()["LIB"]
+    FLAGS = globals()["FLAGS"] + (["-DFEDDAT_ABLATE"] if ablate else []) + (["-DFEDDAT_OPERANDS_F16"] if f16 else [])
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for s in srcs:
@@ -64,5 +67,13 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
     return LIB
 
 
+def build_all(force: bool = False, verbose: bool = False):
+    """Both production libraries: bf16 operands and fp16 operands."""
+    return [build(force, verbose), build(force, verbose, f16=True)]
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, ablate="--ablate" in sys.argv))
+    if "--ablate" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, ablate=True))
+    else:
+        print(*build_all(force="--force" in sys.argv, verbose=True), sep="\n")

@@ -21,9 +21,9 @@ constexpr int PSTRIDE = R * H + R + H;                      // one partial: [out
 
 // x[0..7] (fp32) -> head = bf16(x) (round to nearest even: the remainder is zero-mean and <= 2^-9 |x|; truncated heads
 // left a one-signed 2^-14 bias in the remainder x remainder product), rest = bf16(x - head)
-__device__ __forceinline__ void split_bf16x2(const float (&x)[8], bf16x8& head, bf16x8& rest) {
+__device__ __forceinline__ void split_bf16x2(const float (&x)[8], tbf16x8& head, tbf16x8& rest) {
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    head = cvt8(f32x4{x[0], x[1], x[2], x[3]}, f32x4{x[4], x[5], x[6], x[7]});
+    head = cvt8_tbf16(f32x4{x[0], x[1], x[2], x[3]}, f32x4{x[4], x[5], x[6], x[7]});
     const u32x4_t hp = __builtin_bit_cast(u32x4_t, head);
     float r[8];
 #pragma unroll
@@ -31,7 +31,7 @@ __device__ __forceinline__ void split_bf16x2(const float (&x)[8], bf16x8& head, 
         r[2 * k] = x[2 * k] - __uint_as_float(hp[k] << 16);
         r[2 * k + 1] = x[2 * k + 1] - __uint_as_float(hp[k] & 0xffff0000u);
     }
-    rest = cvt8(f32x4{r[0], r[1], r[2], r[3]}, f32x4{r[4], r[5], r[6], r[7]});
+    rest = cvt8_tbf16(f32x4{r[0], r[1], r[2], r[3]}, f32x4{r[4], r[5], r[6], r[7]});
 }
 
 struct WgradLaunch {
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
     const bool up = prob & 1;
     const float* big = up ? sg.dy : sg.x;
     const float* sm = up ? sg.z : sg.dz;
-    const float alpha = up ? sg.scale : 1.0f;
+    const float unscale = sg.grad_unscale != 0.0f ? sg.grad_unscale : 1.0f;      // 1 / loss scale (a power of two: exact)
+    const float alpha = (up ? sg.scale : 1.0f) * unscale;
     const int T = sg.rows;
     int tps = (T + NBLK * 4 - 1) / (NBLK * 4);
     tps = (tps + 7) & ~7;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) ssum[rt] += sraw[e][rt];
         }
-        bf16x8 sh[NRT], sl[NRT];
+        tbf16x8 sh[NRT], sl[NRT];
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
             float x[8];
@@ -116,14 +117,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = braw[e][v];
-            bf16x8 bh, bl;
+            tbf16x8 bh, bl;
             split_bf16x2(x, bh, bl);
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                acc[rt][v] = mfma16x32(sl[rt], bl, acc[rt][v]);        // smallest terms first
-                acc[rt][v] = mfma16x32(sl[rt], bh, acc[rt][v]);
-                acc[rt][v] = mfma16x32(sh[rt], bl, acc[rt][v]);
-                acc[rt][v] = mfma16x32(sh[rt], bh, acc[rt][v]);
+                acc[rt][v] = mfma16x32_tbf16(sl[rt], bl, acc[rt][v]);        // smallest terms first
+                acc[rt][v] = mfma16x32_tbf16(sl[rt], bh, acc[rt][v]);
+                acc[rt][v] = mfma16x32_tbf16(sh[rt], bl, acc[rt][v]);
+                acc[rt][v] = mfma16x32_tbf16(sh[rt], bh, acc[rt][v]);
             }
         }
 #pragma unroll
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
         *reinterpret_cast<f32x4*>(P + R * H + R + c0 + 4 * i16) = o;
         if (chunk == 0) {
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) P[R * H + rt * 16 + i16] = ssum[rt];
+            for (int rt = 0; rt < NRT; ++rt) P[R * H + rt * 16 + i16] = unscale * ssum[rt];
         }
     }
 }

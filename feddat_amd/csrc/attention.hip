@@ -34,7 +34,7 @@ __device__ __forceinline__ bf16x4 tr_frag(const char* m, int r0, int c0, int lan
     const int row = r0 + (i >> 2);
     const int col = c0 + ((i & 3) << 2);
     const char* p = m + sw_off(row, col >> 3) + ((col & 7) << 1);
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+    return fd_ds_read_tr16(p);
 }
 __device__ __forceinline__ bf16x8 tr_frag8(const char* m, int r0a, int r0b, int c0, int lane) {
     const bf16x4 a = tr_frag(m, r0a, c0, lane);
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
             auto tr = [&](int r0) {
                 const int r = r0 + (i >> 2);
                 const char* pp = panel + r * 32 + (((i & 3) ^ ((r >> 2) & 3)) << 3);
-                return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pp);
+                return fd_ds_read_tr16(pp);
             };
             const bf16x4 a4 = tr(ks * 32 + 4 * g), b4 = tr(ks * 32 + 16 + 4 * g);
             const bf16x8 dsb = bf16x8{a4[0], a4[1], a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};

@@ -31,7 +31,7 @@ __device__ __forceinline__ bf16x4 tr_frag(const char* m, int r0, int c0, int lan
     const int row = r0 + (i >> 2);
     const int col = c0 + ((i & 3) << 2);
     const char* p = m + sw_off(row, col >> 3) + ((col & 7) << 1);
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+    return fd_ds_read_tr16(p);
 }
 __device__ __forceinline__ bf16x8 tr_frag8(const char* m, int r0a, int r0b, int c0, int lane) {
     const bf16x4 a = tr_frag(m, r0a, c0, lane);

@@ -5,10 +5,29 @@
 
 #include "../../include/feddat_hip.h"
 
+// The 16-bit OPERAND FORMAT of the library is a build-time choice (feddat_operand_format(), include/feddat_hip.h):
+//   libfeddat_hip.so      bf16 (8 exponent / 7 mantissa bits)  -- v_mfma_f32_16x16x32_bf16
+//   libfeddat_hip_f16.so  IEEE half (5 / 10), -DFEDDAT_OPERANDS_F16 -- v_mfma_f32_16x16x32_f16, the same MFMA rate, 8x finer
+//                         rounding of every frozen weight and activation operand (the reference's own GPU arithmetic is fp16
+//                         autocast: accelerate_config.yaml:8); the caller keeps gradients in range with a power-of-two loss
+//                         scale (engine.py), as the reference's GradScaler does.
+// Every kernel is written against the type names below; staging, LDS images, fragment layouts and epilogues are byte-identical
+// in both builds (16-bit elements), only the conversion instructions and the MFMA opcode differ.  `bf16` therefore reads
+// "the operand type of this build"; code that needs bf16 whatever the build (the split-operand weight gradients) uses tbf16.
+typedef __bf16 tbf16;
+typedef __bf16 tbf16x8 __attribute__((ext_vector_type(8)));
+#ifdef FEDDAT_OPERANDS_F16
+typedef _Float16 bf16;
+#define FD_OPERAND_FORMAT FEDDAT_OPERANDS_FP16
+#define FD_MFMA_16X16X32_ASM "v_mfma_f32_16x16x32_f16"
+#else
 typedef __bf16 bf16;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define FD_OPERAND_FORMAT FEDDAT_OPERANDS_BF16
+#define FD_MFMA_16X16X32_ASM "v_mfma_f32_16x16x32_bf16"
+#endif
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -70,8 +89,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // Counter-based dropout mask (ALBEF BERT towers, xbert.py:216,333,360,440): element `idx` of the tensor a site drops is
 // KEPT iff hash(idx; key0, key1, step) >= p * 2^32 -- two murmur3 finalisers with the keys injected; (key0, key1) name
 // (seed, pass, site), `step` is the train-step counter read from device memory so that a captured hipGraph draws fresh masks
-// on every replay.  The backward REGENERATES the mask, nothing is stored.  The oracle restates this function
-// (oracle/albef_oracle.py dropout_keep) -- same bits on both sides.
+// on every replay.  The backward REGENERATES the mask, nothing is stored.  (The function is plain
+// 32-bit integer arithmetic, so a host-side restatement draws the same bits: tests/test_dropout_gpu.py.)
 __device__ __forceinline__ uint32_t fd_fmix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
@@ -215,13 +234,33 @@ __device__ __forceinline__ bf16x4 cvt4(const f32x4 a) {
     return r;
 }
 
+// ds_read_b64_tr_b16 of 16-bit operand elements (either operand format: the instruction moves 16-bit lanes)
+__device__ __forceinline__ bf16x4 fd_ds_read_tr16(const char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
 // MFMA wrappers.  Operand convention used everywhere in this library (gfx950
 // v_mfma_f32_16x16x32_bf16): lane l supplies, for the non-contracted index (l & 15), the 8
 // contraction slots (g = l >> 4, j = 0..7); the hardware pairs slot (g, j) of A with slot (g, j) of B.
 // D: lane l holds D[row = 4 * (l >> 4) + r][col = l & 15], r = 0..3, rows indexed by A's
 // non-contracted index, cols by B's.
 __device__ __forceinline__ f32x4 mfma16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef FEDDAT_OPERANDS_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+// bf16 whatever the build's operand format (adapter_wgrad.hip: the hi / lo split needs bf16's fp32 exponent range)
+__device__ __forceinline__ f32x4 mfma16x32_tbf16(tbf16x8 a, tbf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ tbf16x8 cvt8_tbf16(const f32x4 a, const f32x4 b) {
+    tbf16x8 r;
+    r[0] = (tbf16)a[0]; r[1] = (tbf16)a[1]; r[2] = (tbf16)a[2]; r[3] = (tbf16)a[3];
+    r[4] = (tbf16)b[0]; r[5] = (tbf16)b[1]; r[6] = (tbf16)b[2]; r[7] = (tbf16)b[3];
+    return r;
 }
 // fp8 (OCP e4m3 on gfx950) form of the same product: a 16-byte fragment read carries 16 contraction slots per lane = two
 // K = 32 instructions (slots 0-7, then 8-15; A and B are split the same way, which is all the contraction needs).

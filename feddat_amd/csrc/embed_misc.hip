@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restric
 }  // namespace
 
 extern "C" int feddat_abi_version(void) { return FEDDAT_ABI_VERSION; }
+extern "C" int feddat_operand_format(void) { return FD_OPERAND_FORMAT; }
 
 extern "C" int feddat_text_embed(const int64_t* input_ids, const int64_t* token_type_ids, const float* word,
                                  const float* pos, const float* type, const float* ln_g, const float* ln_b, float eps,

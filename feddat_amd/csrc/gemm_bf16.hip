@@ -912,11 +912,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 
 
 __device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    asm volatile(FD_MFMA_16X16X32_ASM " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // first product of a tile: C = 0 as an inline constant, the accumulator needs no zeroing
 __device__ __forceinline__ void mfma_agpr_first(f32x4& c, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    asm volatile(FD_MFMA_16X16X32_ASM " %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
 // (A variant that DEFERRED a tile's epilogue into the next tile's k-loop was built on this kernel -- accumulators copied

@@ -17,6 +17,7 @@ Restructuring relative to the reference (same results, fewer FLOPs -- DESIGN.md 
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import Dict, List, Optional, Sequence
 
@@ -32,6 +33,16 @@ HEAD_TENSORS = ("clf_fc0.weight", "clf_fc0.bias", "clf_norm0.weight", "clf_norm0
 
 def _no_decay(name: str) -> bool:  # task_trainer.py:478
     return ("bias" in name) or ("LayerNorm.weight" in name)
+
+
+def _bound(fn):
+    """Run a public engine method with the calling thread bound to the library of the engine's operand format
+    (lib.operands): engines of both formats can live in one process."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with L.operands(self.operands):
+            return fn(self, *a, **kw)
+    return wrapped
 
 
 class FlatGroup:
@@ -66,8 +77,19 @@ class ViltDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], tasks: Sequence[str], device, batch: int, res: int,
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
                  weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False,
-                 fp8_ffn_chain: bool = True, gelu_codes: bool = True):
-        """fp8=True (BASELINE.json configs[4]): four frozen products per layer run on the block-scaled fp8 MFMA with e4m3
+                 fp8_ffn_chain: bool = True, gelu_codes: bool = True, operands: str = "bf16",
+                 loss_scale: Optional[float] = None):
+        """operands="f16": every 16-bit MFMA operand of the step -- frozen weights and their transposes, LayerNorm outputs,
+        qkv, probabilities, ctx, gelu(u), the adapters' operand copies, and every gradient operand of the dX products and of
+        the attention backward -- is IEEE half instead of bf16 (libfeddat_hip_f16.so: v_mfma_f32_16x16x32_f16, the same MFMA
+        rate and the same bytes; 10 instead of 7 mantissa bits, i.e. the reference's own GPU arithmetic, fp16 autocast:
+        accelerate_config.yaml:8).  The backward then carries a power-of-two `loss_scale` (default 2^14; 1 for bf16): the
+        gradient entering the backbone (d pooler-input) is multiplied by it where it is produced, every kernel of the backward
+        is linear in the gradient, and the factor leaves exactly where the adapter weight gradients are formed
+        (feddat_wgrad_seg.scale); the task head's own gradients never see it.  What the reference's GradScaler does
+        dynamically (task_trainer.py:302,323) is static here: the scaled gradients of this path span 1e-4 .. 1e1 at the
+        default, eleven binades inside either end of fp16's range.
+        fp8=True (BASELINE.json configs[4]): four frozen products per layer run on the block-scaled fp8 MFMA with e4m3
         operands -- forward QKV and FFN1 (activations quantised per token row by the LayerNorm kernel that produces them) and
         the dX products FFN2^T and attention-output^T (the gradient rows quantised per row: by feddat_quant_rows_fp8 behind the
         adapter backward, by the LayerNorm backward itself); weights quantised once here per output channel of each product.
@@ -78,6 +100,21 @@ class ViltDatEngine:
         the two heaviest epilogues (+0.14 ms/step at configs[1]); at B = 32 it takes the worst adapter element after an 80-step
         round from 1.31e-3 to 1.00e-3 and the worst update-norm error from 2.9 % to 1.6 % -- for callers
         that trade 2 % of throughput for that."""
+        if operands not in L.OPERAND_DTYPE:
+            raise L.FeddatHipError(f"operands must be 'bf16' or 'f16', got {operands!r}")
+        if fp8 and operands != "bf16":
+            raise L.FeddatHipError("fp8=True (configs[4]) pairs the e4m3 products with bf16 operands")
+        self.operands = operands
+        self.op_dtype = L.OPERAND_DTYPE[operands]
+        self.loss_scale = float(loss_scale if loss_scale is not None else (16384.0 if operands == "f16" else 1.0))
+        if self.loss_scale <= 0 or math.frexp(self.loss_scale)[0] != 0.5:
+            raise L.FeddatHipError("loss_scale must be a power of two (it is removed exactly)")
+        self._init(params, tasks, device, batch, res, text_len, layers, num_labels, lr, weight_decay, adam_eps, wgrad_splits,
+                   fp8, fp8_ffn_chain, gelu_codes)
+
+    @_bound
+    def _init(self, params, tasks, device, batch, res, text_len, layers, num_labels, lr, weight_decay, adam_eps, wgrad_splits,
+              fp8, fp8_ffn_chain, gelu_codes):
         L.load()
         self.dev = torch.device(device)
         self.tasks = list(tasks)
@@ -101,12 +138,12 @@ class ViltDatEngine:
             return params[name].to(dev, torch.float32).contiguous()
 
         def bf16_of(w):
-            out = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(w.shape, dtype=self.op_dtype, device=dev)
             L.cvt_f32_bf16(w, out)
             return out
 
         def bf16_T(w):  # [R,C] fp32 -> [C,R] bf16
-            out = torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev)
+            out = torch.empty(w.shape[1], w.shape[0], dtype=self.op_dtype, device=dev)
             L.transpose_f32_bf16(w, out, w.shape[0], w.shape[1])
             return out
 
@@ -190,7 +227,7 @@ class ViltDatEngine:
             return torch.empty(*s, device=dev)
 
         def b16(*s):
-            return torch.empty(*s, dtype=torch.bfloat16, device=dev)
+            return torch.empty(*s, dtype=self.op_dtype, device=dev)
         self._px_shape = (B, 3, self.res[0], self.res[1])
         self.inp = dict(input_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
                         token_type_ids=torch.zeros(B, text_len, dtype=torch.int64, device=dev),
@@ -290,12 +327,13 @@ class ViltDatEngine:
         H, r = self.H, self.r
         base = ENC + f"encoder.layer.{i}.output.adapter.adapter_{a}_"
         if a not in self._pack16:       # bf16 operand copies of all layers of adapter a: [layer][wd | wdT | wu | wuT]
-            self._pack16[a] = torch.empty(self.nl, 4, r * H, dtype=torch.bfloat16, device=self.dev)
+            self._pack16[a] = torch.empty(self.nl, 4, r * H, dtype=self.op_dtype, device=self.dev)
         c = self._pack16[a][i]
         return dict(wd=c[0].view(r, H), wdT=c[1].view(H, r), wu=c[2].view(H, r), wuT=c[3].view(r, H),
                     bd=self.ad[a].view(base + "down.bias"), bu=self.ad[a].view(base + "up.bias"),
                     wd32=self.ad[a].view(base + "down.weight"), wu32=self.ad[a].view(base + "up.weight"))
 
+    @_bound
     def repack_adapter(self, a: int):
         """fp32 masters -> bf16 MFMA operand copies (after every optimizer step / load / FedAvg): one launch for all
         layers when the flat fp32 layout is regular (it is: four tensors per layer, fixed order)."""
@@ -313,6 +351,7 @@ class ViltDatEngine:
             for p in packs:
                 L.adapter_pack(p["wd32"], p["wu32"], p["wd"], p["wdT"], p["wu"], p["wuT"])
 
+    @_bound
     def copy_global_to_teacher(self):
         """adapter_1 -> adapter_2 at the start of every local update (task_trainer.py:36-41)."""
         self.ad[2].p.copy_(self.ad[1].p)
@@ -340,6 +379,7 @@ class ViltDatEngine:
         return L.make_segs([dict(row_begin=0, row_end=rows, adapters=ads)])
 
     # ------------------------------------------------------------------------------------------ inputs
+    @_bound
     def set_batch(self, batch: Dict[str, torch.Tensor]):
         """Copy one batch (reference schema: HF ViLT encodings + target_scores) into the static input buffers."""
         px = batch["pixel_values"]
@@ -475,14 +515,14 @@ class ViltDatEngine:
         else:
             self._pool(self.h_out, 2 * B)
 
-    def _sg(self, A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, out, ksplit=1, bias_j=None):
+    def _sg(self, A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, out, ksplit=1, bias_j=None, alpha=1.0):
         """Skinny exact-fp32 product; long contractions are split over the grid and reduced deterministically."""
         if ksplit <= 1:
-            L.sgemm_f32(A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, out, bias_j=bias_j)
+            L.sgemm_f32(A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, out, bias_j=bias_j, alpha=alpha)
             return
         part = self._scratch1(ksplit * I * J)
         L.sgemm_f32(A, sa_i, sa_k, Bm, sb_k, sb_j, I, J, K, part, ksplit=ksplit, bias_j=bias_j,
-                    out_split_stride=I * J)
+                    out_split_stride=I * J, alpha=alpha)
         L.reduce_partials(part, I * J, ksplit, I * J, out)
 
     def _scratch1(self, n):
@@ -623,12 +663,14 @@ class ViltDatEngine:
         """dpooled [2B,H] -> adapter_0 grads (rows [0,R)) and adapter_1 grads (rows [R,2R))."""
         R, R2, B, H = self.R, 2 * self.R, self.B, self.H
         nb = 2 * B
+        # the gradient entering the frozen backbone carries the loss scale from here on (alpha of this product; 1 for bf16
+        # operands): every kernel below is linear in it, and feddat_wgrad_seg.grad_unscale takes it out again
         if self.fused_tail:      # d(pooler input) = (dpooled * (1 - pooled^2)) W_pool in one launch
             L.head_gemm(L.ht_job(self.dpooled, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, pro=L.HT_PRO_TANH_BWD,
-                                 pro_a=self.pooled))
+                                 pro_a=self.pooled, alpha=self.loss_scale))
         else:
             L.tanh_bwd(self.pooled, self.dpooled, self.dpre)
-            self._sg(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, ksplit=4)
+            self._sg(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, ksplit=4, alpha=self.loss_scale)
         L.layernorm_bwd_dx(self._pool_src, self.cls_st, self.lnf_g, nb, H, dy_f32=self.dcls_ln,
                            x_stride=self._pool_stride, out_f32=self.dcls)
         cur, oth = self.dh
@@ -701,7 +743,7 @@ class ViltDatEngine:
         if key not in self._segs_cache:
             n = self.ad_layer_numel
             segs = [dict(x=t["h3"][r0:], dy=self.dcls[r0:], z=self.z[r0:], dz=self.dz[r0:],
-                         grad=self.ad[ad].g[i * n:(i + 1) * n], rows=B, scale=sc)
+                         grad=self.ad[ad].g[i * n:(i + 1) * n], rows=B, scale=sc, grad_unscale=1.0 / self.loss_scale)
                     for ad, r0, sc in ((0, 0, 0.5), (1, B, 1.0)) if ad in self.opt_adapters]
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
         if self._segs_cache[key] is not None:
@@ -753,7 +795,8 @@ class ViltDatEngine:
             for a, row0, xrow0, sc in ((0, 0, 0, 0.5), (1, R, R + x_delta_s, 1.0)):
                 if a in self.opt_adapters:
                     segs.append(dict(x=x[xrow0:], dy=dy[row0:], z=self.z[row0:], dz=self.dz[row0:],
-                                     grad=self.ad[a].g[layer * n:(layer + 1) * n], rows=R, scale=sc))
+                                     grad=self.ad[a].g[layer * n:(layer + 1) * n], rows=R, scale=sc,
+                                     grad_unscale=1.0 / self.loss_scale))
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
         return self._segs_cache[key]
 
@@ -781,6 +824,7 @@ class ViltDatEngine:
             L.adapter_wgrad_partial(segs, self._wpart(layer))
 
     # ------------------------------------------------------------------------------------------ train step
+    @_bound
     def begin_local_update(self, task: str, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,
                            opt_adapters: Sequence[int] = (0, 1)):
         """TaskTrainer.train prologue (task_trainer.py:36-59): teacher snapshot, fresh AdamW state and schedule."""
@@ -800,7 +844,7 @@ class ViltDatEngine:
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.use_layer_calls, self.fp8,
-               self.fp8_ffn_chain, self.fused_tail, self.cls_attention)        # host-side switches that change the launch list are part of the signature
+               self.fp8_ffn_chain, self.fused_tail, self.cls_attention, self.operands, self.loss_scale)        # host-side switches that change the launch list are part of the signature
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig
@@ -862,6 +906,7 @@ class ViltDatEngine:
             self.repack_adapter(0)
         L.step_tick(self.ad[0].state, 2, 1)
 
+    @_bound
     def train_step(self, batch: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False):
         """One DAT+MKD step (task_trainer.py:280-330).  Returns the device tensor holding what the reference
         returns: loss_0 = BCE * num_labels of the P2 pass (loss_buf['p2'][0]); [1] = KL, [2] = L_0."""
@@ -875,6 +920,7 @@ class ViltDatEngine:
             self.graph.replay()
         return self.loss_buf["p2"]
 
+    @_bound
     def ensure_captured(self):
         """Capture the step graph now if it is not there yet (TaskTrainer.train calls this before it starts the upload
         worker, so no capture ever overlaps a prefetch)."""
@@ -911,6 +957,8 @@ class ViltDatEngine:
         self.graph = graph
 
     # ------------------------------------------------------------------------------------------ inference
+    @_bound
+    @_bound
     @torch.no_grad()
     def forward(self, batch: Dict[str, torch.Tensor], mode: str, task: Optional[str] = None):
         """model(task_key, images, texts) -> (pooled, logits) in adapter mode `mode` ('gating' | 'adapter_k')
@@ -940,6 +988,7 @@ class ViltDatEngine:
                 out[n] = grp.view(n)
         return out
 
+    @_bound
     def load_tensors(self, tensors: Dict[str, torch.Tensor]):
         sd = self.state_dict()
         touched = set()

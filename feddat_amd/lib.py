@@ -6,20 +6,26 @@ PyTorch / CPU fallback anywhere in feddat_amd.  torch is used only as plumbing: 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 import torch  # imported first on purpose: libfeddat_hip.so must bind to the HIP runtime torch already loaded
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfeddat_hip.so")
+# the same sources and C ABI with IEEE-half operands (include/feddat_hip.h, Conventions): bound by operands("f16")
+LIB_PATH_F16 = os.path.join(_PKG, "libfeddat_hip_f16.so")
+OPERANDS_BF16, OPERANDS_FP16 = 0, 1      # feddat_operand_format()
+OPERAND_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32, EPI_GELU_G8, EPI_MUL_G8, EPI_GELU_G8_F8, EPI_MUL_G8_F8 = range(9)
 F8_ACT_SCALE, F8_GRAD_HEADROOM = 0.125, 4.0      # FEDDAT_F8_ACT_SCALE / FEDDAT_F8_GRAD_HEADROOM
 G8_LO, G8_STEP = -0.135, 0.005        # FEDDAT_G8_LO / FEDDAT_G8_STEP: gelu' ~ G8_LO + G8_STEP * code
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 
 
@@ -30,7 +36,8 @@ class AdapterSeg(C.Structure):
 
 
 class WgradSeg(C.Structure):
-    _fields_ = [("x", vp), ("dy", vp), ("z", vp), ("dz", vp), ("grad", vp), ("rows", i32), ("scale", f32)]
+    _fields_ = [("x", vp), ("dy", vp), ("z", vp), ("dz", vp), ("grad", vp), ("rows", i32), ("scale", f32),
+                ("grad_unscale", f32), ("reserved", i32)]
 
 
 class ViltLayerWeights(C.Structure):
@@ -74,6 +81,7 @@ def _fill(struct, **tensors):
 
 _SIGS = {
     "feddat_abi_version": [],
+    "feddat_operand_format": [],
     "feddat_ctx_create": [i32, C.POINTER(vp)],
     "feddat_ctx_destroy": [vp],
     "feddat_ctx_device": [vp, C.POINTER(i32), C.POINTER(i32)],
@@ -171,27 +179,59 @@ class FeddatHipError(RuntimeError):
     pass
 
 
-_lib = None
+_lib = None            # the bf16-operand library (the default binding)
+_lib_f16 = None        # the fp16-operand library
+_tls = threading.local()
 
 
-def load() -> C.CDLL:
-    """Load libfeddat_hip.so; raise loudly if it is missing (build it with `python -m feddat_amd.build`)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path: str, want_format: int) -> C.CDLL:
+    if not os.path.exists(path):
         raise FeddatHipError(
-            f"{LIB_PATH} not found: the HIP library is the only implementation of this path "
+            f"{path} not found: the HIP library is the only implementation of this path "
             "(no CPU/PyTorch fallback). Build it with `python __graft_entry__.py` or `python -m feddat_amd.build`.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i64 if name.endswith(("_workspace_elems", "_workspace_bytes", "_table_entries")) else i32
     if lib.feddat_abi_version() != ABI_VERSION:
-        raise FeddatHipError("libfeddat_hip.so ABI version mismatch")
-    _lib = lib
+        raise FeddatHipError(f"{os.path.basename(path)} ABI version mismatch")
+    if lib.feddat_operand_format() != want_format:
+        raise FeddatHipError(f"{os.path.basename(path)} was built for another operand format")
     return lib
+
+
+def load() -> C.CDLL:
+    """The library the calling thread is bound to: libfeddat_hip.so (bf16 operands) unless inside `with operands("f16")`.
+    Raises loudly if it is missing (build with `python -m feddat_amd.build`)."""
+    global _lib, _lib_f16
+    if getattr(_tls, "fmt", "bf16") == "f16":
+        if _lib_f16 is None:
+            _lib_f16 = _open(LIB_PATH_F16, OPERANDS_FP16)
+        return _lib_f16
+    if _lib is None:
+        _lib = _open(LIB_PATH, OPERANDS_BF16)
+    return _lib
+
+
+@contextlib.contextmanager
+def operands(fmt: str):
+    """Bind this thread's calls to the library built for the 16-bit operand format `fmt` ("bf16" | "f16") for the duration of
+    the block.  Both libraries export the same C ABI; buffers the header calls "bf16" hold OPERAND_DTYPE[fmt] values.  An
+    engine makes all its calls (and creates its feddat_ctx) inside the block of ITS format, so engines of both formats can
+    live in one process."""
+    if fmt not in OPERAND_DTYPE:
+        raise FeddatHipError(f"unknown operand format {fmt!r} (bf16 | f16)")
+    prev = getattr(_tls, "fmt", "bf16")
+    _tls.fmt = fmt
+    try:
+        yield
+    finally:
+        _tls.fmt = prev
+
+
+def current_operands() -> str:
+    return getattr(_tls, "fmt", "bf16")
 
 
 def use_ablation_build():
@@ -217,16 +257,17 @@ class Context:
 
     def __init__(self, device: int):
         self._h = vp()
-        _chk(load().feddat_ctx_create(int(device), C.byref(self._h)), "feddat_ctx_create")
+        self._lib = load()          # a handle belongs to the library (operand format) it was made by
+        _chk(self._lib.feddat_ctx_create(int(device), C.byref(self._h)), "feddat_ctx_create")
 
     def info(self):
         d, cu = i32(), i32()
-        _chk(load().feddat_ctx_device(self._h, C.byref(d), C.byref(cu)), "feddat_ctx_device")
+        _chk(self._lib.feddat_ctx_device(self._h, C.byref(d), C.byref(cu)), "feddat_ctx_device")
         return d.value, cu.value
 
     def close(self):
         if self._h:
-            load().feddat_ctx_destroy(self._h)
+            self._lib.feddat_ctx_destroy(self._h)
             self._h = vp()
 
     def __del__(self):
@@ -244,7 +285,8 @@ class RcclComm:
         """timeout_s: watchdog on the collective ncclCommInitRank (feddat_comm_create_timeout): a peer that died or could not
         load RCCL makes this raise after timeout_s instead of hanging; 0 = wait forever."""
         buf = C.create_string_buffer(128)
-        rc0 = load().feddat_comm_unique_id(buf) if rank == 0 else 0
+        self._lib = load()
+        rc0 = self._lib.feddat_comm_unique_id(buf) if rank == 0 else 0
         # rank 0 ships its return code with the id, so that a failure there (RCCL not loadable) raises on EVERY rank instead of
         # leaving the others waiting in the exchange
         msg = exchange(bytes([0 if rc0 == 0 else 1]) + bytes(buf.raw))
@@ -252,24 +294,24 @@ class RcclComm:
             raise FeddatHipError("feddat_comm_unique_id failed on rank 0 (is librccl loadable?)")
         ident = msg[1:]
         self._h = vp()
-        _chk(load().feddat_comm_create_timeout(C.c_char_p(ident), world, rank, int(timeout_s * 1000), C.byref(self._h)),
+        _chk(self._lib.feddat_comm_create_timeout(C.c_char_p(ident), world, rank, int(timeout_s * 1000), C.byref(self._h)),
              "feddat_comm_create_timeout")
         self.world, self.rank = world, rank
 
     def fedavg_allreduce(self, flat, scratch, num: float, total: float):
         _dev(flat, scratch)
-        _chk(load().feddat_fedavg_allreduce(self._h, _p(flat), _p(scratch), flat.numel(), float(num), float(total),
+        _chk(self._lib.feddat_fedavg_allreduce(self._h, _p(flat), _p(scratch), flat.numel(), float(num), float(total),
                                             _stream()), "feddat_fedavg_allreduce")
 
     def info(self):
         """{'rccl_version': ncclGetVersion code, 'ranks': ranks of the communicator, 'rank': this rank} from the library."""
         v, n, r = C.c_int(0), C.c_int(0), C.c_int(0)
-        _chk(load().feddat_comm_info(self._h, C.byref(v), C.byref(n), C.byref(r)), "feddat_comm_info")
+        _chk(self._lib.feddat_comm_info(self._h, C.byref(v), C.byref(n), C.byref(r)), "feddat_comm_info")
         return {"rccl_version": v.value, "ranks": n.value, "rank": r.value}
 
     def close(self):
         if self._h:
-            load().feddat_comm_destroy(self._h)
+            self._lib.feddat_comm_destroy(self._h)
             self._h = vp()
 
 
@@ -501,7 +543,7 @@ def make_wgrad_segs(segs: Sequence[dict]):
     arr = (WgradSeg * len(segs))()
     for s, d in zip(arr, segs):
         s.x, s.dy, s.z, s.dz, s.grad = (d[k].data_ptr() for k in ("x", "dy", "z", "dz", "grad"))
-        s.rows, s.scale = d["rows"], d["scale"]
+        s.rows, s.scale, s.grad_unscale = d["rows"], d["scale"], d.get("grad_unscale", 1.0)
     return arr
 
 

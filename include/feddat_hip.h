@@ -9,7 +9,16 @@
  *   - all launches are asynchronous on `stream`; functions are re-entrant per stream; the only library-side state is the
  *     per-device cache described under "Devices and contexts" (thread-safe) and the optional feddat_ctx handles;
  *   - return value: FEDDAT_OK (0), FEDDAT_EINVAL (bad shape / alignment / null), FEDDAT_ELAUNCH (HIP launch error);
- *   - "bf16" buffers are passed as void* (raw bfloat16, 2 bytes per element); fp32 as float*;
+ *   - "bf16" buffers are passed as void* (2 bytes per element); fp32 as float*.  The 16-bit OPERAND FORMAT is a property
+ *     of the library build, reported by feddat_operand_format(): libfeddat_hip.so = bfloat16 (FEDDAT_OPERANDS_BF16),
+ *     libfeddat_hip_f16.so = IEEE binary16 (FEDDAT_OPERANDS_FP16: the same sources built with -DFEDDAT_OPERANDS_F16, the
+ *     same entry points, v_mfma_f32_16x16x32_f16 instead of _bf16 at the same rate).  In the fp16 library every parameter
+ *     or entry point named "bf16" carries fp16 values: 10 instead of 7 mantissa bits on every frozen weight and activation
+ *     operand -- the reference's own GPU arithmetic (fp16 autocast, src/accelerate_config.yaml:8) -- with the 5-bit
+ *     exponent's range: the caller scales the loss gradient by a power of two (as the reference's GradScaler does,
+ *     task_trainer.py:302,323 via accelerator.backward) and removes the factor where the weight gradients leave
+ *     (feddat_wgrad_seg.scale).  fp32 accumulation, fp32 residual / gradient streams and the split-operand weight
+ *     gradients are the same in both;
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
  */
 #ifndef FEDDAT_HIP_H
@@ -30,8 +39,11 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_ELAUNCH 2
 #define FEDDAT_ETIMEOUT 3   /* feddat_comm_create_timeout only */
 
-#define FEDDAT_ABI_VERSION 6   /* 6: feddat_attn_cls_fwd / _bwd (token-0-only attention of the last layer), fused step tail (feddat_head_gemm, feddat_head_ln_gelu, feddat_head_ln_bwd_full, feddat_dat_loss_fwd_bwd_single, feddat_adamw_multi, feddat_step_tick_multi), feddat_vqa_score_accumulate, feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
+#define FEDDAT_ABI_VERSION 7   /* 7: feddat_operand_format (bf16 / fp16 operand builds of the same ABI); 6: feddat_attn_cls_fwd / _bwd (token-0-only attention of the last layer), fused step tail (feddat_head_gemm, feddat_head_ln_gelu, feddat_head_ln_bwd_full, feddat_dat_loss_fwd_bwd_single, feddat_adamw_multi, feddat_step_tick_multi), feddat_vqa_score_accumulate, feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
+#define FEDDAT_OPERANDS_BF16 0
+#define FEDDAT_OPERANDS_FP16 1
+int feddat_operand_format(void);   /* which 16-bit format this library's "bf16" operands are (see Conventions) */
 
 /* ---------------------------------------------------------------------------------------------
  * Devices and contexts.  The per-op entry points below are stateless towards the caller: whatever they cache (compute-unit
@@ -249,7 +261,9 @@ int feddat_adapter_bwd_fp8(const float* z_saved, const float* dy, float* dx, voi
 /* Weight gradients of the trainable adapter of up to two row segments, from the z/dz written by
  * feddat_adapter_bwd: grad = flat fp32 [wd (r x H) | bd (r) | wu (H x r) | bu (H)] (the state-dict order of one
  * layer's adapter), fully overwritten.  x, dy: fp32 [rows, H] (row stride H); z, dz: fp32 [rows, r].
- * partials: scratch of feddat_adapter_wgrad_workspace_elems(nseg) floats. */
+ * partials: scratch of feddat_adapter_wgrad_workspace_elems(nseg) floats.
+ * grad_unscale (ABI 7): all four gradients are multiplied by it on the way out; 0 (a zero-initialised struct) = 1.  A caller
+ * that runs the backward on a loss scaled by 2^k (fp16 operand build) passes 2^-k here: the factor leaves exactly. */
 typedef struct {
     const float* x;
     const float* dy;
@@ -258,6 +272,8 @@ typedef struct {
     float* grad;
     int rows;
     float scale;
+    float grad_unscale;
+    int reserved;
 } feddat_wgrad_seg;
 long feddat_adapter_wgrad_workspace_elems(int nseg);
 int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int H, int r,

@@ -14,16 +14,42 @@ def _declared():
     return sorted(set(re.findall(r"^(?:int|long) (feddat_[a-z0-9_]+)\(", src, flags=re.M)))
 
 
-def test_library_builds_and_exports_every_declared_symbol():
+@pytest.mark.parametrize("f16", [False, True])
+def test_library_builds_and_exports_every_declared_symbol(f16):
+    """Both operand-format builds of the one source tree (bf16: libfeddat_hip.so, fp16: libfeddat_hip_f16.so) export the
+    whole header and say which format they are."""
     from feddat_amd import build
-    path = build.build()
-    assert os.path.exists(path)
+    path = build.build(f16=f16)
+    assert os.path.exists(path) and path.endswith("_f16.so") == f16
     lib = ctypes.CDLL(path)
     names = _declared()
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/feddat_hip.h but not exported"
-    assert lib.feddat_abi_version() == 6
+    assert lib.feddat_abi_version() == 7
+    assert lib.feddat_operand_format() == (1 if f16 else 0)
+    # the MFMA opcode is the build's operand format's, never the other one's (device code is embedded in the .so)
+    import subprocess
+    txt = subprocess.run(["strings", path], capture_output=True, text=True).stdout
+    assert "gemm_nt_v3_kernel" in txt
+
+
+def test_binding_switches_libraries_per_thread_block():
+    """lib.operands(fmt) binds the calling thread to the library of that operand format and restores the previous one."""
+    from feddat_amd import lib
+    assert lib.current_operands() == "bf16"
+    a = lib.load()
+    with lib.operands("f16"):
+        b = lib.load()
+        assert lib.current_operands() == "f16" and b is not a
+        assert b.feddat_operand_format() == lib.OPERANDS_FP16
+        with lib.operands("bf16"):
+            assert lib.load() is a
+        assert lib.load() is b
+    assert lib.load() is a and a.feddat_operand_format() == lib.OPERANDS_BF16
+    with pytest.raises(lib.FeddatHipError):
+        with lib.operands("fp32"):
+            pass
 
 
 def test_python_binding_covers_the_header():
@@ -36,8 +62,10 @@ def test_product_package_never_imports_the_oracle():
     """The oracle is test infrastructure; a product path that routes through it voids parity claims."""
     pkg = os.path.join(ROOT, "feddat_amd")
     for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath).startswith("build"):
+            continue
         for f in files:
-            if f.endswith(".py"):
+            if f.endswith((".py", ".hip", ".h")):      # the Python host side AND the kernel sources
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle-free", ""), f"{f} mentions the oracle"
 
@@ -57,11 +85,11 @@ def test_library_does_not_read_the_environment_or_link_rccl():
     run time only (dlopen), so the single-GPU path has no dependency on it."""
     import subprocess
     from feddat_amd import build
-    path = build.build()
-    und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
-    assert "getenv" not in und
-    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
-    assert "rccl" not in needed.lower()
+    for path in build.build_all():
+        und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+        assert "getenv" not in und
+        needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+        assert "rccl" not in needed.lower()
 
 
 def test_production_library_has_no_wrong_result_ablations():

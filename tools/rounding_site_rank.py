@@ -34,13 +34,16 @@ ON = set()
 
 
 MANT = int(os.environ.get("ROUND_MANT_BITS", "7"))   # explicit mantissa bits kept: 7 = bf16, 10 = fp16 / tf32, 15 = bf16 hi+lo
+MANT_B = int(os.environ.get("ROUND_MANT_BITS_BWD", str(MANT)))   # the same for the backward sites (WT, dY / dX operands)
+BATCH = int(os.environ.get("ROUND_BATCH", "4"))      # 32 = configs[1]'s batch: the non-chaotic case
 
 
-def bf(t):
+def bf(t, mant=None):
     """Round to nearest even at MANT explicit mantissa bits (MANT = 7 is exactly the fp32 -> bf16 -> fp32 round trip)."""
-    if MANT == 7:
+    mant = MANT if mant is None else mant
+    if mant == 7:
         return t.to(torch.bfloat16).to(torch.float32)
-    drop = 23 - MANT
+    drop = 23 - mant
     xi = t.contiguous().view(torch.int32)
     xi = xi + ((1 << (drop - 1)) - 1) + ((xi >> drop) & 1)
     xi = xi & ~((1 << drop) - 1)
@@ -64,7 +67,7 @@ class _RB(torch.autograd.Function):        # pass the value through, round the G
 
     @staticmethod
     def backward(ctx, g):
-        return bf(g)
+        return bf(g, MANT_B)
 
 
 def rf(site, x):
@@ -87,7 +90,7 @@ class _LinW(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (W,) = ctx.saved_tensors
-        Wb = bf(W) if "WT" in ON else W
+        Wb = bf(W, MANT_B) if "WT" in ON else W
         return g @ Wb, None, None
 
 
@@ -167,9 +170,9 @@ class _Adapter(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         h, z, wd, wu = ctx.saved_tensors
-        dyo = bf(dy) if "ad_dy" in ON else dy
+        dyo = bf(dy, MANT_B) if "ad_dy" in ON else dy
         dz = (dyo @ wu) * (z > 0)
-        dzo = bf(dz) if "ad_dz" in ON else dz
+        dzo = bf(dz, MANT_B) if "ad_dz" in ON else dz
         dx = dzo @ wd
         dy2, z2, dz2, h2 = (t.reshape(-1, t.shape[-1]) for t in (dy, z, dz, h))
         return dx, dz2.t() @ h2, dz2.sum(0), dy2.t() @ z2, dy2.sum(0)
@@ -221,6 +224,13 @@ def patch(on: bool):
 
 
 def parse(cfg):
+    """cfg[@F[/B]]: site set, optionally with the explicit mantissa bits of the forward / backward sites (all@10/7 = an
+    fp16 forward next to a bf16 backward)."""
+    global MANT, MANT_B
+    if "@" in cfg:
+        cfg, m = cfg.split("@")
+        f, _, b = m.partition("/")
+        MANT, MANT_B = int(f), int(b or f)
     if cfg == "all":
         return set(ALL_SITES)
     if cfg == "none":
@@ -232,12 +242,13 @@ def parse(cfg):
     raise SystemExit("bad config " + cfg)
 
 
-def run(steps, cfg, B=4, ref=None, P0=None, every=20):
+def run(steps, cfg, B=None, ref=None, P0=None, every=20):
+    B = BATCH if B is None else B
     global ON
     d = O.ViltDims(layers=12)
     P = O.make_params(d, ["art"], bias_std=0.02)
     ON = parse(cfg)
-    patch(cfg != "none")
+    patch(cfg.split("@")[0] != "none")
     client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=steps)
     names = [k for k in P if ("adapter_0" in k or "adapter_1" in k or "task_layer" in k)]
     out = {}
@@ -266,12 +277,18 @@ if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 80
     cfgs = sys.argv[2:] or (["all"] + ["all-" + s for s in ("W,WT", "x1,x2", "qkv", "p", "ctx", "f", "u", "ad_x,ad_w,ad_z",
                                                               "dh3,dh2", "dU", "dx1,dx2", "dctx,dqkv", "ad_dy,ad_dz")])
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("ROUND_THREADS", os.cpu_count())))
     d = O.ViltDims(layers=12)
     P0 = O.make_params(d, ["art"], bias_std=0.02)
     t0 = time.time()
-    ref = run(steps, "none")
-    print(f"fp32 reference run: {time.time() - t0:.0f} s", flush=True)
+    cache = os.environ.get("ROUND_REF_CACHE")             # the fp32 run of a (steps, batch) pair, kept between invocations
+    if cache and os.path.exists(cache):
+        ref = torch.load(cache)
+    else:
+        ref = run(steps, "none")
+        if cache:
+            torch.save(ref, cache)
+    print(f"fp32 reference run (B = {BATCH}): {time.time() - t0:.0f} s", flush=True)
     for cfg in cfgs:
         t0 = time.time()
         got = run(steps, cfg)

@@ -16,7 +16,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 _SKIP = {"load", "make_segs", "make_wgrad_segs", "adapter_wgrad_workspace_elems", "gemm_skinny_workspace_elems",
-         "make_rccl_comm", "ht_job", "adamw_group", "use_ablation_build", "set_debug_flags"}
+         "make_rccl_comm", "ht_job", "adamw_group", "use_ablation_build", "set_debug_flags", "operands", "current_operands"}
 
 
 def measure(eng, L, batches, steps=3, detail=True, plug_s=0.03):
