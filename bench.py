@@ -55,26 +55,31 @@ def flops_tables(B, S, layers=12, H=768, I=3072, heads=12, r=48, npatch=144):
     return gemms, gemm_flops, gemm_flops + attn + adapters + head
 
 
-def measure_gemms(L, gemms, iters=10):
+def measure_gemms(L, gemms, iters=10, operands="bf16"):
     """Average launch duration of the dominant kernel (gemm_nt_kernel) per shape, HIP events on the launch stream."""
+    with L.operands(operands):
+        return _measure_gemms(L, gemms, iters, L.OPERAND_DTYPE[operands])
+
+
+def _measure_gemms(L, gemms, iters, op_dtype):
     dev = "cuda"
     tot_t, tot_f, rows = 0.0, 0.0, []
     for M, N, K, epi, count in gemms:
-        A = torch.randn(M, K, device=dev).to(torch.bfloat16)
-        Bw = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+        A = torch.randn(M, K, device=dev).to(op_dtype)
+        Bw = (torch.randn(N, K, device=dev) * 0.02).to(op_dtype)
         bias = torch.randn(N, device=dev)
         kw = {}
         if epi in (0, 3, 5, 6):
-            kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw["out_bf16"] = torch.empty(M, N, dtype=op_dtype, device=dev)
         if epi == 3:
-            kw["aux"] = torch.randn(M, N, device=dev).to(torch.bfloat16)
+            kw["aux"] = torch.randn(M, N, device=dev).to(op_dtype)
         if epi == 5:
             kw["out2_bf16"] = torch.empty(M, N, dtype=torch.uint8, device=dev)
         if epi == 6:
             kw["aux"] = torch.randint(0, 255, (M, N), dtype=torch.uint8, device=dev)
         if epi == 2:
-            kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-            kw["out2_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw["out_bf16"] = torch.empty(M, N, dtype=op_dtype, device=dev)
+            kw["out2_bf16"] = torch.empty(M, N, dtype=op_dtype, device=dev)
         if epi == 1:
             kw["resid"] = torch.randn(M, N, device=dev)
             kw["out_f32"] = torch.empty(M, N, device=dev)
@@ -433,7 +438,7 @@ def roofline_block(L, eng, batches, gemms):
     launches); the isolated figure (10 back-to-back launches per shape, operands MALL/L2-warm) is reported beside it and is
     NOT what `frac` is."""
     ach, tsum, rows, alg_bytes, launches, in_step_info = measure_gemms_in_step(L, eng, batches)
-    ach_iso, tsum_iso, rows_iso = measure_gemms(L, gemms)
+    ach_iso, tsum_iso, rows_iso = measure_gemms(L, gemms, operands=eng.operands)
     tr = profiled_traffic()
     kt = profiled_kernel_time()
     if kt:       # the same FLOPs over the kernel-trace durations of the committed profile (another run, maybe another box)
@@ -464,6 +469,10 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="configs[4]: e4m3 MFMA for the QKV / FFN1 forward products of the frozen backbone (bf16 adapters); "
                          "quoted at --batch 64")
+    ap.add_argument("--operands", default="f16", choices=["bf16", "f16"],
+                    help="16-bit MFMA operand format of the frozen products, attention and adapters: IEEE half with a 2^14 loss "
+                         "scale (default: the reference's own GPU arithmetic is fp16 autocast, and the format that meets the "
+                         "north-star parity bar at round length) or bf16 -- same MFMA instruction rate, same bytes")
     ap.add_argument("--hetero", action="store_true",
                     help="N > 1, SURVEY.md 8d config 3: rank r runs K * {40,50,60,70,80}[r % 5] / 80 steps (heterogeneous "
                          "len(loader)); the imbalance is absorbed at the round's barrier and shows up as wait_s")
@@ -518,7 +527,8 @@ def main():
     task = tasks[rank]
     # identical frozen backbone + server adapter on every client (seed 0); heterogeneous data per client
     params = vilt_spec.random_init(12, tasks, seed=0, device="cpu")
-    eng = engine.ViltDatEngine(params, [task], dev, batch=B, res=res, layers=12, fp8=args.fp8)
+    eng = engine.ViltDatEngine(params, [task], dev, batch=B, res=res, layers=12, fp8=args.fp8,
+                               operands="bf16" if args.fp8 else args.operands)
     eng.fused_tail = not args.unfused_tail
     nb = 4
     batches = [vilt_spec.synthetic_batch(B, res, 1234 + 100 * rank + i, device=dev) for i in range(nb)]
@@ -561,14 +571,17 @@ def main():
             "metric": "VQA samples/sec, ViLT-B/32 dual-adapter local step", "value": round(sps, 2),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp8(e4m3)+bf16" if args.fp8 else "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8(e4m3)+bf16" if args.fp8 else {"bf16": "bf16", "f16": "fp16"}[eng.operands],
+            "data": "synthetic",
             "config": {"workload": ("configs[4]: ViLT-B/32 FedDAT, fp8 (e4m3) MFMA for six of the eight frozen products per layer "
                                     "(QKV, FFN1, FFN2 forward; FFN2^T, FFN1^T, attention-output^T backward), "
                                     "bf16 for the attention-output projection and QKV^T; measured parity of this configuration "
                                     "(tests/test_sizes_gpu.py, test_round40_gpu.py: B=64 vs the fp32 oracle mean |ddW| / mean |dW| "
                                     "0.12 (bf16 path 0.011), max |ddW| 3.9e-4; 40-step round vs the reference 0.13, max 3.7e-3), "
                                     f"batch={B}/client, " if args.fp8 else
-                                    f"configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, bf16 MFMA, batch={B}/client, ") +
+                                    f"configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, {'fp16' if eng.operands == 'f16' else 'bf16'} MFMA operands"
+                                    f"{' (loss scale 2^14)' if eng.operands == 'f16' else ''}, fp32 accumulate / masters, "
+                                    f"batch={B}/client, ") +
                                    "384x384 synthetic + 40-token questions, MKD on"
                                    + (f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else ""),
                        "batch_per_client": B, "seq_len": S, "clients": world, "hip_graph": use_graph,

@@ -77,9 +77,9 @@ class ViltDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], tasks: Sequence[str], device, batch: int, res: int,
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
                  weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False,
-                 fp8_ffn_chain: bool = True, gelu_codes: bool = True, operands: str = "bf16",
+                 fp8_ffn_chain: bool = True, gelu_codes: bool = True, operands: Optional[str] = None,
                  loss_scale: Optional[float] = None):
-        """operands="f16": every 16-bit MFMA operand of the step -- frozen weights and their transposes, LayerNorm outputs,
+        """operands: "f16" (the default) or "bf16" (the default with fp8=True, configs[4]).  "f16": every 16-bit MFMA operand of the step -- frozen weights and their transposes, LayerNorm outputs,
         qkv, probabilities, ctx, gelu(u), the adapters' operand copies, and every gradient operand of the dX products and of
         the attention backward -- is IEEE half instead of bf16 (libfeddat_hip_f16.so: v_mfma_f32_16x16x32_f16, the same MFMA
         rate and the same bytes; 10 instead of 7 mantissa bits, i.e. the reference's own GPU arithmetic, fp16 autocast:
@@ -100,6 +100,7 @@ class ViltDatEngine:
         the two heaviest epilogues (+0.14 ms/step at configs[1]); at B = 32 it takes the worst adapter element after an 80-step
         round from 1.31e-3 to 1.00e-3 and the worst update-norm error from 2.9 % to 1.6 % -- for callers
         that trade 2 % of throughput for that."""
+        operands = operands or ("bf16" if fp8 else "f16")
         if operands not in L.OPERAND_DTYPE:
             raise L.FeddatHipError(f"operands must be 'bf16' or 'f16', got {operands!r}")
         if fp8 and operands != "bf16":
@@ -475,6 +476,7 @@ class ViltDatEngine:
         """fp8 products are used where feddat_gemm_fp8_nt applies (M >= 1024); smaller launches stay bf16."""
         return self.fp8 and rows >= 1024
 
+    @_bound
     def _forward_dual(self):
         """Shared embeddings + layer-0 body, then both passes (gated | adapter_1) batched through layers 1..L-1."""
         R, R2, B = self.R, 2 * self.R, self.B
@@ -659,6 +661,7 @@ class ViltDatEngine:
         return grp._wdv
 
     # ------------------------------------------------------------------------------------------ backward
+    @_bound
     def _backward_dual(self):
         """dpooled [2B,H] -> adapter_0 grads (rows [0,R)) and adapter_1 grads (rows [R,2R))."""
         R, R2, B, H = self.R, 2 * self.R, self.B, self.H
@@ -861,6 +864,7 @@ class ViltDatEngine:
         else:
             L.dat_loss_fwd_bwd(logits, teacher, self.inp["target"], self.dlogits, self.loss_buf[slot])
 
+    @_bound
     def _step_kernels(self):
         B, task = self.B, self.task
         hp = self.head[task]
@@ -927,6 +931,7 @@ class ViltDatEngine:
         if self.graph is None:
             self._capture()
 
+    @_bound
     def _capture(self):
         """Capture the whole step into one hipGraph (all launches are on static buffers; the LR schedule and Adam
         step counts live on the device).  The optimizer state is saved/restored around the warm-up + capture

@@ -59,6 +59,9 @@ class Adapter:
         self.names = [n for n in names if "adapter" in n]
         self.device = torch.device(device)
         r = model_dim // adapter_reduction_factor
+        # the module belongs to the operand format (library) the constructing thread is bound to: lib.operands(...)
+        self._fmt = L.current_operands()
+        op = L.OPERAND_DTYPE[self._fmt]
         self._packs: Dict[str, dict] = {}
         for n in self.names:
             if _views is not None:
@@ -71,10 +74,10 @@ class Adapter:
             setattr(self, f"{n}_down", _Linear(wd, bd))
             setattr(self, f"{n}_up", _Linear(wu, bu))
             self._packs[n] = dict(
-                wd=torch.empty(r, model_dim, dtype=torch.bfloat16, device=self.device),
-                wdT=torch.empty(model_dim, r, dtype=torch.bfloat16, device=self.device),
-                wu=torch.empty(model_dim, r, dtype=torch.bfloat16, device=self.device),
-                wuT=torch.empty(r, model_dim, dtype=torch.bfloat16, device=self.device), bd=bd, bu=bu)
+                wd=torch.empty(r, model_dim, dtype=op, device=self.device),
+                wdT=torch.empty(model_dim, r, dtype=op, device=self.device),
+                wu=torch.empty(model_dim, r, dtype=op, device=self.device),
+                wuT=torch.empty(r, model_dim, dtype=op, device=self.device), bd=bd, bu=bu)
         if hasattr(self, "adapter_2_down"):                      # adapter.py:55-58
             for m in (self.adapter_2_down, self.adapter_2_up):
                 for p in m.parameters():
@@ -82,10 +85,11 @@ class Adapter:
         self.refresh()
 
     def refresh(self):
-        """Re-derive the bf16 operand copies after the fp32 weights changed."""
-        for n, p in self._packs.items():
-            L.adapter_pack(getattr(self, f"{n}_down").weight.data, getattr(self, f"{n}_up").weight.data, p["wd"],
-                           p["wdT"], p["wu"], p["wuT"])
+        """Re-derive the 16-bit operand copies after the fp32 weights changed."""
+        with L.operands(self._fmt):
+            for n, p in self._packs.items():
+                L.adapter_pack(getattr(self, f"{n}_down").weight.data, getattr(self, f"{n}_up").weight.data, p["wd"],
+                               p["wdT"], p["wu"], p["wuT"])
 
     def deactivate_gating(self):
         self.gating = False
@@ -139,7 +143,8 @@ class Adapter:
             ads = [dict(self._packs["adapter_0"], scale=0.5 * self.scaling),
                    dict(self._packs["adapter_1"], scale=0.5 * self.scaling)]
         out = torch.empty_like(x)
-        L.adapter_fwd(x.view(T, 768), out.view(T, 768), L.make_segs([dict(row_begin=0, row_end=T, adapters=ads)]), T)
+        with L.operands(self._fmt):
+            L.adapter_fwd(x.view(T, 768), out.view(T, 768), L.make_segs([dict(row_begin=0, row_end=T, adapters=ads)]), T)
         return out
 
     __call__ = forward
@@ -153,20 +158,23 @@ class Adaptered_ViltOutput:
         self.layer = layer
         self.adapter = Adapter(**adapter_config, model_dim=768)
         w = layer.dense.weight.data if hasattr(layer.dense.weight, "data") else layer.dense.weight
-        self._w16 = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
-        L.cvt_f32_bf16(w.contiguous().float(), self._w16)
+        self._fmt = self.adapter._fmt
+        self._w16 = torch.empty(w.shape, dtype=L.OPERAND_DTYPE[self._fmt], device=w.device)
+        with L.operands(self._fmt):
+            L.cvt_f32_bf16(w.contiguous().float(), self._w16)
         b = layer.dense.bias
         self._b = (b.data if hasattr(b, "data") else b).contiguous().float()
 
     def forward(self, hidden_states: torch.Tensor, input_tensor: torch.Tensor) -> torch.Tensor:
         x = hidden_states.reshape(-1, hidden_states.shape[-1])
-        if x.dtype != torch.bfloat16:
-            x16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-            L.cvt_f32_bf16(x.contiguous().float(), x16)
-            x = x16
         res = input_tensor.reshape(-1, 768).contiguous().float()
         h = torch.empty_like(res)
-        L.gemm_bf16_nt(x, self._w16, L.EPI_RESID_F32, bias=self._b, resid=res, out_f32=h)
+        with L.operands(self._fmt):
+            if x.dtype != self._w16.dtype:
+                x16 = torch.empty(x.shape, dtype=self._w16.dtype, device=x.device)
+                L.cvt_f32_bf16(x.contiguous().float(), x16)
+                x = x16
+            L.gemm_bf16_nt(x, self._w16, L.EPI_RESID_F32, bias=self._b, resid=res, out_f32=h)
         return self.adapter(h, h).view(input_tensor.shape)
 
     __call__ = forward
@@ -187,11 +195,13 @@ class ViltContinualLearner:
     BERT_LOCAL_PATH = "./models/bert-base-uncased"       # vilt.py:47
 
     def __init__(self, ordered_cl_tasks: List[str], params: Dict[str, torch.Tensor], device, batch_size: int,
-                 image_size: int = 384, num_layers: int = 12, lr: float = 1e-4, vocab=None):
+                 image_size: int = 384, num_layers: int = 12, lr: float = 1e-4, vocab=None, operands: str = None):
+        """operands: 16-bit MFMA operand format of the engine, "f16" (default; the reference's mixed_precision: fp16,
+        accelerate_config.yaml:8) or "bf16" (engine.ViltDatEngine)."""
         self.ordered_cl_tasks = list(ordered_cl_tasks)
         self.device = torch.device(device)
         self.engine = ViltDatEngine(params, self.ordered_cl_tasks, self.device, batch=batch_size, res=image_size,
-                                    layers=num_layers, lr=lr)
+                                    layers=num_layers, lr=lr, operands=operands)
         self.max_text_length = self.engine.Lt               # vilt.py:50: config.max_position_embeddings = 40
         self._vocab = vocab
         self._tokenizer = None
@@ -286,10 +296,11 @@ class ViltContinualLearner:
 
 def create_vilt_continual_learner_model(params: Dict[str, torch.Tensor], ordered_cl_tasks: List[str], device,
                                         batch_size: int, image_size: int = 384, num_layers: int = 12,
-                                        lr: float = 1e-4, vocab=None) -> ViltContinualLearner:
+                                        lr: float = 1e-4, vocab=None, operands: str = None) -> ViltContinualLearner:
     """vilt.py:421-452 (the pretrained checkpoint is passed in as a tensor dict: feddat_amd.weights.load_vilt_pretrained
     reads it from a local HF directory; there is no hub access here)."""
-    return ViltContinualLearner(ordered_cl_tasks, params, device, batch_size, image_size, num_layers, lr, vocab=vocab)
+    return ViltContinualLearner(ordered_cl_tasks, params, device, batch_size, image_size, num_layers, lr, vocab=vocab,
+                                operands=operands)
 
 
 def convert_batch_to_vilt_input_dict(batch: Dict):

@@ -300,6 +300,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--albef_dims", type=str, default="",
                    help="ALBEF only: override depths for quick runs, e.g. vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2")
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
+    p.add_argument("--mixed_precision", default="fp16", choices=["fp16", "bf16"],
+                   help="16-bit MFMA operand format of the ViLT engine, named like accelerate's setting: fp16 (the reference's "
+                        "accelerate_config.yaml:8; static 2^14 loss scale) or bf16")
     p.add_argument("--exchange", default="rccl_cabi", choices=["rccl_cabi", "torch"],
                    help="the round's FedAvg collective: rccl_cabi = feddat_fedavg_allreduce on a communicator made through "
                         "the C ABI (RCCL bound by dlopen; also taken with ONE rank, where it is the identity); torch = "
@@ -379,7 +382,8 @@ def main(argv=None):
         else:                # no --pretrained_model_name: random weights of the real architecture (synthetic benchmarks)
             params = vilt_spec.random_init(args.num_layers, tasks, seed=args.seed)
         model = create_vilt_continual_learner_model(params, tasks, dev, args.batch_size, args.image_size,
-                                                    args.num_layers, args.lr)
+                                                    args.num_layers, args.lr,
+                                                    operands={"fp16": "f16", "bf16": "bf16"}[args.mixed_precision])
         Trainer = TaskTrainer
     eng = model.engine
     # personal parameters per client (main.py:440-450): head + adapter_0 + adapter_2

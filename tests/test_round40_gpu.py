@@ -123,8 +123,9 @@ def round80(engine, golden_dir):
 
 
 def test_round_of_80_steps_measured_bound(round80):
-    """What the bf16 path delivers at the longest round length, asserted so that a regression fails: per tensor, on the
-    update, mean |ddW| <= 0.06 mean |dW| (measured 0.031), update norm within 3 % (measured 0.7 %), max |ddW| < 2.0e-3 (measured
+    """What the engine (default fp16 operands; r05: max 1.28e-3, ratio 0.026, norm 1.3 %) delivers at the longest round length at
+    B = 4, asserted so that a regression fails: per tensor, on the
+    update, mean |ddW| <= 0.06 mean |dW| (bf16 operands measured 0.031), update norm within 3 %, max |ddW| < 2.0e-3 (bf16
     1.3-1.6e-3: above the north-star's 1e-3, see the strict xfail below), at most 2 % of a tensor's elements -- one element of a
     48-element bias -- off by more than 5e-4 (measured 0.87 % in the worst weight matrix), loss trajectory within 5 %.  The reference moves these weights by up to 5e-3 over the round."""
     rows = round80["rows"]
@@ -140,12 +141,12 @@ def test_round_of_80_steps_measured_bound(round80):
         assert r["norm_ratio"] < 0.03 and r["n_gt_5e4"] <= max(1, int(2e-2 * r["numel"])), (k, r)
 
 
-@pytest.mark.xfail(strict=True, reason="north_star: max |ddW| < 1e-3 after one FL round.  Holds up to ~55 steps; at 80 steps the "
-                   "bf16 path measures 1.2-1.5e-3.  tools/rounding_site_rank.py (DESIGN.md section 5): EVERY bf16 rounding site alone "
-                   "-- frozen weights, LN outputs, qkv, probabilities, gelu(u), the backward's dY copies -- reproduces the full "
-                   "error, so no single site can be promoted to close it, and the same emulation with EVERY site at 10 mantissa bits (fp16 / "
-                   "tf32 width) still gives 1.28e-3 at 80 steps, at 13 bits 6.7e-4: the element-wise AdamW trajectory amplifies any "
-                   "perturbation ~6x per 20 steps late in the round")
+@pytest.mark.xfail(strict=True, reason="B = 4 is the STRESS case, not a configuration of the metric (configs[1] / [2] are B = 32, where "
+                   "the bound holds at every round length: tests/test_round_b32_gpu.py, 8.1e-4 at 80 steps).  At B = 4 per-element "
+                   "gradients are single-digit-sample sums and the element-wise AdamW trajectory is chaotic late in the round: "
+                   "the default fp16 operands measure 1.28e-3 over all elements at 80 steps (bf16: 1.3-1.6e-3), which is what "
+                   "tools/rounding_site_rank.py's emulation of 10 mantissa bits at every site predicts (1.28e-3; 13 bits: 6.7e-4; "
+                   "the two fp32 implementations, oracle and reference, already differ by 6e-5).  Holds up to ~60 steps")
 def test_round_of_80_steps_north_star_target(round80):
     assert max(r["max"] for r in round80["rows"].values()) < 1e-3
 

@@ -11,7 +11,12 @@ length.  The engine replays the same 80 batches as one hipGraph per step (produc
   * test_b32_round_vs_live_oracle: the same run compared on ALL elements with the CPU oracle stepping batch for batch
     (the oracle is pinned to the reference's 40- and 80-step rounds at B = 4: tests/test_oracle_golden.py, and to this
     fixture's first snapshot below).
-The B = 4 rounds of tests/test_round40_gpu.py stay as the stress case: per-element gradients are noisiest there."""
+The B = 4 rounds of tests/test_round40_gpu.py stay as the stress case: per-element gradients are noisiest there.
+
+Round 5: both operand formats.  "f16" (the engine's default: fp16 MFMA operands + 2^14 loss scale, the reference's own
+mixed_precision) is asserted against north_star's bound itself -- every adapter AND head tensor, every snapshot, max |ddW| < 1e-3
+(measured 8.1e-4 at 80 steps, head 1.8e-4) --; "bf16" keeps its measured bounds, plus a strict-xfail copy of the north-star
+assertion at 80 steps so that the gap of that format stays visible."""
 import os
 
 import numpy as np
@@ -35,18 +40,21 @@ def _samples(flat, n=1024):
     return flat[torch.linspace(0, flat.numel() - 1, min(n, flat.numel())).long()]
 
 
-@pytest.fixture(scope="module")
-def b32_round(golden_dir):
+@pytest.fixture(scope="module", params=["f16", "bf16"])
+def b32_round(golden_dir, request):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from feddat_amd import engine
+    fmt = request.param
+    oracle_steps = ORACLE_STEPS if fmt == "f16" else 0      # the live oracle steps next to the default format only
     g = load(golden_dir, "g8b_round80_b32.npz")
     steps, B = int(g["steps"]), int(g["batch"])
     assert (steps, B) == (80, 32)
     d = O.ViltDims(layers=12)
     P = O.make_params(d, ["art"], bias_std=0.02)
     P0 = {k: v.clone() for k, v in P.items()}
-    eng = engine.ViltDatEngine(P, ["art"], DEV, batch=B, res=384, layers=12)
+    eng = engine.ViltDatEngine(P, ["art"], DEV, batch=B, res=384, layers=12, operands=fmt)
+    assert eng.op_dtype == {"f16": torch.float16, "bf16": torch.bfloat16}[fmt]
     eng.begin_local_update("art", steps_per_epoch=steps)
     client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=steps)
     torch.set_num_threads(min(torch.get_num_threads(), 32))
@@ -54,15 +62,15 @@ def b32_round(golden_dir):
     losses, snaps, osnaps = [], {}, {}
     for s in range(steps):
         b = O.synthetic_batch(B, 384, 8000 + s)
-        if s < ORACLE_STEPS:
+        if s < oracle_steps:
             client.train_step(b)
         losses.append(float(eng.train_step(_dev(b), use_graph=True)[0]))
         if s + 1 in SNAPS:
             sd = eng.state_dict()
             snaps[s + 1] = {k: (sd[k].cpu() - P0[k]) for k in keys}
-            if s + 1 <= ORACLE_STEPS:
+            if s + 1 <= oracle_steps:
                 osnaps[s + 1] = {k: (P[k] - P0[k]).clone() for k in keys}
-    return dict(g=g, keys=keys, losses=np.array(losses), snaps=snaps, osnaps=osnaps)
+    return dict(g=g, keys=keys, losses=np.array(losses), snaps=snaps, osnaps=osnaps, fmt=fmt)
 
 
 def _vs_golden(r, n):
@@ -103,6 +111,11 @@ def _table(rows):
 # of the backbone, not a kernel).  Their bound is therefore stated against 2 sum(lr) and is not the north-star's.
 BOUNDS = {20: dict(adapters=1.0e-3, head=1.7e-3), 40: dict(adapters=1.0e-3, head=3.5e-3),
           60: dict(adapters=1.2e-3, head=3.8e-3), 80: dict(adapters=1.7e-3, head=4.0e-3)}
+# fp16 operands (r05, same fixture, same replay): the north-star bound on EVERY trainable tensor at every round length
+#     adapters               2.1e-5      8.4e-5      6.4e-4      8.1e-4     mean ratio 0.002 / 0.002 / 0.009 / 0.009, norm <= 0.5 %
+#     head                   3.7e-5      5.3e-5      1.1e-4      1.8e-4     (the bf16 weights' systematic walk of clf_norm0.bias is gone)
+NORTH_STAR = 1.0e-3
+BOUNDS_F16 = {n: dict(adapters=b, head=min(b, 5e-4)) for n, b in ((20, 2e-4), (40, 4e-4), (60, NORTH_STAR), (80, NORTH_STAR))}
 MOVED = {20: (3e-4, 7e-4), 40: (1.4e-3, 3e-3), 60: (3e-3, 6e-3), 80: (3.5e-3, 9e-3)}      # the reference's own max |dW| per group
 
 
@@ -114,12 +127,17 @@ def test_b32_round_vs_reference_golden(b32_round, n):
     tensor's samples off by more than 1e-3; and the fixture really moves the weights by what the table says."""
     rows = _vs_golden(b32_round, n)
     t = _table(rows)
-    print(f"B=32, {n:2d} steps vs the reference | adapters: max |ddW| {t['adapters']['max']:.2e}, mean ratio "
+    f16 = b32_round["fmt"] == "f16"
+    bounds = (BOUNDS_F16 if f16 else BOUNDS)[n]
+    print(f"B=32, {b32_round['fmt']}, {n:2d} steps vs the reference | adapters: max |ddW| {t['adapters']['max']:.2e}, mean ratio "
           f"{t['adapters']['ratio']:.4f}, norm {t['adapters']['norm']:.5f}, moved {t['adapters']['moved']:.2e} | head: max |ddW| "
           f"{t['head']['max']:.2e}, mean ratio {t['head']['ratio']:.4f}, norm {t['head']['norm']:.5f}, moved {t['head']['moved']:.2e}")
     assert t["adapters"]["moved"] > MOVED[n][0] and t["head"]["moved"] > MOVED[n][1]
     for k, r in rows.items():
-        assert r["max"] < BOUNDS[n][_group(k)], (n, k, r)
+        assert r["max"] < bounds[_group(k)], (n, k, r)
+        if f16:      # north_star: no sample of any trainable tensor off by 1e-3; bulk within 2 % (3 % at 80) and norm within 1 %
+            assert r["n_gt_1e3"] == 0 and r["ratio"] < (0.02 if n <= 60 else 0.03) and r["norm"] < 0.01, (n, k, r)
+            continue
         # bulk of the tensor: mean error / mean |dW_ref| and the update norm (measured worst adapter tensor 0.011 / 0.015 /
         # 0.030 / 0.063 and 0.4 / 0.4 / 0.8 / 2.9 % at 20 / 40 / 60 / 80 steps; head 0.007-0.009 and < 0.1 % throughout)
         assert r["ratio"] < (0.05 if n <= 60 else 0.09), (n, k, r)
@@ -131,11 +149,23 @@ def test_b32_round_vs_reference_golden(b32_round, n):
         assert rel[:10].max() < 3e-3 and rel.max() < 3e-2
 
 
+def test_north_star_bound_at_80_steps_every_format(b32_round, request):
+    """north_star verbatim: adapter-weight max-abs-diff < 1e-3 after one FL round (the longest round of configs[2], 80 steps,
+    at its own batch size).  Holds for the default fp16 operands; for bf16 operands it is a STRICT xfail (1.3e-3: that format's
+    gap, kept visible -- if it ever passes the marker trips)."""
+    if b32_round["fmt"] == "bf16":
+        request.applymarker(pytest.mark.xfail(strict=True, reason="bf16 operands: 1.3e-3 at 80 steps (frozen-weight rounding)"))
+    t = _table(_vs_golden(b32_round, 80))
+    assert t["adapters"]["max"] < NORTH_STAR, t
+
+
 def test_b32_round_vs_live_oracle(b32_round):
     """ALL elements, against the CPU oracle stepping the same batches (first ORACLE_STEPS steps of the round; 40 by default:
     ~3 CPU-minutes on the GPU box -- FEDDAT_B32_ORACLE_STEPS=80 runs the whole round); the oracle's own update at its last
     snapshot is pinned to the reference's samples first (< 1e-4: two fp32 implementations)."""
     r = b32_round
+    if r["fmt"] != "f16":
+        pytest.skip("the live oracle steps next to the default operand format")
     assert r["osnaps"], "no oracle snapshot inside the prefix"
     g, bad = r["g"], []
     for n in sorted(r["osnaps"]):
@@ -148,7 +178,7 @@ def test_b32_round_vs_live_oracle(b32_round):
             ratio = float(err.mean()) / max(float(d_ref.abs().mean()), 1e-12)
             w = worst[_group(k)]
             w["max"], w["ratio"], pin_worst = max(w["max"], float(err.max())), max(w["ratio"], ratio), max(pin_worst, pin)
-            if pin >= 1e-4 or float(err.max()) >= 1.25 * BOUNDS[n][_group(k)] or ratio >= 0.05:
+            if pin >= 1e-4 or float(err.max()) >= NORTH_STAR or ratio >= 0.03:
                 bad.append((n, k, "oracle vs reference", pin, "max over all elements", float(err.max()), "ratio", ratio))
         print(f"B=32, {n:2d} steps vs the live oracle, ALL elements | adapters: max |ddW| {worst['adapters']['max']:.2e}, mean "
               f"ratio {worst['adapters']['ratio']:.4f} | head: max |ddW| {worst['head']['max']:.2e}, mean ratio "
@@ -168,7 +198,7 @@ def test_b32_round_80_steps_with_bf16_u_instead_of_gelu_codes(golden_dir):
     d = O.ViltDims(layers=12)
     P = O.make_params(d, ["art"], bias_std=0.02)
     P0 = {k: v.clone() for k, v in P.items()}
-    eng = engine.ViltDatEngine(P, ["art"], DEV, batch=32, res=384, layers=12, gelu_codes=False)
+    eng = engine.ViltDatEngine(P, ["art"], DEV, batch=32, res=384, layers=12, gelu_codes=False, operands="bf16")
     assert not eng.g8u and eng.act[1]["u"].dtype == torch.bfloat16
     eng.begin_local_update("art", steps_per_epoch=80)
     for s in range(80):

@@ -77,8 +77,9 @@ def test_main_trains_from_a_pretrained_directory(vilt_dir, tmp_path):
             "--num_layers", "2", "--image_size", "224", "--synthetic_steps", "2", "--output_dir", str(tmp_path)]
     model = train.main(argv + ["--pretrained_model_name", vilt_dir])
     ref = weights.convert_vilt_state_dict(weights.read_checkpoint(vilt_dir), 2)
-    wq = ref["vilt_encoder.vilt.encoder.layer.1.attention.attention.query.weight"].to(DEV).to(torch.bfloat16)
-    assert torch.equal(model.engine.layers[1]["wqkv"][:768], wq)            # the engine's bf16 operand IS the file's tensor
+    wq = ref["vilt_encoder.vilt.encoder.layer.1.attention.attention.query.weight"].to(DEV).to(model.engine.op_dtype)
+    assert model.engine.op_dtype == torch.float16       # the default operand format (mixed_precision fp16, as the reference)
+    assert torch.equal(model.engine.layers[1]["wqkv"][:768], wq)            # the engine's 16-bit operand IS the file's tensor
     assert model.exchange_used in ("feddat_fedavg_allreduce", "none")
     rand = train.main(argv)                                                   # no flag: random weights of the architecture
     assert not torch.equal(rand.engine.layers[1]["wqkv"][:768], wq)

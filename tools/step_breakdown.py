@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--res", type=int, default=384)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--detail", action="store_true", help="split GEMMs by shape/epilogue")
+    ap.add_argument("--operands", default="f16", choices=["bf16", "f16"], help="16-bit operand format of the engine")
     ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="feddat_set_debug_flags value (ablations)")
     args = ap.parse_args()
     from feddat_amd import engine, lib as L, vilt_spec
@@ -99,7 +100,7 @@ def main():
     L.set_debug_flags(args.debug_flags)
     dev = torch.device("cuda", 0)
     params = vilt_spec.random_init(12, ["c0"], seed=0)
-    eng = engine.ViltDatEngine(params, ["c0"], dev, batch=args.batch, res=args.res, layers=12)
+    eng = engine.ViltDatEngine(params, ["c0"], dev, batch=args.batch, res=args.res, layers=12, operands=args.operands)
     batches = [vilt_spec.synthetic_batch(args.batch, args.res, 1234 + i, device=dev) for i in range(2)]
     eng.begin_local_update("c0", steps_per_epoch=100)
     agg, step_ms, empty_us = measure(eng, L, batches, args.steps, args.detail)
