@@ -133,8 +133,48 @@ def measure_gemms_in_step(L, eng, batches, steps=3):
     rows = [dict(M=M, N=N, K=K, epi=epi, count=n, us=round(ms / n * 1e3, 2),
                  tflops=round(2.0 * M * N * K * n / (ms * 1e-3) / 1e12, 1)) for (M, N, K, epi), (n, ms) in sorted(g.items())]
     other = {str(k): round(v[1], 4) for k, v in agg.items() if not (isinstance(k, tuple) and not k[5])}
+    other_n = {str(k): v[0] for k, v in agg.items() if not isinstance(k, tuple)}
     return tot_f / tot_t, tot_t, rows, alg, launches, dict(eager_step_ms=round(step_ms, 3),
-                                                           empty_bracket_us=round(empty_us, 2), other_ops_ms_per_step=other)
+                                                           empty_bracket_us=round(empty_us, 2), other_ops_ms_per_step=other,
+                                                           second=second_roofline(other, other_n, 2 * eng.R))
+
+
+def row_kernel_bytes(T, H=768, I=3072, r=48, heads=12, S=185):
+    """Algorithmic HBM bytes per launch of the step's HBM-bound row kernels at T rows (every operand and result once;
+    DESIGN.md section 4): name of the C-ABI wrapper -> bytes."""
+    nb = T // S
+    return {
+        "adapter_fwd_ln": T * H * (4 + 4 + 2) + T * 2 * r * 4,           # h3 in, h_in out (fp32), next LN out (16 bit), z saved
+        "adapter_bwd": T * H * (4 + 4 + 2) + T * 2 * r * 4 * 2 + T * r * 4 * 2,    # dy in, dx out (fp32 + 16 bit), z saved in, z / dz out
+        "adapter_wgrad_partial": T * H * 4 * 2 + T * r * 4 * 2,          # x, dy (fp32), z, dz
+        "layernorm_bwd_dx": T * H * (2 + 4 + 4 + 4 + 2),                 # dy (16 bit), x, dres in, out fp32 (+ 16-bit copy)
+        "layernorm_fwd": T * H * (4 + 2),
+        "attn_fwd": T * 3 * H * 2 + T * H * 2 + nb * heads * S * 4,      # qkv in, ctx out, lse
+        "attn_bwd": T * 3 * H * 2 * 2 + T * H * 2 * 2 + nb * heads * S * 4,   # qkv, ctx, dctx in, dqkv out
+    }
+
+
+PEAK_HBM = 8.0e12           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def second_roofline(other_ms, launches, T):
+    """`roofline.second`: the step's HBM-bound row kernel furthest below its roof (the one the next kernel work goes to), among
+    those that take >= 0.1 ms of the step, from the same in-step event brackets as the GEMM figure."""
+    by = row_kernel_bytes(T)
+    rows = []
+    for name, nbytes in by.items():
+        if name in other_ms and launches.get(name, 0) > 0 and other_ms[name] >= 0.1:
+            us = other_ms[name] / launches[name] * 1e3
+            rows.append(dict(kernel=name, bound="hbm", launches_per_step=launches[name], us=round(us, 2),
+                             algorithmic_bytes_per_launch=nbytes, achieved=round(nbytes / (us * 1e-6) / 1e9, 1),
+                             peak=PEAK_HBM / 1e9, unit="GB/s", frac=round(nbytes / (us * 1e-6) / PEAK_HBM, 4),
+                             ms_per_step=round(other_ms[name], 4)))
+    if not rows:
+        return None
+    rows.sort(key=lambda r: r["frac"])
+    worst = dict(rows[0])
+    worst["all_row_kernels"] = [{k: r[k] for k in ("kernel", "us", "frac", "ms_per_step")} for r in rows]
+    return worst
 
 
 def profiled_traffic(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel"), pattern="r[0-9][0-9]_pmc_per_kernel.csv"):
@@ -176,7 +216,16 @@ def profiled_kernel_time(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel
             steps = int(r["calls"])
     if not steps or not ms:
         return None
-    return {"ms_per_step": round(ms / steps, 3), "steps": steps, "source": os.path.basename(files[-1])}
+    out = {"ms_per_step": round(ms / steps, 3), "steps": steps, "source": os.path.basename(files[-1]),
+           "provenance": "HISTORICAL: the committed rocprofv3 summary of an earlier run of this command (commit / device below "
+                         "when recorded), not this run -- a cross-check of the live figure, stale after a kernel change"}
+    meta = files[-1].replace("_kernel_stats.csv", "_meta.json")
+    if os.path.exists(meta):
+        try:
+            out.update({k: v for k, v in json.load(open(meta)).items() if k in ("commit", "device", "operands", "date")})
+        except Exception:       # noqa: BLE001 -- provenance only
+            pass
+    return out
 
 
 def cpu_baseline(params_cpu, batches_cpu, B, res, task, timed_steps=3):
@@ -239,11 +288,18 @@ def make_exchange(eng, world, rank, dist):
         if float(ok) > 0:
             v = info["rccl_version"]
             desc = {"library": "RCCL %d.%d.%d (C ABI: feddat_fedavg_allreduce)" % (v // 10000, v // 100 % 100, v % 100),
-                    "ranks_in_communicator": info["ranks"], "payload_bytes": nbytes, "per_round": 1}
+                    "rccl_version": v, "path": "feddat_comm_create_timeout -> ncclCommInitRank -> feddat_fedavg_allreduce",
+                    "ranks_requested": world, "ranks_in_communicator": info["ranks"], "payload_bytes": nbytes, "per_round": 1}
+            if info["ranks"] != world:      # a communicator that does not span --gpus ranks measures something else: fail loudly
+                raise SystemExit(f"bench.py: feddat_comm_info reports {info['ranks']} ranks in the communicator, --gpus {world} "
+                                 f"were asked for (rank {rank}); refusing to print a throughput line")
             return (lambda: allreduce_average(eng, world, comm=comm)), desc
         why = "C-ABI communicator unavailable on some rank" + (f" ({err[:200]})" if err else "")
-    desc = {"library": "torch.distributed " + dist.get_backend() + f" ({why})",
-            "ranks_in_communicator": dist.get_world_size(), "payload_bytes": nbytes, "per_round": 1}
+    desc = {"library": "torch.distributed " + dist.get_backend() + f" ({why})", "path": "torch.distributed.all_reduce",
+            "ranks_requested": world, "ranks_in_communicator": dist.get_world_size(), "payload_bytes": nbytes, "per_round": 1,
+            "fallback_reason": why}
+    if dist.get_world_size() != world:
+        raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {world} were asked for")
     return (lambda: allreduce_average(eng, world)), desc
 
 
@@ -295,7 +351,7 @@ def gather_ranks(tr, B, world, rank, dist, dev):
     return max(float(t[0]) for t in allr), int(sum(float(t[4]) for t in allr)), rows
 
 
-def round_split(rows, dt):
+def round_split(rows, dt, payload_bytes=None):
     """+ `hetero_bound`: with K = N heterogeneous clients every rank waits at the all-reduce for the one with the most steps,
     so N ranks can deliver at most sum(steps) / max(steps) ranks' worth of work per round (SURVEY 8d config 3's
     len(loader) in {40..80} on 8 ranks: 5.625 of 8 = 0.70; homogeneous: N) -- `scaling_x_bound` is what a reading of the
@@ -305,9 +361,18 @@ def round_split(rows, dt):
     steps = [r["steps"] for r in rows]
     bound = sum(steps) / max(steps)
     busy = sum(r["compute_s"] for r in rows)
+    ar = max(r["allreduce_ms"] for r in rows)
+    n = len(rows)
+    bus = None
+    if payload_bytes and ar > 0:      # ring all-reduce moves 2 (N - 1) / N of the payload over every rank's links
+        bus = {"algbw_GBps": round(payload_bytes / (ar * 1e-3) / 1e9, 3),
+               "busbw_GBps": round(2.0 * (n - 1) / n * payload_bytes / (ar * 1e-3) / 1e9, 3),
+               "note": "one 3.58 MB (ViLT) / 8.95 MB (ALBEF) all-reduce per round: latency-bound, far below the ~153 GB/s of an xGMI link"}
     return {"round_s": round(dt, 4), "compute_s_max": max(r["compute_s"] for r in rows),
             "compute_s_min": min(r["compute_s"] for r in rows), "wait_s_mean": round(sum(r["wait_s"] for r in rows) / len(rows), 4),
-            "allreduce_ms_max": max(r["allreduce_ms"] for r in rows),
+            "allreduce_ms_max": ar, "allreduce_bandwidth": bus,
+            "share_of_round": {"compute": round(max(r["compute_s"] for r in rows) / dt, 4) if dt > 0 else None,
+                               "allreduce": round(ar * 1e-3 / dt, 5) if dt > 0 else None},
             "hetero_bound": {"scaling_x_bound": round(bound, 3), "round_efficiency_bound": round(bound / len(rows), 3),
                              "efficiency_vs_bound": round(busy / (dt * bound), 3) if dt > 0 else None}}
 
@@ -416,7 +481,7 @@ def bench_albef(args, world, rank, dev, dist):
             "samples_per_sec_per_gpu": round(sps / world, 2),
             "mfma_frac_vit_flops_only": round(flops * B * total_steps / world / dt / PEAK_BF16, 4)}
         if rows is not None:
-            out["per_rank"], out["round_split"] = rows, round_split(rows, dt)
+            out["per_rank"], out["round_split"] = rows, round_split(rows, dt, coll and coll.get("payload_bytes"))
         if not args.no_roofline:
             try:
                 out["roofline"] = albef_roofline(L, eng, batches)
@@ -443,7 +508,8 @@ def roofline_block(L, eng, batches, gemms):
     kt = profiled_kernel_time()
     if kt:       # the same FLOPs over the kernel-trace durations of the committed profile (another run, maybe another box)
         kt["frac"] = round(ach * tsum / (kt["ms_per_step"] * 1e-3) / PEAK_BF16, 4)
-    return {"kernel_trace": kt,
+    second = in_step_info.pop("second", None)
+    return {"kernel_trace": kt, "second": second,
             "kernel": "gemm_nt_v3_kernel / gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one train_step, "
                       "FLOP-weighted, durations measured in-step)",
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
@@ -459,8 +525,8 @@ def roofline_block(L, eng, batches, gemms):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)     # 50 warm + 200 timed
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--res", type=int, default=384)
     ap.add_argument("--workload", default="vilt", choices=["vilt", "albef"],
@@ -475,7 +541,8 @@ def main():
                          "north-star parity bar at round length) or bf16 -- same MFMA instruction rate, same bytes")
     ap.add_argument("--hetero", action="store_true",
                     help="N > 1, SURVEY.md 8d config 3: rank r runs K * {40,50,60,70,80}[r % 5] / 80 steps (heterogeneous "
-                         "len(loader)); the imbalance is absorbed at the round's barrier and shows up as wait_s")
+                         "len(loader)) on answers drawn from its own Dirichlet(0.5) label prior; the imbalance is absorbed at the "
+                         "round's barrier and shows up as wait_s")
     ap.add_argument("--albef-dropout", dest="albef_dropout", type=float, default=0.0,
                     help="--workload albef: BERT hidden / attention dropout inside train_step (reference recipe: 0.1; the "
                          "default 0 is the deterministic configuration SURVEY.md 8d quotes config 4 in)")
@@ -531,7 +598,9 @@ def main():
                                operands="bf16" if args.fp8 else args.operands)
     eng.fused_tail = not args.unfused_tail
     nb = 4
-    batches = [vilt_spec.synthetic_batch(B, res, 1234 + 100 * rank + i, device=dev) for i in range(nb)]
+    # --hetero: client r also draws its answers from its own Dirichlet(0.5) label prior
+    prior = vilt_spec.client_label_prior(rank) if args.hetero else None
+    batches = [vilt_spec.synthetic_batch(B, res, 1234 + 100 * rank + i, device=dev, label_prior=prior) for i in range(nb)]
     steps_per_epoch = max(args.steps + args.warmup, 40)
     eng.begin_local_update(task, steps_per_epoch=steps_per_epoch)
     use_graph = not args.no_graph
@@ -586,6 +655,7 @@ def main():
                                    + (f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else ""),
                        "batch_per_client": B, "seq_len": S, "clients": world, "hip_graph": use_graph,
                        "ranks": (dist.get_world_size() if dist is not None else 1), "hetero_steps": bool(args.hetero),
+                       "hetero_label_prior": "Dirichlet(alpha=0.5) per client" if args.hetero else None,
                        "collective": coll, "last_loss_0": round(loss, 4)},
             "samples_per_sec_per_gpu": round(sps / world, 2),
             "mfma_frac_executed_flops": round(exec_flops * total_steps / world / dt / PEAK_BF16, 4),
@@ -593,7 +663,7 @@ def main():
         }
         out.update(extra_host)
         if rank_rows is not None:      # configs[2]: per-GPU rate and the round's split (compute / wait at the barrier / all-reduce)
-            out["per_rank"], out["round_split"] = rank_rows, round_split(rank_rows, dt)
+            out["per_rank"], out["round_split"] = rank_rows, round_split(rank_rows, dt, coll and coll.get("payload_bytes"))
         if not args.no_roofline:
             try:
                 out["roofline"] = roofline_block(L, eng, batches, gemms)

@@ -90,12 +90,17 @@ class ALBEFContinualLearner:
         return enc["input_ids"][:, :longest].contiguous(), enc["attention_mask"][:, :longest].contiguous(), enc["lengths"]
 
     def process_inputs(self, batch: Dict) -> Dict:
-        """ALBEFWrapper.forward's tokenisation (albef.py:52-73) once per batch on the device: questions padded to the
-        longest and truncated at 25 tokens, answers padded to the longest; the eval path appends [SEP] to every entry of
-        the answer list (albef.py:63) and tokenises it the same way."""
+        """ALBEFWrapper.forward's tokenisation (albef.py:52-73) once per batch on the device: TRAIN questions padded to the
+        longest and truncated at 25 tokens (albef.py:56), answers padded to the longest; EVAL questions are tokenised WITHOUT
+        truncation (albef.py:62 passes no max_length) -- one longer than the engine's frame is an error, not a silent cut that
+        would change rank_answer's result; the eval path appends [SEP] to every entry of the answer list (albef.py:63) and
+        tokenises it the same way."""
         eng = self.engine
         out = {"image": batch["images"].to(self.device, torch.float32, non_blocking=True), "train": batch.get("train", True)}
-        qi, qm, _ = self._tok(list(batch["questions"]), min(25, eng.Lq), True, "question")
+        if out["train"]:
+            qi, qm, _ = self._tok(list(batch["questions"]), min(25, eng.Lq), True, "question")
+        else:
+            qi, qm, _ = self._tok(list(batch["questions"]), eng.Lq, False, "eval question (the reference does not truncate it)")
         out["question_ids"], out["question_mask"] = qi, qm
         if out["train"]:
             ai, am, _ = self._tok(list(batch["answers"]), eng.La, False, "answer")

@@ -28,6 +28,7 @@ struct Rccl {
     GetUniqueIdFn get_id = nullptr;
     CommInitRankFn init_rank = nullptr;
     CommDestroyFn destroy = nullptr;
+    CommDestroyFn abort = nullptr;           // optional: ncclCommAbort (releases a communicator without waiting for its peers)
     AllReduceFn all_reduce = nullptr;
     GetVersionFn get_version = nullptr;      // optional (diagnostics only)
     CommQueryFn comm_count = nullptr, comm_user_rank = nullptr;
@@ -55,6 +56,7 @@ const Rccl& rccl() {
         g_rccl.get_id = (GetUniqueIdFn)dlsym(g_rccl.h, "ncclGetUniqueId");
         g_rccl.init_rank = (CommInitRankFn)dlsym(g_rccl.h, "ncclCommInitRank");
         g_rccl.destroy = (CommDestroyFn)dlsym(g_rccl.h, "ncclCommDestroy");
+        g_rccl.abort = (CommDestroyFn)dlsym(g_rccl.h, "ncclCommAbort");
         g_rccl.all_reduce = (AllReduceFn)dlsym(g_rccl.h, "ncclAllReduce");
         g_rccl.get_version = (GetVersionFn)dlsym(g_rccl.h, "ncclGetVersion");
         g_rccl.comm_count = (CommQueryFn)dlsym(g_rccl.h, "ncclCommCount");
@@ -94,22 +96,34 @@ extern "C" int feddat_comm_create_timeout(const void* id_128_bytes, int world, i
         std::mutex mu;
         std::condition_variable cv;
         bool done = false;
+        bool abandoned = false;      // the caller gave up (timeout): a communicator that still appears belongs to nobody
         int rc = -1;
         void* comm = nullptr;
     };
     auto job = std::make_shared<Job>();
     const CommInitRankFn init = r.init_rank;
-    std::thread([job, init, id, world, rank, dev] {
+    const CommDestroyFn drop = r.abort ? r.abort : r.destroy;      // ncclCommAbort does not wait for the peers
+    std::thread([job, init, drop, id, world, rank, dev] {
         void* c = nullptr;
         int rc = hipSetDevice(dev) == hipSuccess ? init(&c, world, id, rank) : -1;
-        std::lock_guard<std::mutex> lk(job->mu);
-        job->rc = rc;
-        job->comm = c;
-        job->done = true;
-        job->cv.notify_all();
+        bool orphan;
+        {
+            std::lock_guard<std::mutex> lk(job->mu);
+            job->rc = rc;
+            job->comm = c;
+            job->done = true;
+            orphan = job->abandoned;
+            job->cv.notify_all();
+        }
+        // the bootstrap completed after the caller had timed out and moved on to the fallback exchange: nobody will ever
+        // use (or destroy) this communicator -- release it here instead of leaking it next to the fallback's collectives
+        if (orphan && rc == 0 && c) drop(c);
     }).detach();
     std::unique_lock<std::mutex> lk(job->mu);
-    if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) return FEDDAT_ETIMEOUT;
+    if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) {
+        job->abandoned = true;
+        return FEDDAT_ETIMEOUT;
+    }
     if (job->rc != 0) return FEDDAT_ELAUNCH;
     *comm_out = job->comm;
     return FEDDAT_OK;

@@ -64,6 +64,12 @@ def make_rccl_comm(world: int, rank: int):
     """RCCL communicator through the C ABI (feddat_comm_*); the unique id travels over the already-initialised
     torch.distributed group (any backend) as a host object."""
     import torch.distributed as dist
+    # every rank says whether it can bind RCCL BEFORE anyone enters the collective ncclCommInitRank: a rank without a loadable
+    # librccl makes all ranks fail fast here, together, instead of its peers waiting out the bootstrap watchdog
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(L.rccl_available()))
+    if not all(flags):
+        raise L.FeddatHipError(f"RCCL is not loadable on rank(s) {[r for r, f in enumerate(flags) if not f]}")
 
     def exchange(ident: bytes) -> bytes:
         box = [ident]

@@ -277,6 +277,12 @@ class Context:
             pass
 
 
+def rccl_available() -> bool:
+    """True when the library could bind RCCL in this process (feddat_comm_info without a communicator: version only)."""
+    v = C.c_int(0)
+    return load().feddat_comm_info(None, C.byref(v), None, None) == 0 and v.value > 0
+
+
 class RcclComm:
     """ncclComm_t made through the C ABI (feddat_comm_*): rank 0 draws the unique id, `exchange(id_bytes) -> id_bytes`
     ships it to the other ranks over any host channel (torch.distributed object broadcast, a TCPStore, MPI, a file)."""

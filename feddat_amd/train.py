@@ -292,6 +292,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--synthetic_steps", type=str, default="8",
                    help="batches per client per round: one integer, or a comma list dealt to the clients in order "
                         "(heterogeneous len(loader), e.g. 40,50,60,70,80,45,55,65 for 8 clients)")
+    p.add_argument("--synthetic_label_alpha", type=float, default=0.0,
+                   help="> 0: client k of the synthetic ViLT data draws its answers from its own Dirichlet(alpha) label prior "
+                        "(SURVEY.md 8d config 3 uses 0.5: heterogeneous clients); 0 = uniform labels")
     p.add_argument("--image_size", type=int, default=384)
     p.add_argument("--num_layers", type=int, default=12)
     p.add_argument("--albef_dropout", type=float, default=0.1,
@@ -390,12 +393,13 @@ def main(argv=None):
     def personal(sd):
         return {n: v.clone() for n, v in sd.items() if ("task" in n or "adapter_0" in n or "adapter_2" in n)}
     personal_params = {t: personal(model.state_dict()) for t in my_tasks}
-    def make_batch(seed):
+    def make_batch(seed, ti=0):
         if albef:
             return albef_spec.synthetic_batch(args.batch_size, seed, image=args.image_size, vocab=dims.get("vocab", 30522),
                                               device=dev)
-        return vilt_spec.synthetic_batch(args.batch_size, args.image_size, seed, device=dev)
-    data = {t: [make_batch(args.seed + 1000 * ti + s) for s in range(steps_of[t])] for ti, t in enumerate(tasks)
+        prior = vilt_spec.client_label_prior(ti, alpha=args.synthetic_label_alpha) if args.synthetic_label_alpha > 0 else None
+        return vilt_spec.synthetic_batch(args.batch_size, args.image_size, seed, device=dev, label_prior=prior)
+    data = {t: [make_batch(args.seed + 1000 * ti + s, ti) for s in range(steps_of[t])] for ti, t in enumerate(tasks)
             if t in my_tasks}
     server_flat = eng.comm_flat().clone()
     acc = torch.zeros_like(server_flat)

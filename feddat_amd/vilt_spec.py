@@ -79,9 +79,22 @@ def random_init(layers: int = 12, tasks: Sequence[str] = ("art",), seed: int = 0
     return out
 
 
-def synthetic_batch(B: int, res: int, seed: int, device="cpu", text_len: int = 40, num_labels: int = 100):
+def client_label_prior(client: int, num_labels: int = 100, alpha: float = 0.5, seed: int = 1234) -> torch.Tensor:
+    """Heterogeneous clients: client k draws its answers from its own Dirichlet(alpha = 0.5) prior over
+    the labels -- a few answers dominate each client, differently per client, so the clients' gradients disagree the way
+    non-IID VQA domains do (the reference's clients are different datasets: vqa_utils.py:21-31,62-67 build the targets)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + 7919 * int(client))
+    p = torch._standard_gamma(torch.full((num_labels,), float(alpha)), generator=g)
+    p = p.clamp_min(1e-12)
+    return p / p.sum()
+
+
+def synthetic_batch(B: int, res: int, seed: int, device="cpu", text_len: int = 40, num_labels: int = 100,
+                    label_prior: torch.Tensor = None):
     """Synthetic VQA batch in the reference's schema (HF ViLT encodings + target_scores):
-    N(0,1) pixels, [CLS] 38 random ids [SEP], 1-3 labels per row with scores in {0.3, 0.6, 0.9, 1.0}."""
+    N(0,1) pixels, [CLS] 38 random ids [SEP], 1-3 labels per row with scores in {0.3, 0.6, 0.9, 1.0}; labels uniform, or
+    drawn without replacement from `label_prior` (client_label_prior: the heterogeneous clients of config 3)."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     px = torch.randn(B, 3, res, res, generator=g)
@@ -91,7 +104,10 @@ def synthetic_batch(B: int, res: int, seed: int, device="cpu", text_len: int = 4
     scores = torch.tensor([0.3, 0.6, 0.9, 1.0])
     for b in range(B):
         n = int(torch.randint(1, 4, (1,), generator=g))
-        labs = torch.randperm(num_labels, generator=g)[:n]
+        if label_prior is None:
+            labs = torch.randperm(num_labels, generator=g)[:n]
+        else:
+            labs = torch.multinomial(label_prior, n, replacement=False, generator=g)
         target[b, labs] = scores[torch.randint(0, 4, (n,), generator=g)]
     batch = {"pixel_values": px, "pixel_mask": torch.ones(B, res, res, dtype=torch.long), "input_ids": ids,
              "attention_mask": torch.ones(B, text_len, dtype=torch.long),

@@ -41,7 +41,16 @@ def _read_tensor_file(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return dict(load_file(path))
-    obj = torch.load(path, map_location="cpu", weights_only=True)
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:      # noqa: BLE001 -- the restricted unpickler's error is opaque; say what to do
+        # the reference calls plain torch.load (albef.py:208): checkpoints that carry non-tensor objects (config, optimizer or
+        # scheduler state) are refused by the tensors-only unpickler used here
+        raise FeddatHipError(
+            f"{path}: torch.load(weights_only=True) refused the file ({type(e).__name__}: {str(e)[:200]}).  Only tensor state "
+            "dicts are read (no arbitrary unpickling of a downloaded file); re-save the checkpoint as tensors only, e.g. "
+            "torch.save({'model': torch.load(p, weights_only=False)['model']}, out) in an environment you trust, or convert "
+            "it to .safetensors") from e
     if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):      # ALBEF.pth
         obj = obj["model"]
     if isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
@@ -245,6 +254,9 @@ def load_albef_pretrained(path: str, seed: int = 0, image: int = 384, **dims) ->
     sd = convert_albef_state_dict(read_checkpoint(path), image=image, **dims)
     shapes = albef_spec.param_shapes(image=image, **dims)
     sd.update(init_trainable({k: v for k, v in shapes.items() if k not in sd}, seed))
+    lack = [k for k in shapes if k not in sd]             # every expected key has a source (as in load_vilt_pretrained)
+    if lack:
+        raise FeddatHipError(f"no source for {lack[:4]}")
     return sd
 
 

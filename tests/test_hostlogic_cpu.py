@@ -61,3 +61,45 @@ def test_bench_reads_the_committed_profile_summaries():
     assert bench.profiled_traffic(pattern="r[0-9][0-9]_nothing.csv") is None
     assert bench.profiled_kernel_time(pattern="r[0-9][0-9]_nothing.csv") is None
     assert bench.profiled_kernel_time(step_marker="no_such_kernel") is None
+
+
+def test_bench_round_split_reports_allreduce_bandwidth_and_shares():
+    import bench
+    rows = [dict(rank=r, steps=20, samples_per_sec=4000.0, compute_s=0.14, wait_s=0.001, allreduce_ms=0.5) for r in range(8)]
+    rs = bench.round_split(rows, 0.15, payload_bytes=894528 * 4)
+    bw = rs["allreduce_bandwidth"]
+    assert abs(bw["algbw_GBps"] - 894528 * 4 / 0.5e-3 / 1e9) < 1e-2
+    assert abs(bw["busbw_GBps"] - bw["algbw_GBps"] * 2 * 7 / 8) < 1e-2
+    assert 0.9 < rs["share_of_round"]["compute"] < 1.0 and rs["share_of_round"]["allreduce"] < 0.01
+    assert bench.round_split(rows, 0.15)["allreduce_bandwidth"] is None
+
+
+def test_bench_second_roofline_names_the_worst_row_kernel():
+    """roofline.second: among the HBM-bound row kernels that take >= 0.1 ms of the step, the one furthest below 8 TB/s."""
+    import bench
+    T = 11840
+    by = bench.row_kernel_bytes(T)
+    assert abs(by["layernorm_bwd_dx"] - 145.5e6) < 1e6 and abs(by["adapter_fwd_ln"] - 95.5e6) < 1e6
+    other = {"adapter_fwd_ln": 0.344, "layernorm_bwd_dx": 0.510, "layernorm_fwd": 0.05, "attn_fwd": 0.231}
+    n = {"adapter_fwd_ln": 11, "layernorm_bwd_dx": 23, "layernorm_fwd": 13, "attn_fwd": 11}
+    s = bench.second_roofline(other, n, T)
+    assert s["kernel"] == "adapter_fwd_ln" and s["bound"] == "hbm" and 0.3 < s["frac"] < 0.45
+    assert [r["kernel"] for r in s["all_row_kernels"]] == ["adapter_fwd_ln", "attn_fwd", "layernorm_bwd_dx"]     # >= 0.1 ms only
+    assert bench.second_roofline({}, {}, T) is None
+
+
+def test_client_label_priors_are_heterogeneous_and_reproducible():
+    """Dirichlet(0.5) label prior per client; the product's generator draws what the checker's draws."""
+    import torch
+    from feddat_amd import vilt_spec
+    from oracle import feddat_oracle as O
+    p0, p1 = vilt_spec.client_label_prior(0), vilt_spec.client_label_prior(1)
+    assert torch.equal(p0, vilt_spec.client_label_prior(0)) and not torch.equal(p0, p1)
+    assert abs(float(p0.sum()) - 1) < 1e-6 and float(p0.max()) > 0.03 and int((p0 < 1e-3).sum()) > 10      # a few answers dominate
+    a, b = vilt_spec.synthetic_batch(8, 32, 77, label_prior=p0), O.synthetic_batch(8, 32, 77, label_prior=p0)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    # the clients' answer distributions differ: label mass of 64 batches of each client
+    m = [sum((vilt_spec.synthetic_batch(8, 32, 100 + s, label_prior=p)["target_scores"] > 0).float().sum(0) for s in range(64))
+         for p in (p0, p1)]
+    cos = float((m[0] * m[1]).sum() / (m[0].norm() * m[1].norm()))
+    assert cos < 0.6
