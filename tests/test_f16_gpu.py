@@ -253,9 +253,12 @@ def test_the_loss_scale_leaves_exactly():
         got = _run(engine, "bf16", sc)
         for k in base:
             assert torch.equal(base[k], got[k]), (sc, k)
+    # (AdamW turns an element whose gradient is ~0 into +-lr steps, so a last-bit difference of such a gradient is worth up to
+    #  2 x sum(lr) = 1.3e-4 over these three warm-up steps on that element; the bulk agrees to 1e-7)
     a, b = _run(engine, "f16", 1024.0), _run(engine, "f16", 16384.0)
     for k in a:
-        assert (a[k] - b[k]).abs().max() < 5e-5, k
+        d = (a[k] - b[k]).abs()
+        assert float(d.max()) < 1.5e-4 and float(d.mean()) < 2e-7, (k, float(d.max()), float(d.mean()))
     with pytest.raises(lib.FeddatHipError):
         engine.ViltDatEngine(O.make_params(O.ViltDims(layers=1), ["art"]), ["art"], DEV, batch=1, res=224, layers=1,
                              loss_scale=1000.0)
