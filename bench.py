@@ -445,6 +445,38 @@ def albef_cpu_baseline(B_cpu=4, timed_steps=2):
                        f"{torch.__version__} CPU, {nt} threads")
 
 
+def albef_flops(Ni, Lq, La, n_ans=1, H=768, I=3072, r=48, V=30522, vit=12, enc=12, fusion=6, dec=6):
+    """Algorithmic FLOPs per sample of ALBEF's dual-adapter + MKD train_step, counted the way SURVEY.md 8d counts ViLT's:
+    linears 2 M N K, attention 4 Sq Skv 64 per head forward, backward = dX only through the frozen linears (the same FLOPs as
+    their forward), attention backward = 2 x its forward, an active adapter forward 2 x 2 H r per token and dX + dW = 2 x that;
+    nothing below the first ViT adapter is back-propagated.
+    -> (reference: P0 gated no-grad + P1 + P2 gated = 3 forwards + 2 backwards (task_trainer.py:280-330 around
+        albef_model.py:69-145), executed: the engine runs the gated forward once (P0 == P2 here: only adapters train, dropout 0)
+        = 2 forwards + 2 backwards, and the image encoder ahead of block 0's adapter once)."""
+    lin = lambda M, N, K: 2.0 * M * N * K  # noqa: E731
+    att = lambda Sq, Skv: 4.0 * Sq * Skv * H  # noqa: E731
+    blk = lambda S: lin(S, 3 * H, H) + lin(S, H, H) + lin(S, I, H) + lin(S, H, I)  # noqa: E731
+    ad = lambda S: 2.0 * S * H * r * 2  # noqa: E731
+    vit_blk_lin, vit_blk_att = blk(Ni), att(Ni, Ni)
+    patch = lin(Ni - 1, H, H)
+    enc_self = enc * (blk(Lq) + att(Lq, Lq))
+    enc_cross = (enc - fusion) * (lin(Lq, H, H) * 2 + lin(Ni, 2 * H, H) + att(Lq, Ni))
+    dec_self = dec * (blk(La) + att(La, La)) * n_ans
+    dec_cross = dec * (lin(La, H, H) * 2 * n_ans + lin(Lq, 2 * H, H) + att(La, Lq) * n_ans)
+    head = n_ans * (La - 1) * (2.0 * H * H + 2.0 * H * V)
+    lin_all = patch + vit * vit_blk_lin + enc_self - enc * att(Lq, Lq) + enc_cross - (enc - fusion) * att(Lq, Ni) + \
+        dec_self - dec * att(La, La) * n_ans + dec_cross - dec * att(La, Lq) * n_ans + head
+    att_all = vit * vit_blk_att + enc * att(Lq, Lq) + (enc - fusion) * att(Lq, Ni) + dec * n_ans * (att(La, La) + att(La, Lq))
+    ad_tok = vit * Ni + enc * Lq + dec * La * n_ans           # adapter applications per sample (30 modules)
+    fwd = lambda k: lin_all + att_all + k * ad(1) * ad_tok  # noqa: E731
+    # backward: everything above block 0's adapter; block 0's own attention / MLP and the patch embedding are not differentiated
+    below = patch + vit_blk_lin + vit_blk_att
+    bwd = lambda k: (lin_all - patch - vit_blk_lin) + 2.0 * (att_all - vit_blk_att) + 2.0 * k * ad(1) * ad_tok  # noqa: E731
+    reference = fwd(2) + fwd(1) + bwd(1) + fwd(2) + bwd(2)
+    executed = fwd(2) + fwd(1) - below + bwd(1) + bwd(2)
+    return reference, executed
+
+
 def bench_albef(args, world, rank, dev, dist):
     """configs[3]: one ALBEF dual-adapter + MKD train_step per step (one hipGraph replay); with N clients the timed region ends with the FedAvg all-reduce of the 8.95 MB adapter_1 payload."""
     from feddat_amd import albef_engine, albef_spec, lib as L
@@ -480,6 +512,12 @@ def bench_albef(args, world, rank, dev, dist):
                        "last_loss_0": round(loss, 4)},
             "samples_per_sec_per_gpu": round(sps / world, 2),
             "mfma_frac_vit_flops_only": round(flops * B * total_steps / world / dt / PEAK_BF16, 4)}
+        ref_f, exe_f = albef_flops(eng.Ni, eng.Lq, eng.La)
+        out["flops_per_sample"] = {"reference_step": ref_f, "executed": exe_f,
+                                   "note": "albef_flops(): counted as SURVEY.md 8d counts ViLT's step (3 fwd + 2 bwd of the reference; "
+                                           "the engine runs 2 + 2: P0 == P2 with dropout 0)"}
+        out["mfma_frac_reference_flops"] = round(sps / world * ref_f / PEAK_BF16, 4)      # speed-equivalent at the reference's count
+        out["mfma_frac_executed_flops"] = round(sps / world * exe_f / PEAK_BF16, 4)
         if rows is not None:
             out["per_rank"], out["round_split"] = rows, round_split(rows, dt, coll and coll.get("payload_bytes"))
         if not args.no_roofline:

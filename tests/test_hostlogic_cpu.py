@@ -103,3 +103,14 @@ def test_client_label_priors_are_heterogeneous_and_reproducible():
          for p in (p0, p1)]
     cos = float((m[0] * m[1]).sum() / (m[0].norm() * m[1].norm()))
     assert cos < 0.6
+
+
+def test_bench_albef_flop_count():
+    """configs[3]'s whole-step MFMA fractions rest on albef_flops(): the ViT's 12 blocks of 577 tokens dominate (~70 % of
+    the FLOPs), the reference runs 3 forwards + 2 backwards, the engine 2 + 2 minus the shared prefix below the first adapter."""
+    import bench
+    ref, exe = bench.albef_flops(577, 25, 4)
+    vit_fwd = 12 * (2.0 * 577 * 768 * 9216 + 4.0 * 577 * 577 * 768)
+    assert 0.80 < 5 * vit_fwd / ref < 0.95             # 3 fwd + ~2 bwd of the ViT against everything
+    assert 0.75 < exe / ref < 0.82
+    assert 6.0e11 < ref < 6.8e11
