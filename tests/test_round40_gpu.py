@@ -89,6 +89,44 @@ def test_fp8_round_40_steps_vs_reference_golden(engine, golden_dir):
     assert worst["max"] < 6e-3 and worst["ratio"] < 0.25 and worst["norm"] < 0.06
 
 
+@pytest.mark.parametrize("fp8", [True, False])
+def test_b64_round_40_steps_vs_reference_golden(engine, golden_dir, fp8):
+    """configs[4] at its OWN batch size over a round: B = 64 / client, 40 train_steps (len(loader) = 40), hipGraph replay, against
+    the REFERENCE's own run of that round (tests/golden/g8b_round40_b64.npz: oracle/make_golden.py --only-g8 --steps 40 --batch 64,
+    updates stored after 20 and 40 steps).  fp8 = the six-product e4m3 configuration `bench.py --fp8` runs, asserted with the
+    tolerances its line quotes; fp8 = False = the default fp16-operand engine on the same fixture (north_star's bound)."""
+    from tests.test_round_b32_gpu import _table, _vs_golden
+    g = load(golden_dir, "g8b_round40_b64.npz")
+    steps, B = int(g["steps"]), int(g["batch"])
+    assert (steps, B) == (40, 64)
+    d = O.ViltDims(layers=12)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    P0 = {k: v.clone() for k, v in P.items()}
+    eng = engine.ViltDatEngine(P, ["art"], DEV, batch=B, res=384, layers=12, fp8=fp8)
+    assert eng.operands == ("bf16" if fp8 else "f16")
+    eng.begin_local_update("art", steps_per_epoch=steps)
+    keys = [k.split("::", 2)[2] for k in g if k.startswith("s40::dsamp::")]
+    losses, snaps = [], {}
+    for s in range(steps):
+        losses.append(float(eng.train_step(_dev(O.synthetic_batch(B, 384, 8000 + s)), use_graph=True)[0]))
+        if s + 1 in (20, 40):
+            sd = eng.state_dict()
+            snaps[s + 1] = {k: (sd[k].cpu() - P0[k]) for k in keys}
+    rel = np.abs(np.array(losses) - g["losses"]) / np.maximum(g["losses"], 1.0)
+    r = dict(g=g, keys=keys, snaps=snaps)
+    for n in (20, 40):
+        t = _table(_vs_golden(r, n))
+        print(f"B=64 {'fp8 (six products)' if fp8 else 'fp16 operands'}, {n} steps vs the reference | adapters: max |ddW| "
+              f"{t['adapters']['max']:.2e}, mean ratio {t['adapters']['ratio']:.4f}, norm {t['adapters']['norm']:.4f}, moved "
+              f"{t['adapters']['moved']:.2e} | head: max {t['head']['max']:.2e}, ratio {t['head']['ratio']:.4f} | loss rel {rel.max():.1e}")
+        for grp in ("adapters", "head"):
+            if fp8:      # the tolerances of configs[4] (bench.py --fp8 quotes them): an e4m3 run keeps size and direction of every update
+                assert t[grp]["max"] < 4e-3 and t[grp]["ratio"] < 0.2 and t[grp]["norm"] < 0.05, (n, grp, t[grp])
+            else:
+                assert t[grp]["max"] < 1e-3 and t[grp]["ratio"] < 0.02 and t[grp]["norm"] < 0.01, (n, grp, t[grp])
+    assert rel.max() < (2e-2 if fp8 else 3e-3)
+
+
 @pytest.fixture(scope="module")
 def round80(engine, golden_dir):
     """One 80-step round (configs[2]'s longest len(loader)) of the 12-layer model on the engine (hipGraph replay) and,
