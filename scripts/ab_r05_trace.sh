@@ -1,7 +1,7 @@
 # kernel-trace of the graph-replayed step in both operand formats on one box (which kernels carry the f16 - bf16 difference)
 R=$(pwd)
 for f in bf16 f16; do
-  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ab/$f -o step --output-format csv -- python $R/bench.py --operands $f --steps 40 --warmup 10 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_ab/$f.log 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ab/$f -o step --output-format csv -- python $R/bench.py --operands $f --steps 40 --warmup 10 --no-cpu-baseline --no-roofline --no-operand-ab > $R/gpurun_out/prof_ab/$f.log 2>&1)
   st=$(find gpurun_out/prof_ab/$f -name "step_kernel_stats.csv" | head -1)
   cp $st gpurun_out/ab_${f}_kernel_stats.csv
 done

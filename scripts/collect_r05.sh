@@ -7,7 +7,7 @@ rocminfo 2>/dev/null | grep -m1 "Marketing Name.*MI" > gpurun_out/r05/device.txt
 python bench.py > gpurun_out/r05/bench_default.json 2> gpurun_out/r05/bench_default.err
 tail -c 300 gpurun_out/r05/bench_default.json
 # the operand formats next to each other on this box (no roofline / CPU legs): fp16 (default), bf16, fp16, bf16
-for f in f16 bf16 f16 bf16; do python bench.py --operands $f --no-cpu-baseline --no-roofline 2>/dev/null | tail -1; done > gpurun_out/r05/bench_operands_ab.json
+for f in f16 bf16 f16 bf16; do python bench.py --operands $f --no-cpu-baseline --no-roofline --no-operand-ab 2>/dev/null | tail -1; done > gpurun_out/r05/bench_operands_ab.json
 python tools/step_breakdown.py --detail > gpurun_out/r05/step_breakdown.txt 2>&1
 bash tools/collect_profiles.sh r05 > gpurun_out/r05/collect.log 2>&1
 python tools/trace_gaps.py $(find gpurun_out/prof_r05/trace -name step_kernel_trace.csv | head -1) > gpurun_out/r05/step_timeline.txt 2>&1
