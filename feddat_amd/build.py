@@ -29,16 +29,21 @@ ABLATE_LIB = os.path.join(PKG, "libfeddat_hip_ablate.so")
 F16_LIB = os.path.join(PKG, "libfeddat_hip_f16.so")
 
 
-def build(force: bool = False, verbose: bool = False, ablate: bool = False, f16: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, ablate: bool = False, f16: bool = False, variant: str = "",
+          extra_flags=()) -> str:
     """ablate=True: the -DFEDDAT_ABLATE build with the timing-only (wrong-result) probes of tools/ compiled in, written to
     libfeddat_hip_ablate.so; the production library has none of them (csrc/common.hip.h: FD_ABL).
     f16=True: the same sources with IEEE-half operands (-DFEDDAT_OPERANDS_F16: v_mfma_f32_16x16x32_f16, csrc/common.hip.h) ->
-    libfeddat_hip_f16.so, the same C ABI (feddat_operand_format() tells them apart)."""
+    libfeddat_hip_f16.so, the same C ABI (feddat_operand_format() tells them apart).
+    variant / extra_flags: an experimental build of either (tools/ A/Bs, e.g. variant="nt", extra_flags=["-DFD_EPI_NT"]) ->
+    libfeddat_hip[_f16]_<variant>.so in its own object directory; nothing in feddat_amd/ loads such a library."""
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "feddat_hip.h")]
     objdir = os.path.join(PKG, "build_ablate" if ablate else "build_f16" if f16 else "build")
     LIB = ABLATE_LIB if ablate else F16_LIB if f16 else globals()["LIB"]
     FLAGS = globals()["FLAGS"] + (["-DFEDDAT_ABLATE"] if ablate else []) + (["-DFEDDAT_OPERANDS_F16"] if f16 else [])
+    if variant:
+        objdir, LIB, FLAGS = objdir + "_" + variant, LIB[:-3] + "_" + variant + ".so", FLAGS + list(extra_flags)
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for s in srcs:
@@ -73,7 +78,9 @@ def build_all(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
-    if "--ablate" in sys.argv:
+    if "--nt" in sys.argv:      # A/B build: streaming hints on the heavy GEMM epilogues (scripts/ab_r05_nt.sh)
+        print(build(force="--force" in sys.argv, verbose=True, f16=True, variant="nt", extra_flags=["-DFD_EPI_NT"]))
+    elif "--ablate" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, ablate=True))
     else:
         print(*build_all(force="--force" in sys.argv, verbose=True), sep="\n")

@@ -392,6 +392,16 @@ constexpr int V2_EPI_LD16 = 208;              // bytes per staged bf16 row (96 x
 constexpr int V2_EPI_LD8 = 112;               // bytes per staged row of 8-bit gelu' codes (96 + 16 pad); 22 rows are addressable
 // SINK (v3: one wave per SIMD, nothing else to hide a stall): stores of rows outside the tile go to a dummy line
 // instead of being predicated, so the whole epilogue is one basic block the scheduler can interleave.
+// Streaming hints on the heavy epilogues' HBM streams (the 16-bit / code outputs that nothing in this launch reads back, the
+// code input that is read once): -DFD_EPI_NT builds them as non-temporal accesses so that they do not displace the B half an
+// XCD's L2 holds for the whole launch (tools/ A/B: scripts/ab_r05_nt.sh; results in DESIGN.md section 7d).
+#ifdef FD_EPI_NT
+#define FD_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define FD_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define FD_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#define FD_STREAM_LOAD(ptr) (*(ptr))
+#endif
 __device__ uint4 fd_epi_sink[64];
 template <int EPI, int WM, bool SINK = false>
 __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)[WM][6], char* stg, int mbase, int nbase,
@@ -442,7 +452,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
         for (int p = 0; p < 2; ++p) {
             const unsigned mc = (unsigned)min(mbase + i * 16 + r8[p], m_end - 1);
             const unsigned off = mc * (unsigned)g.ldaux + (unsigned)(nbase + c8[p] * 16);
-            ux8[i][p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g.aux) + off);
+            ux8[i][p] = FD_STREAM_LOAD(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g.aux) + off));
         }
     };
     if (G8IN) {
@@ -477,7 +487,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
                 bf16* o = m < m_end ? dst + (size_t)m * ld + nbase + sc8[p] * 8 : reinterpret_cast<bf16*>(fd_epi_sink) + lane * 8;
                 *reinterpret_cast<bf16x8*>(o) = v[p];
             } else if (m < m_end && !FD_ABL(g.nostore & 1)) {
-                *reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8) = v[p];
+                FD_STREAM_STORE(reinterpret_cast<bf16x8*>(dst + (size_t)m * ld + nbase + sc8[p] * 8), v[p]);
             }
         }
     };
@@ -490,7 +500,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
         for (int p = 0; p < 2; ++p) {
             const int m = mbase + i * 16 + r8[p];
             if (m < m_end && (p == 0 || lane < 32) && !FD_ABL(g.nostore & 1))
-                *reinterpret_cast<u32x4*>(o8 + (size_t)m * ld + nbase + c8[p] * 16) = cv[p];
+                FD_STREAM_STORE(reinterpret_cast<u32x4*>(o8 + (size_t)m * ld + nbase + c8[p] * 16), cv[p]);
         }
     };
     f32x4 sw4[G8OUT_ ? 1 : 6];
