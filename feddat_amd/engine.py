@@ -961,6 +961,17 @@ class ViltDatEngine:
         torch.cuda.synchronize()
         self.graph = graph
 
+    def assert_finite(self):
+        """The static loss scale has no GradScaler behind it that would skip an overflowed step (task_trainer.py:302 via
+        accelerate): if a gradient operand left fp16's range the update turned non-finite.  One host read-back of the trainable
+        state, meant to be called once per local update (TaskTrainer.train does); raises with what to change."""
+        for name, grp in (("adapter_0", self.ad[0]), ("adapter_1", self.ad[1]), ("head", self.head[self.task])):
+            if not bool(torch.isfinite(grp.p).all()):
+                raise L.FeddatHipError(
+                    f"non-finite values in {name} after the local update: with operands={self.operands!r} the backward carries a "
+                    f"static loss scale of {self.loss_scale:g}; this model's gradients leave fp16's range at that scale -- "
+                    "construct the engine with a smaller power of two (loss_scale=...) or operands='bf16'")
+
     # ------------------------------------------------------------------------------------------ inference
     @_bound
     @_bound

@@ -130,6 +130,7 @@ class TaskTrainer:
                 if self.args.debug > 0 and step > self.args.debug:     # task_trainer.py:82-83
                     break
                 loss = self.train_step(model, step, batch, optimizer, scheduler, hooks=None, epoch=epoch)
+        eng.assert_finite()        # one read-back per local update: a loss scale too large for this model's gradients is an error
         return 0.0, model
 
     def train_step(self, model: ViltContinualLearner, step, batch, optimizer=None, scheduler=None, hooks=None,
