@@ -100,6 +100,46 @@ def test_continual_learner_train_and_fedavg_round(api, golden_dir):
     assert len(ev) == 3 and server.optimizer_adapters() == (1,)
 
 
+def test_heterogeneous_clients_round_vs_oracle(api):
+    """SURVEY 8d config 3 in small: two clients whose answers come from DIFFERENT Dirichlet(0.5) label priors and whose loaders
+    have different lengths (5 and 3 batches), one FL round -- local updates from the same server state, personal parameters kept
+    per client, get_average_net of adapter_1 -- against the oracle doing the same on the same batches.  The clients' adapter_1
+    updates must really disagree (cosine well below 1), and the average must match."""
+    from feddat_amd import vilt_spec
+    tasks = ["art", "gqa"]
+    d = O.ViltDims(layers=2)
+    P = O.make_params(d, tasks, bias_std=0.02)
+    P_ref = {k: v.clone() for k, v in P.items()}
+    args = types.SimpleNamespace(local_epochs=1, num_epochs=15, lr=1e-4, optimizer_mode="dat", debug=0, hip_graph=True)
+    server = api.modeling.create_vilt_continual_learner_model(P, tasks, DEV, batch_size=4, image_size=224, num_layers=2)
+    server_sd = {k: v.clone() for k, v in server.state_dict().items()}
+    comm = server.comm_state_dict_names
+    steps = {"art": 5, "gqa": 3}
+    c_models, c_ref = [], []
+    for ci, t in enumerate(tasks):
+        prior = vilt_spec.client_label_prior(ci)
+        host = [O.synthetic_batch(4, 224, 900 + 10 * ci + s, label_prior=prior) for s in range(steps[t])]
+        server.load_state_dict(server_sd)
+        server.adapter_requires_grad.update({0: True, 1: True})
+        api.train.TaskTrainer(args, t, [_dev(b) for b in host]).train(server)
+        c_models.append({n: server.state_dict()[n].clone() for n in comm})
+        Pc = {k: v.clone() for k, v in P_ref.items()}
+        client = O.DatClient(Pc, d, t, lr=1e-4, steps_per_epoch=steps[t])
+        for b in host:
+            client.train_step(b)
+        c_ref.append({n: Pc[n].clone() for n in comm})
+        assert_update_parity(comm, server.state_dict(), Pc, P_ref, 1e-3, 0.1, f"client {t} adapter_1")
+    big = max(comm, key=lambda n: P_ref[n].numel())
+    da, db = (c_ref[0][big] - P_ref[big]).flatten(), (c_ref[1][big] - P_ref[big]).flatten()
+    cos = float(torch.dot(da, db) / (da.norm() * db.norm()))
+    assert cos < 0.9, cos                                  # heterogeneous clients: the updates point in different directions
+    server.load_state_dict(server_sd)
+    api.train.get_average_net(server, c_models, [1, 1], tasks, DEV)
+    ref_server = {n: torch.zeros_like(P_ref[n]) for n in comm}
+    O.get_average_net(ref_server, c_ref, [1, 1])
+    assert_update_parity(comm, server.state_dict(), ref_server, P_ref, 1e-3, 0.1, "averaged adapter_1 of heterogeneous clients")
+
+
 def test_kl_loss_op(api, golden_dir):
     g = load(golden_dir, "g2_loss.npz")
     kl = api.train.kl_loss(torch.from_numpy(g["logits"]).to(DEV), torch.from_numpy(g["teacher"]).to(DEV))
