@@ -573,6 +573,9 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="configs[4]: e4m3 MFMA for the QKV / FFN1 forward products of the frozen backbone (bf16 adapters); "
                          "quoted at --batch 64")
+    ap.add_argument("--fp8-products", dest="fp8_products", type=int, default=7, choices=[6, 7],
+                    help="--fp8: 7 (default) = also QKV^T on the block-scaled fp8 MFMA with MX-scaled e4m3 dqkv from the attention "
+                         "backward; 6 = the round-3 / 4 configuration (A/B)")
     ap.add_argument("--operands", default="f16", choices=["bf16", "f16"],
                     help="16-bit MFMA operand format of the frozen products, attention and adapters: IEEE half with a 2^14 loss "
                          "scale (default: the reference's own GPU arithmetic is fp16 autocast, and the format that meets the "
@@ -635,7 +638,7 @@ def main():
     # identical frozen backbone + server adapter on every client (seed 0); heterogeneous data per client
     params = vilt_spec.random_init(12, tasks, seed=0, device="cpu")
     eng = engine.ViltDatEngine(params, [task], dev, batch=B, res=res, layers=12, fp8=args.fp8,
-                               operands="bf16" if args.fp8 else args.operands)
+                               operands="bf16" if args.fp8 else args.operands, fp8_mx_dqkv=args.fp8_products == 7)
     eng.fused_tail = not args.unfused_tail
     nb = 4
     # --hetero: client r also draws its answers from its own Dirichlet(0.5) label prior

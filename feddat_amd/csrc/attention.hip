@@ -323,14 +323,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
 //            dS = P (dP - D);  dV += P^T dO, dK += dS^T Q;  dS^T goes to LDS as bf16 panels [q tile][key][16 q];
 //   phase B: wave w owns query tile w: dQ = sum over keys dS K, the dS operand read back transposed from the panels.
 // 2 NKS waves per block; LDS = 3 S_pad x 128 B + S_pad^2 x 2 B + 3 S_pad x 4 B  (144 KiB at S_pad = 192).
-template <int NKS>
+// F8MX (configs[4]): dq | dk | dv leave as e4m3 with one E8M0 scale per (row, 32 columns) -- the MX block format the block-scaled
+// MFMA of feddat_gemm_fp8mx_nt consumes -- instead of 16-bit values: every (sample, head) block owns whole 64-column slices of
+// its rows, i.e. two whole scale blocks per row and part, so the quantisation needs nothing from other blocks (a per-ROW scale
+// would need the maximum over all 36 slices of the row: a second pass over dqkv).  Half the bytes of the 16-bit form.
+template <int NKS, bool F8MX = false>
 __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv,
                                                                      const uint8_t* __restrict__ kmask,
                                                                      const bf16* __restrict__ ctx,
                                                                      const float* __restrict__ lse,
                                                                      const bf16* __restrict__ dctx,
                                                                      bf16* __restrict__ dqkv, int S, int heads,
-                                                                     const int npairs, const int dbg_in) {
+                                                                     const int npairs, const int dbg_in,
+                                                                     uint8_t* __restrict__ dq8 = nullptr,
+                                                                     uint8_t* __restrict__ dqsc = nullptr) {
     // dbg (tools/attn_ablate.py, debug flags bits 20..22; -DFEDDAT_ABLATE build only, the constant 0 otherwise; timing only):
     // 1 no global stores, 2 no phase-A arithmetic, 4 no phase B
     const int dbg = FD_ABL(dbg_in);
@@ -508,7 +514,36 @@ __global__ __launch_bounds__(NKS * 128) void attn_bwd_fused_kernel(const bf16* _
         for (int p = 0; p < 2; ++p) {
             const int r = p * 8 + (lane >> 3), c = lane & 7;
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + r * XROW + c * 16);
-            if (row0 + r < S && !(dbg & 1)) *reinterpret_cast<bf16x8*>(gbase + (size_t)(row0 + r) * ld + c * 8) = v;
+            if (!F8MX) {
+                if (row0 + r < S && !(dbg & 1)) *reinterpret_cast<bf16x8*>(gbase + (size_t)(row0 + r) * ld + c * 8) = v;
+            } else {
+                // lanes c = 0..3 / 4..7 of a row hold one 32-column block each: its maximum over the 4 lanes, the E8M0 exponent
+                // e = ceil(log2(amax / 448)) from the float's bits, codes = e4m3(v * 2^-e) (|.| <= 448 by construction)
+                float f[8], amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] = (float)v[e];
+                    amax = fmaxf(amax, fabsf(f[e]));
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                const unsigned xb = __float_as_uint(amax * (1.0f / 448.0f));
+                int ex = (int)((xb >> 23) & 0xffu) - 127 + ((xb & 0x7fffffu) ? 1 : 0);
+                ex = amax > 0.f ? max(-126, min(126, ex)) : -126;
+                const float inv = __uint_as_float((unsigned)(127 - ex) << 23);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * inv, -448.0f, 448.0f);
+                int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+                int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+                if (row0 + r < S && !(dbg & 1)) {
+                    // gbase addresses the 16-bit layout [rows, 3H] in elements: the same element offsets address the byte layout
+                    const size_t off = (size_t)(gbase - dqkv) + (size_t)(row0 + r) * ld + c * 8;
+                    *reinterpret_cast<int2*>(dq8 + off) = int2{lo, hi};
+                    if ((c & 3) == 0) dqsc[off >> 5] = (uint8_t)(ex + 127);
+                }
+            }
         }
     };
     if (have_kv) {
@@ -637,6 +672,34 @@ extern "C" int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const v
     FD_LAUNCH_RET();
 }
 
+// configs[4]: the same backward with dq | dk | dv written as MX-scaled e4m3 (attn_bwd_fused_kernel<N, true>): dq8 [B S, 3 H] bytes
+// in the layout of the 16-bit dqkv, dq_scale [B S, 3 H / 32] E8M0 bytes.  Sequences of up to 192 tokens (the fused kernel).
+extern "C" int feddat_attn_bwd_fp8mx(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse,
+                                     const void* dctx, uint8_t* dq8, uint8_t* dq_scale, int B, int S, int heads,
+                                     hipStream_t stream) {
+    FD_CHECK_ARG(qkv && ctx && lse && dctx && dq8 && dq_scale && B > 0 && S > 0 && S <= 192 && heads > 0);
+    FD_CHECK_ARG(((uintptr_t)dq8 & 7) == 0);
+    const int nks = (S + 31) / 32;
+    const int sp = nks * 32;
+    const int ldsf = 3 * sp * ROWB + sp * sp * 2 + 3 * sp * 4;
+    int n_cu = 0;
+    if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+    const int grid = B * heads < n_cu ? B * heads : n_cu;
+#define ATTN_BWD_MX(N)                                                                                               \
+    case N:                                                                                                          \
+        if (set_lds(attn_bwd_fused_kernel<N, true>, ldsf)) return FEDDAT_ELAUNCH;                                    \
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<N, true>), dim3(grid), dim3((N) * 128), ldsf, stream,              \
+                           (const bf16*)qkv, key_mask, (const bf16*)ctx, lse, (const bf16*)dctx, (bf16*)dq8, S, heads, \
+                           B * heads, 0, dq8, dq_scale);                                                             \
+        break;
+    switch (nks) {
+        ATTN_BWD_MX(1) ATTN_BWD_MX(2) ATTN_BWD_MX(3) ATTN_BWD_MX(4) ATTN_BWD_MX(5) ATTN_BWD_MX(6)
+        default: return FEDDAT_EINVAL;
+    }
+#undef ATTN_BWD_MX
+    FD_LAUNCH_RET();
+}
+
 int fd_prepare_attn_kernels() {
 #define PREP(N)                                                                          \
     if (set_lds(attn_fwd_kernel<N>, (N) * 32 * ROWB * 2 + (N) * 32 * 4)) return FEDDAT_ELAUNCH; \
@@ -647,6 +710,10 @@ int fd_prepare_attn_kernels() {
     if (set_lds(attn_bwd_fused_kernel<N>, 3 * (N) * 32 * ROWB + (N) * 32 * (N) * 32 * 2 + 3 * (N) * 32 * 4)) return FEDDAT_ELAUNCH;
     PREPF(1) PREPF(2) PREPF(3) PREPF(4) PREPF(5) PREPF(6)
 #undef PREPF
+#define PREPM(N)                                                                                                      \
+    if (set_lds(attn_bwd_fused_kernel<N, true>, 3 * (N) * 32 * ROWB + (N) * 32 * (N) * 32 * 2 + 3 * (N) * 32 * 4)) return FEDDAT_ELAUNCH;
+    PREPM(1) PREPM(2) PREPM(3) PREPM(4) PREPM(5) PREPM(6)
+#undef PREPM
     return FEDDAT_OK;
 }
 

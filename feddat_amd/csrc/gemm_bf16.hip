@@ -35,6 +35,8 @@ struct GemmArgs {
     int nostore;   // tools/ ablation (debug flag 16): the bf16 epilogues do everything but their global stores
     const float* sa;   // fp8 operands: per-row scale of A [M] and per-row scale of B [N] (acc * sa[m] * sw[n]); else null
     const float* sw;
+    const uint8_t* amx;   // MXA kernels: E8M0 block scales of A, one byte per (row, 32 consecutive k): [M, ld_mx], 2^(byte - 127)
+    int ld_mx;
 };
 
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, int ld, int row0, int rows_max, int k0,
@@ -513,7 +515,7 @@ __device__ __forceinline__ void v2_epilogue_bf16(const GemmArgs& g, f32x4 (&acc)
     for (int i = 0; i < WM; ++i) {
         f32x4 val[6];
         if (g.sw) {          // fp8 operands: dequantise the accumulators (per-row scale of A x per-channel scale of B)
-            const float sa = g.sa[min(mbase + i * 16 + frow, m_end - 1)];
+            const float sa = g.sa ? g.sa[min(mbase + i * 16 + frow, m_end - 1)] : 1.0f;      // (MXA: the block scales are in the MFMA)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 if (EPI == FEDDAT_EPI_MUL_G8_F8)      // the output keeps the input's row scale (x FEDDAT_F8_GRAD_HEADROOM): no sa
@@ -682,13 +684,22 @@ template <int WM>
 struct V2State {
     const bf16* pa[WM];
     const bf16* pb[3];
+    const uint8_t* psc;   // MXA: this lane's row of A block scales (k-tile 0)
     int l_tile, l_kt;     // tile index / k-tile of the next staging load
 };
 
-template <int EPI, int WM, bool FP8 = false, bool FP8_K32 = false>
+// MXA (fp8, K = 128 MFMA only): A carries true MX block scales -- one E8M0 byte per (row, 32 consecutive k) in g.amx -- which the
+// block-scaled MFMA applies itself (its scale operand: every lane supplies the scale of the 32 k-values it supplies).  For that
+// a lane's two 16-byte fragment reads must be the two halves of ONE 32-byte block: chunks 2 fg, 2 fg + 1 of the 128-byte row
+// instead of fg, 4 + fg (A and B alike: the contraction only needs both to use the same slot map).  The scales of a k-tile
+// (4 bytes per row) ride the staging pipeline as one more piece per wave: a dword per row -> LDS [rows][4] per stage; the
+// consumer reads its byte (row of the row group, block fg) next to its fragments.
+template <int EPI, int WM, bool FP8 = false, bool FP8_K32 = false, bool MXA = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     using Cfg = V2Cfg<WM>;
     constexpr int NP = Cfg::NP;
+    static_assert(!MXA || (FP8 && !FP8_K32), "MX block scales exist on the K = 128 fp8 path only");
+    constexpr int SC_OFF = Cfg::LDS;              // MXA: 2 stages x [64 WM rows][4 bytes] behind everything else
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef FEDDAT_ABLATE
     // tools/gemm_dephase.py (timing probe): blocks start (bid / 8) % 4 x q x 2 us apart, so that the CUs' epilogues (HBM write
@@ -720,6 +731,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     v2_tile_coords(a, bid, total, m0, n0, m_last);
     V2State<WM> L;
     v2_piece_ptrs<WM>(g, m0, m_last, n0, wave, lane, L.pa, L.pb);
+    // MXA: the wave stages the block scales of the A rows it stages (8 WM rows: lanes beyond repeat the last one)
+    auto sc_ptr = [&](int tm0, int tml) {
+        const int r = wave * (8 * WM) + min(lane, 8 * WM - 1);
+        return g.amx + (size_t)min(tm0 + r, tml) * g.ld_mx;
+    };
+    L.psc = MXA ? sc_ptr(m0, m_last) : nullptr;
     L.l_tile = 0;
     L.l_kt = 0;
     int issued = 0;                     // k-tiles whose staging loads have been issued (may run past total_it)
@@ -743,6 +760,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
                 int lm0, ln0, lml;
                 v2_tile_coords(a, bid + L.l_tile * grid, total, lm0, ln0, lml);
                 v2_piece_ptrs<WM>(g, lm0, lml, ln0, wave, lane, L.pa, L.pb);
+                if (MXA) L.psc = sc_ptr(lm0, lml);
             }
         }
         ++issued;
@@ -752,20 +770,30 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
                    (p < WM ? (wave * WM + p) * 1024 : Cfg::TILE_A + (wave * 3 + p - WM) * 1024);
         *reinterpret_cast<u32x4*>(sb) = rs[p];
     };
+    unsigned rsc = 0;       // MXA: the scale piece (4 block scales of this lane's row for the k-tile being staged)
+    auto gload_sc = [&]() {
+        if (MXA) rsc = *reinterpret_cast<const unsigned*>(L.psc + L.l_kt * 4);
+    };
+    auto lwrite_sc = [&](int stage) {
+        if (MXA && lane < 8 * WM) *reinterpret_cast<unsigned*>(smem + SC_OFF + stage * (256 * WM) + (wave * (8 * WM) + lane) * 4) = rsc;
+    };
     auto gload = [&]() {
 #pragma unroll
         for (int p = 0; p < NP; ++p) gload_piece(p);
+        gload_sc();
         stream_advance();
     };
     auto lwrite = [&](int stage) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) lwrite_piece(p, stage);
+        lwrite_sc(stage);
         ++written;
     };
 
     const int frow = lane & 15, fg = lane >> 4;
     // fragment read of row r (a multiple of 16 + frow), k-half ks: 16-byte chunk (4 ks + fg) ^ (frow & 7) of the row
-    const int frag_off[2] = {frow * 128 + (((0 + fg) ^ (frow & 7)) << 4), frow * 128 + (((4 + fg) ^ (frow & 7)) << 4)};
+    const int frag_off[2] = {frow * 128 + (((MXA ? 2 * fg : fg) ^ (frow & 7)) << 4),
+                             frow * 128 + (((MXA ? 2 * fg + 1 : 4 + fg) ^ (frow & 7)) << 4)};
     char* stg = smem + Cfg::EPI_OFF + wave * V2_EPI_WAVE;
     int kt = 0, c_tile = 0, st = 0;
     bool pend = false;                  // a finished tile whose epilogue has not run yet
@@ -809,7 +837,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     for (int it = 0; it < total_it; ++it) {
         // ------------------------------ L phase ------------------------------
         bf16x8 fa[2][WM], fb[2][6];
+        int asc[MXA ? WM : 1];      // MXA: E8M0 scale of this lane's 32 k-values of A row group i
         auto read_frags = [&]() {
+            if (MXA) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    asc[i] = *reinterpret_cast<const uint8_t*>(smem + SC_OFF + st * (256 * WM) + (wm * (16 * WM) + i * 16 + frow) * 4 + fg);
+            }
             // address = per-lane swizzled offset (loop invariant, one per k-half) + wave-uniform tile base + immediate
             const int a_base = st * Cfg::STAGE + wm * (16 * WM * 128);
             const int b_base = st * Cfg::STAGE + Cfg::TILE_A + wn * (96 * 128);
@@ -863,7 +897,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16x128_fp8_mx(fb[0][j], fb[1][j], fa[0][i], fa[1][i], acc[i][j]);
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = MXA ? mfma16x128_fp8_mx_sb(fb[0][j], fb[1][j], fa[0][i], fa[1][i], acc[i][j], asc[MXA ? i : 0])
+                                    : mfma16x128_fp8_mx(fb[0][j], fb[1][j], fa[0][i], fa[1][i], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 2 * i; p < 2 * i + 2; ++p)
@@ -871,6 +907,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
                         lwrite_piece(p, wstage);
                         gload_piece(p);
                     }
+                if (MXA && i == WM - 1) {
+                    lwrite_sc(wstage);
+                    gload_sc();
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -1449,7 +1489,8 @@ static int fp8_launch(GemmArgsV2& a2, int M, int N, int K, int epi, hipStream_t 
         case FEDDAT_EPI_RESID_F32: kern = gemm_nt_v2_kernel<FEDDAT_EPI_RESID_F32, 3, true>; break;
         case FEDDAT_EPI_F32: FD_FP8_PICK(FEDDAT_EPI_F32); break;
         case FEDDAT_EPI_BF16:
-            if (fd_debug_flags() & 256) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, true>;
+            if (g.amx) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, false, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, false, true>;
+            else if (fd_debug_flags() & 256) kern = wm4 ? gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 4, true, true> : gemm_nt_v2_kernel<FEDDAT_EPI_BF16, 3, true, true>;
             else FD_FP8_PICK(FEDDAT_EPI_BF16);
             break;
         case FEDDAT_EPI_GELU:      // debug flag 256, tools/ A/B only: the CDNA3-style K = 32 fp8 instruction (bf16 issue rate)
@@ -1459,11 +1500,26 @@ static int fp8_launch(GemmArgsV2& a2, int M, int N, int K, int epi, hipStream_t 
         default: return FEDDAT_EINVAL;
     }
 #undef FD_FP8_PICK
-    const int lds_bytes = wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS;
+    const int lds_bytes = (wm4 ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) + (g.amx ? 2 * 256 * (wm4 ? 4 : 3) : 0);   // MXA: + the scale stages
     if (fd_set_max_lds((const void*)kern, lds_bytes) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     const int total = a2.tiles_m * tiles_n;
     hipLaunchKernelGGL(kern, dim3(total < n_cu ? total : n_cu), dim3(512), lds_bytes, stream, a2);
     FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_gemm_fp8mx_nt(const void* A8, int lda, const uint8_t* a_mx, int ld_mx, const void* B8, int ldb,
+                                    const float* b_scale, int M, int N, int K, const float* bias, void* out_bf16, int ldo16,
+                                    hipStream_t stream) {
+    FD_CHECK_ARG(A8 && a_mx && B8 && b_scale && out_bf16 && M >= 1024 && N > 0 && N % V2_BN == 0 && K > 0 && K % 128 == 0);
+    FD_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ((uintptr_t)out_bf16 & 15) == 0 && ldo16 % 8 == 0);
+    FD_CHECK_ARG(ld_mx % 4 == 0 && ld_mx >= K / 32 && ((uintptr_t)a_mx & 3) == 0);
+    GemmArgsV2 a2;
+    GemmArgs& g = a2.g;
+    g = GemmArgs{};
+    g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.bias = bias; g.sa = nullptr; g.sw = b_scale; g.amx = a_mx; g.ld_mx = ld_mx;
+    g.out_bf16 = (bf16*)out_bf16;
+    g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2; g.ldo16 = ldo16; g.epi = FEDDAT_EPI_BF16;
+    return fp8_launch(a2, M, N, K, FEDDAT_EPI_BF16, stream);
 }
 
 extern "C" int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void* B8, int ldb,

@@ -78,7 +78,7 @@ class ViltDatEngine:
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
                  weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False,
                  fp8_ffn_chain: bool = True, gelu_codes: bool = True, operands: Optional[str] = None,
-                 loss_scale: Optional[float] = None):
+                 loss_scale: Optional[float] = None, fp8_mx_dqkv: bool = True):
         """operands: "f16" (the default) or "bf16" (the default with fp8=True, configs[4]).  "f16": every 16-bit MFMA operand of the step -- frozen weights and their transposes, LayerNorm outputs,
         qkv, probabilities, ctx, gelu(u), the adapters' operand copies, and every gradient operand of the dX products and of
         the attention backward -- is IEEE half instead of bf16 (libfeddat_hip_f16.so: v_mfma_f32_16x16x32_f16, the same MFMA
@@ -110,6 +110,10 @@ class ViltDatEngine:
         self.loss_scale = float(loss_scale if loss_scale is not None else (16384.0 if operands == "f16" else 1.0))
         if self.loss_scale <= 0 or math.frexp(self.loss_scale)[0] != 0.5:
             raise L.FeddatHipError("loss_scale must be a power of two (it is removed exactly)")
+        # fp8 (round 5): the attention backward writes dq | dk | dv as MX-scaled e4m3 (one E8M0 scale per (row, 32 columns):
+        # feddat_attn_bwd_fp8mx) and QKV^T runs on the block-scaled fp8 MFMA with those scales (feddat_gemm_fp8mx_nt): the seventh
+        # of the eight frozen products per layer, and half the bytes of the backward's largest write
+        self.fp8_mx_dqkv = bool(fp8) and bool(fp8_mx_dqkv)
         self._init(params, tasks, device, batch, res, text_len, layers, num_labels, lr, weight_decay, adam_eps, wgrad_splits,
                    fp8, fp8_ffn_chain, gelu_codes)
 
@@ -191,6 +195,8 @@ class ViltDatEngine:
                 extra["w28"], extra["s2"] = fp8_of(w2)
                 extra["w1T8"], s1T = fp8_of(w1.t().contiguous())
                 extra["s1T4"] = s1T * L.F8_GRAD_HEADROOM
+                if self.fp8_mx_dqkv:      # QKV^T: [768, 2304], per output channel
+                    extra["wqkvT8"], extra["sqkvT"] = fp8_of(wqkv.t().contiguous())
             self.layers.append(dict(
                 extra, wqkv=bf16_of(wqkv), wqkvT=bf16_T(wqkv), bqkv=bqkv,
                 wo=bf16_of(wo), woT=bf16_T(wo), bo=P(Lp + "attention.output.dense.bias"),
@@ -251,6 +257,11 @@ class ViltDatEngine:
             self.f8 = torch.empty(R2, I, dtype=torch.uint8, device=dev)     # gelu(u) as e4m3, fixed scale
             self.f8s = torch.full((R2,), L.F8_ACT_SCALE, dtype=torch.float32, device=dev)
             self.dU8 = torch.empty(R2, I, dtype=torch.uint8, device=dev)    # dU rows as e4m3, row scale = headroom x gsc
+            if self.fp8_mx_dqkv:
+                if self.S > 192:
+                    raise L.FeddatHipError("fp8_mx_dqkv needs sequences of at most 192 tokens (feddat_attn_bwd_fp8mx)")
+                self.dqkv8 = torch.empty(R2, 3 * H, dtype=torch.uint8, device=dev)        # dq | dk | dv as e4m3 ...
+                self.dqkv_sc = torch.empty(R2, 3 * H // 32, dtype=torch.uint8, device=dev)   # ... + E8M0 per (row, 32 columns)
         self.f16 = b16(R2, I)          # gelu(u), transient
         # layer 0 (shared body, R rows): only h3 is kept
         self.l0 = dict(qkv=b16(R, 3 * H), ctx=b16(R, H), lse=f32(B, self.heads, self.S), h2=f32(R, H), h3=f32(R, H))
@@ -702,8 +713,13 @@ class ViltDatEngine:
                 L.layernorm_bwd_dx_fp8(a["h2"], a["st2"], W["ln2g"], R2, H, self.g8, self.gsc, dy_bf16=self.dx16, dres=oth,
                                        out_f32=cur)
                 L.gemm_fp8_nt(self.g8, self.gsc, W["woT8"], W["soT"], L.EPI_BF16, out_bf16=self.dctx)
-                L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=m2)
-                L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
+                if self.fp8_mx_dqkv:
+                    L.attn_bwd_fp8mx(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv8, self.dqkv_sc, nb, self.S, self.heads,
+                                     key_mask=m2)
+                    L.gemm_fp8mx_nt(self.dqkv8, self.dqkv_sc, W["wqkvT8"], W["sqkvT"], out_bf16=self.dx16)
+                else:
+                    L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=m2)
+                    L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
                 L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
                 cur, oth = oth, cur
                 continue
@@ -847,7 +863,7 @@ class ViltDatEngine:
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.use_layer_calls, self.fp8,
-               self.fp8_ffn_chain, self.fused_tail, self.cls_attention, self.operands, self.loss_scale)        # host-side switches that change the launch list are part of the signature
+               self.fp8_ffn_chain, self.fused_tail, self.cls_attention, self.operands, self.loss_scale, self.fp8_mx_dqkv)        # host-side switches that change the launch list are part of the signature
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig

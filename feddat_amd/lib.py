@@ -96,6 +96,7 @@ _SIGS = {
     "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
     "feddat_gemm_fp8_nt": [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp],
     "feddat_layernorm_bwd_dx_fp8": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp],
+    "feddat_gemm_fp8mx_nt": [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp],
     "feddat_gemm_fp8_nt_f32": [vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, i32, vp],
     "feddat_quant_rows_fp8": [vp, i64, i32, i32, vp, vp, vp],
     "feddat_layernorm_fwd_fp8": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
@@ -103,6 +104,7 @@ _SIGS = {
                                    vp, i64, vp],
     "feddat_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "feddat_attn_bwd_fp8mx": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn_cls_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn_cls_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "feddat_attn2_fwd": [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, i32, i32, i32, i64, i64, i32, vp],
@@ -386,6 +388,16 @@ def gemm_fp8_nt(A8, a_scale, B8, b_scale, epi, *, bias=None, aux=None, out_bf16=
                                    0 if out2_bf16 is None else out2_bf16.stride(0), _stream()), "feddat_gemm_fp8_nt")
 
 
+def gemm_fp8mx_nt(A8, a_mx, B8, b_scale, *, bias=None, out_bf16=None):
+    """out = (A . B^T) * b_scale[None, :] + bias with A = A8 (e4m3) * 2^(a_mx - 127) per (row, 32-column block): a_mx uint8
+    [M, K / 32] E8M0 block scales applied by the MFMA itself (feddat_gemm_fp8mx_nt)."""
+    _dev(A8, a_mx, B8, b_scale, out_bf16)
+    M, K = A8.shape
+    N = B8.shape[0]
+    _chk(load().feddat_gemm_fp8mx_nt(_p(A8), A8.stride(0), _p(a_mx), a_mx.stride(0), _p(B8), B8.stride(0), _p(b_scale), M, N, K,
+                                     _p(bias), _p(out_bf16), out_bf16.stride(0), _stream()), "feddat_gemm_fp8mx_nt")
+
+
 def gemm_fp8_nt_f32(A8, a_scale, B8, b_scale, *, bias=None, resid=None, out_f32=None):
     """out_f32 = (A8 @ B8^T) * a_scale[:, None] * b_scale[None, :] + bias (+ resid)."""
     _dev(A8, B8, a_scale, b_scale, out_f32, resid, bias)
@@ -417,6 +429,13 @@ def attn_bwd(qkv, ctx, lse, dctx, dqkv, B, S, heads, key_mask=None):
     _dev(qkv, ctx, dctx, dqkv)
     _chk(load().feddat_attn_bwd(_p(qkv), _p(key_mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), B, S, heads, _stream()),
          "feddat_attn_bwd")
+
+
+def attn_bwd_fp8mx(qkv, ctx, lse, dctx, dq8, dq_scale, B, S, heads, key_mask=None):
+    """attn_bwd with dq | dk | dv as MX-scaled e4m3: dq8 uint8 [B S, 3 H], dq_scale uint8 [B S, 3 H / 32] (E8M0 per 32 columns)."""
+    _dev(qkv, ctx, dctx, dq8, dq_scale)
+    _chk(load().feddat_attn_bwd_fp8mx(_p(qkv), _p(key_mask), _p(ctx), _p(lse), _p(dctx), _p(dq8), _p(dq_scale), B, S, heads,
+                                      _stream()), "feddat_attn_bwd_fp8mx")
 
 
 def attn_cls_fwd(qkv, ctx, lse, B, S, heads, key_mask=None):

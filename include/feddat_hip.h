@@ -122,6 +122,12 @@ int feddat_gemm_fp8_nt(const void* A8, int lda, const float* a_scale, const void
                        hipStream_t stream);
 /* the same fp8 product with an fp32 output: out_f32 = (A8 B8^T) * a_scale[m] * b_scale[n] + bias (+ resid, fp32, may be NULL):
  * FFN2 of a ViLT layer on configs[4], fed by the e4m3 gelu(u) that FEDDAT_EPI_GELU_G8_F8 leaves (adaptered_output.py:74-76). */
+/* configs[4], the product whose A operand is written 64 columns at a time by different blocks (dqkv -> QKV^T): A carries true MX
+ * block scales -- one E8M0 byte per (row, 32 consecutive k): a_mx [M, ld_mx], value 2^(byte - 127), A8[m][k] * 2^(a_mx[m][k / 32] -
+ * 127) is the operand -- which the CDNA4 block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) applies itself; B keeps its
+ * per-output-channel fp32 scale.  out_bf16 = (A . B^T) * b_scale[n] + bias.  M >= 1024, N % 192 == 0, K % 128 == 0. */
+int feddat_gemm_fp8mx_nt(const void* A8, int lda, const uint8_t* a_mx, int ld_mx, const void* B8, int ldb, const float* b_scale,
+                         int M, int N, int K, const float* bias, void* out_bf16, int ldo16, hipStream_t stream);
 int feddat_gemm_fp8_nt_f32(const void* A8, int lda, const float* a_scale, const void* B8, int ldb, const float* b_scale, int M,
                            int N, int K, const float* bias, const float* resid, int ldr, float* out_f32, int ldo32,
                            hipStream_t stream);
@@ -150,6 +156,11 @@ int feddat_attn_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* 
 /* dX-only backward: dqkv (bf16 [B*S, 3*H]) from dctx (bf16 [B*S,H]), qkv, ctx, lse. */
 int feddat_attn_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* dctx,
                     void* dqkv, int B, int S, int heads, hipStream_t stream);
+/* configs[4]: feddat_attn_bwd whose dq | dk | dv leave as MX-scaled e4m3 instead of 16-bit values: dq8 [B S, 3 H] bytes (the column
+ * layout of dqkv), dq_scale [B S, 3 H / 32] E8M0 bytes, element = e4m3 * 2^(scale - 127), one scale per (row, 32 columns) =
+ * the A operand of feddat_gemm_fp8mx_nt (QKV^T on the block-scaled fp8 MFMA).  S <= 192. */
+int feddat_attn_bwd_fp8mx(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* dctx,
+                          uint8_t* dq8, uint8_t* dq_scale, int B, int S, int heads, hipStream_t stream);
 /* The same attention for a layer of which only token 0 of every sample is consumed (the LAST ViLT layer: HF ViltPooler
  * reads hidden_states[:, 0]; vilt.py:127): one query per (sample, head).  feddat_attn_cls_fwd writes row b*S of ctx and
  * lse[b, h, 0] only.  feddat_attn_cls_bwd takes dctx0 = fp32 [B, H], the gradient of those rows (all other rows of dctx

@@ -1138,6 +1138,89 @@ def test_gemm_fp8_vs_fp32_on_the_dequantised_operands(L, M, N, K, epi):
     assert rel_err(ref, full) < 0.08
 
 
+def _mx_quant(x):
+    """Host-side (torch) MX quantiser: one E8M0 scale per (row, 32 consecutive columns), 2^ceil(log2(amax / 448)); e4m3 codes by
+    torch's own round-to-nearest-even conversion.  -> (codes uint8 [M, K], scale bytes uint8 [M, K / 32], dequantised fp32)."""
+    M, K = x.shape
+    xb = x.view(M, K // 32, 32)
+    amax = xb.abs().amax(-1)
+    e = torch.ceil(torch.log2(amax.clamp_min(2.0 ** -120) / 448.0)).clamp(-127, 127)
+    scale = torch.exp2(e)
+    q = (xb / scale[..., None]).to(torch.float8_e4m3fn)
+    deq = (q.float() * scale[..., None]).view(M, K)
+    return q.view(M, K).view(torch.uint8).contiguous(), (e + 127).to(torch.uint8).contiguous(), deq
+
+
+@pytest.mark.parametrize("M,N,K", [(11840, 768, 2304), (23680, 768, 2304), (1200, 192, 128), (11849, 768, 768), (5920, 2304, 768)])
+def test_gemm_fp8_mx_block_scaled_A(L, M, N, K):
+    """feddat_gemm_fp8mx_nt: A with true MX block scales (E8M0 per (row, 32 k)) applied by the block-scaled MFMA itself.  Rows whose
+    32-blocks differ in magnitude by many binades (what per-row scaling cannot represent) against the fp32 product of the
+    dequantised operands: only accumulation order + the bf16 output rounding differ."""
+    g = torch.Generator().manual_seed(M + K)
+    mag = torch.exp2(torch.randint(-12, 4, (M, K // 32, 1), generator=g).float())          # block magnitudes over 16 binades
+    A = (torch.randn(M, K // 32, 32, generator=g) * mag).view(M, K).to(DEV)
+    A[5, 64:96] = 0.0                                                                       # an all-zero block
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) * 0.01
+    A8, amx, Adeq = _mx_quant(A)
+    assert (Adeq - A).abs().max() <= float(A.abs().max()) / 8 and float((Adeq - A).abs().mean() / A.abs().mean()) < 0.04
+    W8, sw = torch.empty(N, K, dtype=torch.uint8, device=DEV), torch.empty(N, device=DEV)
+    L.quant_rows_fp8(W, W8, sw)
+    ref = Adeq @ _fp8_deq(W8, sw).t() + bias
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.gemm_fp8mx_nt(A8, amx, W8, sw, bias=bias, out_bf16=out)
+    assert torch.isfinite(out.float()).all()
+    err = (out.float() - ref).abs()
+    tol = 8e-3 * ref.abs() + 2e-3 * float(ref.abs().mean())            # bf16 output rounding + accumulation order
+    assert bool((err <= tol).all()), (float(err.max()), float(ref.abs().max()), int((err > tol).sum()))
+
+
+@pytest.mark.parametrize("B,S,heads,masked", [(4, 185, 12, False), (3, 90, 12, True), (64, 185, 12, False)])
+def test_attention_bwd_mx_fp8_output(L, B, S, heads, masked):
+    """feddat_attn_bwd_fp8mx: the same backward as feddat_attn_bwd with dq | dk | dv written as e4m3 + one E8M0 scale per (row, 32
+    columns).  Dequantised it must equal the 16-bit dqkv of the plain kernel up to the e4m3 rounding of each value (3 mantissa
+    bits: 1/16 relative, half a subnormal step of its block at the bottom); every scale is the smallest power of two that
+    brings its block's maximum under 448."""
+    g = torch.Generator().manual_seed(S + B)
+    H = heads * 64
+    qkv = bf(torch.randn(B * S, 3 * H, generator=g)).to(DEV)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.uint8)
+        for b in range(B):
+            mask[b, 20 + 3 * b: 20 + 3 * b + 7] = 0
+        mask = mask.to(DEV)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, S, device=DEV)
+    L.attn_fwd(qkv, ctx, lse, B, S, heads, key_mask=mask)
+    dctx = bf(torch.randn(B * S, H, generator=g) * 1e-3).to(DEV)
+    ref = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=DEV)
+    L.attn_bwd(qkv, ctx, lse, dctx, ref, B, S, heads, key_mask=mask)
+    dq8 = torch.full((B * S, 3 * H), 0x7F, dtype=torch.uint8, device=DEV)
+    sc = torch.zeros(B * S, 3 * H // 32, dtype=torch.uint8, device=DEV)
+    L.attn_bwd_fp8mx(qkv, ctx, lse, dctx, dq8, sc, B, S, heads, key_mask=mask)
+    scale = torch.exp2(sc.float() - 127.0)
+    deq = (dq8.view(torch.float8_e4m3fn).float().view(B * S, -1, 32) * scale[..., None]).view(B * S, 3 * H)
+    r32 = ref.float()
+    amax = r32.view(B * S, -1, 32).abs().amax(-1)
+    assert torch.isfinite(deq).all()
+    tol = r32.abs() / 16 + (amax * 1e-5)[..., None].expand(-1, -1, 32).reshape(B * S, 3 * H) + 1e-30
+    assert bool(((deq - r32).abs() <= tol).all()), float(((deq - r32).abs() / tol).max())
+    nz = amax > 0
+    assert bool((scale[nz] * 448.0 >= amax[nz] * 0.999).all()) and bool((scale[nz] * 448.0 < amax[nz] * 2.001).all())
+    # ... and it is the operand feddat_gemm_fp8mx_nt takes: QKV^T of the quantised gradient against the 16-bit product
+    W = (torch.randn(768, 3 * H, generator=g) * 0.05).to(DEV)
+    if B * S >= 1024 and 3 * H % 128 == 0:
+        W8, sw = torch.empty(768, 3 * H, dtype=torch.uint8, device=DEV), torch.empty(768, device=DEV)
+        L.quant_rows_fp8(W, W8, sw)
+        out = torch.empty(B * S, 768, dtype=torch.bfloat16, device=DEV)
+        L.gemm_fp8mx_nt(dq8, sc, W8, sw, out_bf16=out)
+        full = r32 @ W.t()
+        assert rel_err(out, deq @ _fp8_deq(W8, sw).t()) < 1e-2
+        print(f"QKV^T on MX e4m3 dqkv vs the 16-bit operands: rel err {rel_err(out, full):.4f}")
+        assert rel_err(out, full) < 0.08
+
+
 @pytest.mark.parametrize("R,V,ldl,with_teacher", [(96, 30522, 30592, True), (7, 1001, 1024, True), (5, 3072, 3072, False)])
 def test_lm_loss_fwd_bwd_vs_torch(L, R, V, ldl, with_teacher):
     """feddat_lm_loss_fwd_bwd against autograd on the reference's formula (albef_model.py:142-143: per-row weighted CE with
