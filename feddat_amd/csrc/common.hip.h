@@ -283,8 +283,9 @@ __device__ __forceinline__ f32x4 mfma16x128_fp8_mx(bf16x8 a_lo, bf16x8 a_hi, bf1
     const i32x8 B = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
-// the same with a real E8M0 block scale on the SECOND operand: lane l's `scale_b` (low byte) scales the 32 k-values lane l
-// supplies in (b_lo, b_hi) by 2^(byte - 127); the first operand keeps unit scales
+// the same with real E8M0 block scales on the SECOND operand: lane (r = l & 15, g = l >> 4) passes in `scale_b` (low byte) the
+// scale 2^(byte - 127) of the g-th 32-element k-block of row r (k = 32 g .. 32 g + 31, which lives in the first / last four
+// registers of lanes (r, 2 (g & 1)), (r, 2 (g & 1) + 1): tools/mx_scale_probe.py); the first operand keeps unit scales
 __device__ __forceinline__ f32x4 mfma16x128_fp8_mx_sb(bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi, f32x4 c, int scale_b) {
     const i32x4 a0 = __builtin_bit_cast(i32x4, a_lo), a1 = __builtin_bit_cast(i32x4, a_hi);
     const i32x4 b0 = __builtin_bit_cast(i32x4, b_lo), b1 = __builtin_bit_cast(i32x4, b_hi);

@@ -689,11 +689,13 @@ struct V2State {
 };
 
 // MXA (fp8, K = 128 MFMA only): A carries true MX block scales -- one E8M0 byte per (row, 32 consecutive k) in g.amx -- which the
-// block-scaled MFMA applies itself (its scale operand: every lane supplies the scale of the 32 k-values it supplies).  For that
-// a lane's two 16-byte fragment reads must be the two halves of ONE 32-byte block: chunks 2 fg, 2 fg + 1 of the 128-byte row
-// instead of fg, 4 + fg (A and B alike: the contraction only needs both to use the same slot map).  The scales of a k-tile
-// (4 bytes per row) ride the staging pipeline as one more piece per wave: a dword per row -> LDS [rows][4] per stage; the
-// consumer reads its byte (row of the row group, block fg) next to its fragments.
+// block-scaled MFMA applies itself.  Measured semantics of v_mfma_scale_f32_16x16x128_f8f6f4 (tools/mx_scale_probe.py): lane
+// (row r, group g) holds k = 16 g .. 16 g + 15 in its first four operand registers and k = 64 + 16 g .. in the last four --
+// exactly this kernel's fragment pair (16-byte chunks g and 4 + g of the 128-byte row) -- and the scale of block kb = k / 32 of
+// row r is taken from the scale register of lane (r, g = kb): the lane does NOT scale its own 32 values, it supplies the scale of
+// the kb-th 32-block of its row.  So the memory order of A is the hardware's k order, and lane (r, g) passes amx[r][4 kt + g].
+// The scales of a k-tile (4 bytes per row) ride the staging pipeline as one more piece per wave: a dword per row -> LDS
+// [rows][4] per stage; the consumer reads its byte next to its fragments.
 template <int EPI, int WM, bool FP8 = false, bool FP8_K32 = false, bool MXA = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
     using Cfg = V2Cfg<WM>;
@@ -792,8 +794,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v2_kernel(GemmArgsV2 a) {
 
     const int frow = lane & 15, fg = lane >> 4;
     // fragment read of row r (a multiple of 16 + frow), k-half ks: 16-byte chunk (4 ks + fg) ^ (frow & 7) of the row
-    const int frag_off[2] = {frow * 128 + (((MXA ? 2 * fg : fg) ^ (frow & 7)) << 4),
-                             frow * 128 + (((MXA ? 2 * fg + 1 : 4 + fg) ^ (frow & 7)) << 4)};
+    const int frag_off[2] = {frow * 128 + (((0 + fg) ^ (frow & 7)) << 4), frow * 128 + (((4 + fg) ^ (frow & 7)) << 4)};
     char* stg = smem + Cfg::EPI_OFF + wave * V2_EPI_WAVE;
     int kt = 0, c_tile = 0, st = 0;
     bool pend = false;                  // a finished tile whose epilogue has not run yet
