@@ -703,25 +703,29 @@ def main():
         extra_host = {} if host_ms is None else {
             "host_input_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()},
             "host_input_samples_per_sec": {k: round(B * 1e3 / v, 1) for k, v in host_ms.items()}}
+        if args.fp8:
+            n8 = "seven" if eng.fp8_mx_dqkv else "six"
+            workload = (
+                f"configs[4]: ViLT-B/32 FedDAT, fp8 (e4m3) MFMA for {n8} of the eight frozen products per layer (QKV, FFN1, FFN2 forward; "
+                "FFN2^T, FFN1^T, attention-output^T backward" +
+                ("; QKV^T on MX block-scaled e4m3 dqkv written by the attention backward" if eng.fp8_mx_dqkv else "") +
+                "), bf16 for the attention-output projection" + ("" if eng.fp8_mx_dqkv else " and QKV^T") +
+                " (measured and declined: profiles/r05_fp8_remaining_products.txt); measured parity of this configuration at its own "
+                "batch (tests/test_round40_gpu.py::test_b64_round_40_steps_vs_reference_golden, B=64, the reference's own 40-step "
+                "round): mean |ddW| / mean |dW| 0.16, update norm within 3.9 %, max |ddW| 2.95e-3 adapters / 3.9e-3 head (the default "
+                f"fp16-operand engine on the same round: 0.004, 0.2 %, 3.0e-4), batch={B}/client, ")
+        else:
+            workload = (f"configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, {'fp16' if eng.operands == 'f16' else 'bf16'} MFMA operands"
+                        f"{' (loss scale 2^14)' if eng.operands == 'f16' else ''}, fp32 accumulate / masters, batch={B}/client, ")
+        workload += "384x384 synthetic + 40-token questions, MKD on" + (
+            f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else "")
         out = {
             "metric": "VQA samples/sec, ViLT-B/32 dual-adapter local step", "value": round(sps, 2),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8(e4m3)+bf16" if args.fp8 else {"bf16": "bf16", "f16": "fp16"}[eng.operands],
             "data": "synthetic",
-            "config": {"workload": ("configs[4]: ViLT-B/32 FedDAT, fp8 (e4m3) MFMA for six of the eight frozen products per layer "
-                                    "(QKV, FFN1, FFN2 forward; FFN2^T, FFN1^T, attention-output^T backward), "
-                                    "bf16 for the attention-output projection and QKV^T (measured: profiles/r05_fp8_remaining_products.txt); measured "
-                                    "parity of this configuration at its own batch (tests/test_round40_gpu.py::test_b64_round_40_steps_"
-                                    "vs_reference_golden, B=64, the reference's own 40-step round): mean |ddW| / mean |dW| 0.16, update norm "
-                                    "within 3.9 %, max |ddW| 2.95e-3 adapters / 3.9e-3 head (the default fp16-operand engine on the same "
-                                    "round: 0.004, 0.2 %, 3.0e-4), "
-                                    f"batch={B}/client, " if args.fp8 else
-                                    f"configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, {'fp16' if eng.operands == 'f16' else 'bf16'} MFMA operands"
-                                    f"{' (loss scale 2^14)' if eng.operands == 'f16' else ''}, fp32 accumulate / masters, "
-                                    f"batch={B}/client, ") +
-                                   "384x384 synthetic + 40-token questions, MKD on"
-                                   + (f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else ""),
+            "config": {"workload": workload,
                        "batch_per_client": B, "seq_len": S, "clients": world, "hip_graph": use_graph,
                        "ranks": (dist.get_world_size() if dist is not None else 1), "hetero_steps": bool(args.hetero),
                        "hetero_label_prior": "Dirichlet(alpha=0.5) per client" if args.hetero else None,

@@ -327,8 +327,10 @@ def test_fused_tail_equals_the_single_purpose_launches(eng_mod):
         "task_layer.art.clf_fc1.weight"].to(DEV)).abs().max()) > 1e-5
 
 
-def test_fp8_forward_config4_stated_tolerances(eng_mod):
-    """BASELINE.json configs[4]: e4m3 MFMA for the forward QKV / FFN1 products and the dX products FFN2^T / attention-output^T
+@pytest.mark.parametrize("mx_dqkv", [True, False])
+def test_fp8_forward_config4_stated_tolerances(eng_mod, mx_dqkv):
+    """(mx_dqkv: the seven-product form -- QKV^T on MX block-scaled e4m3 dqkv from the attention backward -- and the six-product one.)
+    BASELINE.json configs[4]: e4m3 MFMA for the forward QKV / FFN1 products and the dX products FFN2^T / attention-output^T
     of the frozen backbone (per-row activation / gradient scales, per-channel weight scales), bf16 adapters.  e4m3 has 3 mantissa bits: the stated tolerances are LOOSER than the
     bf16 path's -- logits within 0.1 abs of the fp32 oracle (bf16 path: 3e-2; measured 0.043 vs 0.003), losses within 1 %
     (bf16: 0.2 %), and the adapter updates are compared with the bf16 engine's: mean |ddW| <= 0.3 mean |dW| and cosine > 0.9
@@ -337,7 +339,8 @@ def test_fp8_forward_config4_stated_tolerances(eng_mod):
     B, res = 8, 384                                        # 2R = 2960 rows: the fp8 products are really taken
     P = O.make_params(d, ["art"], bias_std=0.02)
     P0 = _clone(P)
-    e8 = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=B, res=res, layers=4, fp8=True)
+    e8 = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=B, res=res, layers=4, fp8=True, fp8_mx_dqkv=mx_dqkv)
+    assert e8.fp8_mx_dqkv == mx_dqkv and hasattr(e8, "dqkv8") == mx_dqkv
     e16 = eng_mod.ViltDatEngine(P, ["art"], DEV, batch=B, res=res, layers=4)
     b = O.synthetic_batch(B, res, 77)
     with torch.no_grad():
