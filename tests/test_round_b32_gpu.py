@@ -29,7 +29,8 @@ from tests.golden_util import load
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 SNAPS = (20, 40, 60, 80)
-ORACLE_STEPS = int(os.environ.get("FEDDAT_B32_ORACLE_STEPS", "40"))     # live-oracle prefix (CPU minutes on the GPU box)
+ORACLE_STEPS = int(os.environ.get("FEDDAT_B32_ORACLE_STEPS", "20"))     # live-oracle prefix (6 CPU-seconds per step on the GPU box;
+# 80 = the whole round: profiles/r05_round_b32_all_elements.txt holds that table)
 
 
 def _dev(b):
@@ -164,8 +165,8 @@ def test_north_star_bound_at_80_steps_every_format(b32_round, request):
 
 
 def test_b32_round_vs_live_oracle(b32_round):
-    """ALL elements (4.4 M), against the CPU oracle stepping the same batches (first ORACLE_STEPS steps of the round; 40 by default:
-    ~3 CPU-minutes on the GPU box -- FEDDAT_B32_ORACLE_STEPS=80 runs the whole round; tools/round_b32_all_elements.py prints the
+    """ALL elements (4.4 M), against the CPU oracle stepping the same batches (first ORACLE_STEPS steps of the round; 20 by default:
+    ~2 CPU-minutes on the GPU box -- FEDDAT_B32_ORACLE_STEPS=80 runs the whole round; tools/round_b32_all_elements.py prints the
     same table for several engine configurations); the oracle's own update at its last snapshot is pinned to the reference's
     samples first (< 1e-4: two fp32 implementations).  Measured, fp16 operands (profiles/r05_round_b32_all_elements.txt):
         steps                                   20        40        60        80
