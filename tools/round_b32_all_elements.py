@@ -2,7 +2,8 @@
 """The 80-step round at B = 32 on ALL elements: the CPU oracle steps the round once (snapshots after 20 / 40 / 60 / 80 steps; ~8
 minutes on the GPU box's host cores), then each engine configuration replays the same batches (10 s each) and is compared on
 every element of every trainable tensor -- max |ddW|, the number of elements off by more than 1e-3 / 5e-4, mean ratio.
-    python tools/round_b32_all_elements.py f16 f16:codes=0 bf16"""
+    python tools/round_b32_all_elements.py f16 f16:codes=0 bf16
+    FEDDAT_ROUND_SEED0=9000 python tools/round_b32_all_elements.py f16 bf16      # the same on other batches (default 8000 = the fixture's)"""
 import os
 import sys
 
@@ -22,7 +23,9 @@ def main():
     P = O.make_params(d, ["art"], bias_std=0.02)
     P0 = {k: v.clone() for k, v in P.items()}
     names = [k for k in P if ("adapter_0" in k or "adapter_1" in k or k.startswith("task_layer.art."))]
-    host = [O.synthetic_batch(32, 384, 8000 + s) for s in range(80)]
+    seed0 = int(os.environ.get("FEDDAT_ROUND_SEED0", "8000"))
+    print("batches", seed0, "..", seed0 + 79)
+    host = [O.synthetic_batch(32, 384, seed0 + s) for s in range(80)]
     torch.set_num_threads(min(torch.get_num_threads(), 32))
     client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=80)
     ref = {}
