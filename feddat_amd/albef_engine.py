@@ -167,7 +167,8 @@ class AlbefDatEngine:
         # [M, 2M) adapter_1 -- the ViLT engine's 2R-row batching; adapters, weight gradients and the two losses take
         # two-segment descriptors): 366 -> 183 text-side GEMM launches per step, results equal to the two-pass form
         # (tests/test_albef_gpu.py::test_stacked_text_towers_equal_the_two_separate_passes).  Under hipGraph replay it LOSES:
-        # 34.6 against 32.6 ms / step at B = 32 (same box, tools/albef_stack_ab.py) -- the two passes' small kernels already
+        # 34.6 against 32.6 ms / step at B = 32 in round 4, 31.2 against 30.4 in round 5 once its 1600-row products left the
+        # persistent GEMM kernels (36 tiles = 36 CUs) for the small-tile one (same box, tools/albef_stack_ab.py) -- the two passes' small kernels already
         # overlap each other on two streams, and a stacked launch of twice the rows costs more than one of the pair.  It
         # stays as a switch because it halves the host launches of the eager (no-graph) step.
         self.batch_text = bool(stack_text) and self.dropout <= 0

@@ -1569,8 +1569,19 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
                                    float* out_f32, int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2,
                                    hipStream_t stream) {
     FD_CHECK_ARG(A && B && M > 0 && N > 0 && K > 0);
-    const bool use_v2 = (N % V2_BN == 0) && (K % BK == 0) && (M >= 1024);
-    FD_CHECK_ARG((N % BN == 0 || use_v2 || (M < 1024 && N % 64 == 0)) && K % BK == 0);
+    bool use_v2 = (N % V2_BN == 0) && (K % BK == 0) && (M >= 1024);
+    // Medium M (ALBEF's stacked text streams: 2 x 800 rows): the persistent kernels would put 1600 x 768 on 9 x 4 = 36 tiles, i.e.
+    // 36 of the 256 CUs; the small-tile kernel fills the chip with 64 x 64 tiles (same k order: bit-identical results).  Taken
+    // when a launch has fewer 192-row tiles than 0.6 x the CUs; not for the gelu' code epilogues (persistent kernels only);
+    // debug flag 1 (everything on the two-group persistent kernel) keeps the old routing (A/B: tools/albef_stack_ab.py).
+    bool small_grid = false;
+    if (use_v2 && M < 4096 && epi != FEDDAT_EPI_GELU_G8 && epi != FEDDAT_EPI_MUL_G8 && !(fd_debug_flags() & 1)) {
+        int n_cu = 0;
+        if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+        small_grid = ((M + 191) / 192) * (N / V2_BN) * 10 < n_cu * 6;
+        if (small_grid) use_v2 = false;
+    }
+    FD_CHECK_ARG((N % BN == 0 || use_v2 || ((M < 1024 || small_grid) && N % 64 == 0)) && K % BK == 0);
     FD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K);
     switch (epi) {
         case FEDDAT_EPI_BF16: FD_CHECK_ARG(out_bf16 && ldo16 % 4 == 0); break;
@@ -1689,7 +1700,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     }
     // few rows and too few 128 x 128 tiles to fill the chip: the latency-oriented small-tile kernel
     const bool v1_ok = N % BN == 0;
-    if (M < 1024 && N % 64 == 0 && (!v1_ok || ((M + BM - 1) / BM) * (N / BN) < 150) && !(fd_debug_flags() & 128)) {
+    if ((M < 1024 || small_grid) && N % 64 == 0 && (!v1_ok || ((M + BM - 1) / BM) * (N / BN) < 150) && !(fd_debug_flags() & 128)) {
         const int tm = (M + 63) / 64;
         if (fd_set_max_lds((const void*)gemm_nt_mid_kernel, MID_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
         hipLaunchKernelGGL(gemm_nt_mid_kernel, dim3(tm * (N / 64)), dim3(256), MID_LDS, stream, g);
