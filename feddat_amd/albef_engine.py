@@ -31,7 +31,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import lib as L
-from .engine import FlatGroup
+from .engine import FlatGroup, _bound
 
 PRE = "albef_model.albef."
 ADAPTER_TENSORS = ("down.weight", "down.bias", "up.weight", "up.bias")
@@ -41,7 +41,23 @@ class AlbefDatEngine:
     def __init__(self, params: Dict[str, torch.Tensor], device, batch: int, n_answers: int, q_len: int = 25, a_len: int = 4,
                  vit_depth: int = 12, enc_layers: int = 12, fusion_layer: int = 6, dec_layers: int = 6, image: int = 384,
                  vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0,
-                 max_pos: int = 512, dropout: float = 0.0, seed: int = 0, stack_text: bool = False):
+                 max_pos: int = 512, dropout: float = 0.0, seed: int = 0, stack_text: bool = False,
+                 operands: str = "bf16", loss_scale: Optional[float] = None):
+        """operands="f16": every 16-bit MFMA operand in IEEE half (libfeddat_hip_f16.so) with a power-of-two loss scale on
+        dL/dlogits (feddat_lm_loss_fwd_bwd's grad_scale, default 2^14) that leaves through feddat_wgrad_seg.grad_unscale -- the
+        ViLT engine's scheme (engine.ViltDatEngine); the default here stays bf16."""
+        if operands not in L.OPERAND_DTYPE:
+            raise L.FeddatHipError(f"operands must be 'bf16' or 'f16', got {operands!r}")
+        self.operands, self.op_dtype = operands, L.OPERAND_DTYPE[operands]
+        self.loss_scale = float(loss_scale if loss_scale is not None else (16384.0 if operands == "f16" else 1.0))
+        if self.loss_scale <= 0 or math.frexp(self.loss_scale)[0] != 0.5:
+            raise L.FeddatHipError("loss_scale must be a power of two (it is removed exactly)")
+        with L.operands(operands):
+            self._init(params, device, batch, n_answers, q_len, a_len, vit_depth, enc_layers, fusion_layer, dec_layers, image, vocab,
+                       lr, weight_decay, adam_eps, pad_id, max_pos, dropout, seed, stack_text)
+
+    def _init(self, params, device, batch, n_answers, q_len, a_len, vit_depth, enc_layers, fusion_layer, dec_layers, image, vocab, lr,
+              weight_decay, adam_eps, pad_id, max_pos, dropout, seed, stack_text):
         L.load()
         if not 0.0 <= dropout < 1.0:
             raise L.FeddatHipError("dropout must be in [0, 1)")
@@ -63,12 +79,12 @@ class AlbefDatEngine:
             return params[PRE + name].to(dev, torch.float32).contiguous()
 
         def bf16_of(w):
-            out = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(w.shape, dtype=self.op_dtype, device=dev)
             L.cvt_f32_bf16(w.contiguous(), out)
             return out
 
         def bf16_T(w):
-            out = torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev)
+            out = torch.empty(w.shape[1], w.shape[0], dtype=self.op_dtype, device=dev)
             L.transpose_f32_bf16(w.contiguous(), out, w.shape[0], w.shape[1])
             return out
 
@@ -150,7 +166,7 @@ class AlbefDatEngine:
                 grp.view(n).copy_(params[n].to(dev, torch.float32))
         self.ad_numel = self.r * H + self.r + H * self.r + H
         nm = len(self.modules)
-        self._pack16 = [torch.empty(nm, 4, self.r * H, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+        self._pack16 = [torch.empty(nm, 4, self.r * H, dtype=self.op_dtype, device=dev) for _ in range(3)]
         for a in range(3):
             self.repack_adapter(a)
         self.sched = dict(warmup=1, total=2)
@@ -189,7 +205,7 @@ class AlbefDatEngine:
             return torch.empty(*s, device=dev)
 
         def b16(*s):
-            return torch.empty(*s, dtype=torch.bfloat16, device=dev)
+            return torch.empty(*s, dtype=self.op_dtype, device=dev)
         B, N, Lq, La = self.B, self.N, self.Lq, self.La
         self.inp = dict(image=f32(B, 3, self.img, self.img), question_ids=torch.zeros(B, Lq, dtype=torch.int64, device=dev),
                         question_mask=torch.ones(B, Lq, dtype=torch.int64, device=dev),
@@ -301,6 +317,7 @@ class AlbefDatEngine:
                     bd=self.ad[a].view(base + "down.bias"), bu=self.ad[a].view(base + "up.bias"),
                     wd32=self.ad[a].view(base + "down.weight"), wu32=self.ad[a].view(base + "up.weight"))
 
+    @_bound
     def repack_adapter(self, a: int):
         p0 = self._pack(a, 0)
         L.adapter_pack_strided(p0["wd32"], p0["wu32"], self.ad_numel, p0["wd"], p0["wdT"], p0["wu"], p0["wuT"],
@@ -328,8 +345,10 @@ class AlbefDatEngine:
             if key not in self._segs_cache:
                 n, h, g = self.ad_numel, rows // 2, self.gs["both"]
                 self._segs_cache[key] = L.make_wgrad_segs([
-                    dict(x=x, dy=dy, z=g["z"], dz=g["dz"], grad=self.ad[0].g[m * n:(m + 1) * n], rows=h, scale=0.5),
-                    dict(x=x[h:], dy=dy[h:], z=g["z"][h:], dz=g["dz"][h:], grad=self.ad[1].g[m * n:(m + 1) * n], rows=h, scale=1.0)])
+                    dict(x=x, dy=dy, z=g["z"], dz=g["dz"], grad=self.ad[0].g[m * n:(m + 1) * n], rows=h, scale=0.5,
+                         grad_unscale=1.0 / self.loss_scale),
+                    dict(x=x[h:], dy=dy[h:], z=g["z"][h:], dz=g["dz"][h:], grad=self.ad[1].g[m * n:(m + 1) * n], rows=h, scale=1.0,
+                         grad_unscale=1.0 / self.loss_scale)])
             ws = self.wpart_stride2
             L.adapter_wgrad_partial(self._segs_cache[key], self.wpart["both"][m * ws:(m + 1) * ws])
             self._wg_done["both"].append(m)
@@ -342,7 +361,8 @@ class AlbefDatEngine:
             n = self.ad_numel
             self._segs_cache[key] = L.make_wgrad_segs([dict(x=x, dy=dy, z=self.gs[mode]["z"], dz=self.gs[mode]["dz"],
                                                             grad=self.ad[a].g[m * n:(m + 1) * n], rows=rows,
-                                                            scale=0.5 if mode == "gating" else 1.0)])
+                                                            scale=0.5 if mode == "gating" else 1.0,
+                                                            grad_unscale=1.0 / self.loss_scale)])
         ws = self.wpart_stride
         L.adapter_wgrad_partial(self._segs_cache[key], self.wpart[mode][m * ws:(m + 1) * ws])
         self._wg_done[mode].append(m)
@@ -379,6 +399,7 @@ class AlbefDatEngine:
             for j, m in enumerate(ms):
                 L.adapter_wgrad_reduce(ptrs[j:j + 1], 1, 1, self.wpart[mode][m * ws:], ws)
 
+    @_bound
     def copy_global_to_teacher(self):
         self.ad[2].p.copy_(self.ad[1].p)
         self.repack_adapter(2)
@@ -398,6 +419,7 @@ class AlbefDatEngine:
         return self._segs_cache[key]
 
     # ------------------------------------------------------------------------------------------ inputs
+    @_bound
     def set_batch(self, batch: Dict):
         """Reference batch after tokenisation (albef.py:52-60): image [B,3,R,R] f32; question_ids / question_mask [B, lq];
         answer_ids / answer_mask [n, la]; weights [n]; k = answers per question (host list, sum = n).
@@ -709,10 +731,10 @@ class AlbefDatEngine:
             for half, own in ((0, "gating"), (1, "adapter_1")):
                 L.lm_loss_fwd_bwd(lg[half * R1:(half + 1) * R1], lg[(1 - half) * R1:(2 - half) * R1], self.labels, self.row_w, self.V,
                                   3.0, 9.0 / self.N, g["dlogits"][half * R1:(half + 1) * R1], self.acts[own]["loss"],
-                                  row_kl=self.row_kl)
+                                  row_kl=self.row_kl, grad_scale=self.loss_scale)
         else:
             L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
-                              S["loss"], row_kl=self.row_kl)
+                              S["loss"], row_kl=self.row_kl, grad_scale=self.loss_scale)
         # LM head backward (frozen): logits = LN(gelu(dense(h))) W_emb^T
         L.gemm_bf16_nt(g["dlogits"], hd["wT"], L.EPI_BF16, out_bf16=g["b1"][:R])
         L.layernorm_bwd_dx(S["tg"], S["tst"], hd["lng"], R, H, dy_bf16=g["b1"][:R], out_f32=g["d1"][:R])
@@ -729,6 +751,7 @@ class AlbefDatEngine:
                        self.Ni, self.Ni, None, g["d_qs"], g["d_img"], pass_id, 0)
 
     # ------------------------------------------------------------------------------------------ train step
+    @_bound
     def begin_local_update(self, steps_per_epoch: int, num_epochs: int = 15, warmup_ratio: float = 0.1,
                            opt_adapters: Sequence[int] = (0, 1), dropout_epoch: int = 0):
         """TaskTrainer.train prologue (task_trainer.py:36-59): teacher snapshot, fresh AdamW state and schedule.
@@ -749,7 +772,8 @@ class AlbefDatEngine:
         self.drop_ctr.copy_(torch.tensor([(int(dropout_epoch) << 16) & 0x7FFFFFFF, 0], dtype=torch.int32))
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
-        sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.dropout, self.batch_text)
+        sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.dropout, self.batch_text,
+               self.operands, self.loss_scale)
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig
@@ -760,6 +784,7 @@ class AlbefDatEngine:
         L.adamw_flat(grp.p, grp.g, grp.m, grp.v, grp.seg_off, grp._wdv, grp.state, self.lr, self.sched["warmup"],
                      self.sched["total"], 0.9, 0.98, self.eps)
 
+    @_bound
     def _step_kernels(self):
         # The two passes are independent up to the loss and from the loss down to their adapters, so they run side by
         # side on two streams (separate activation, scratch and weight-gradient workspaces per pass; inside a captured
@@ -832,6 +857,7 @@ class AlbefDatEngine:
         if drop:
             L.step_tick(self.drop_ctr, 1, 0)                 # the next train_step draws fresh masks (also under graph replay)
 
+    @_bound
     def train_step(self, batch: Optional[Dict] = None, use_graph: bool = False):
         """One DAT + MKD step; returns the device buffer {loss_0, kl_0, L_0} of the P2 pass (the reference returns loss_0).
         use_graph: replay the ~3000 launches of a step as one hipGraph (the BERT towers' launches are tiny: eager mode is
@@ -846,6 +872,7 @@ class AlbefDatEngine:
             self.graph.replay()
         return self.acts["gating"]["loss"]
 
+    @_bound
     def _capture(self):
         """Capture the whole step into one hipGraph (static buffers; schedule and Adam counters live on the device); the
         optimizer state is saved / restored around the warm-up + capture run so that capturing does not advance training."""
@@ -874,6 +901,7 @@ class AlbefDatEngine:
         self.graph = graph
 
     # ------------------------------------------------------------------------------------------ inference
+    @_bound
     @torch.no_grad()
     def forward_train_logits(self, batch: Dict, mode: str):
         """-> (loss, logits [N, La-1, V]) of ALBEF.forward(train=True) in adapter mode `mode` ('gating' | 'adapter_k')."""
@@ -890,6 +918,7 @@ class AlbefDatEngine:
         _, n, la = self._k             # the batch's own answer count / length inside the engine's frame
         return S["loss"][0].clone(), logits[:, :self.V].reshape(self.N, self.La - 1, self.V)[:n, :la - 1].clone()
 
+    @_bound
     @torch.no_grad()
     def rank_answer(self, batch: Dict, answer_ids: torch.Tensor, answer_mask: torch.Tensor, k: int, mode: str = "gating"):
         """ALBEF.forward(train=False) -> rank_answer (albef_model.py:147-156,171-228; eval loop task_trainer.py:159-204):
@@ -931,6 +960,7 @@ class AlbefDatEngine:
         probs, rerank = L.topk_rows(topk_probs, k, minus=answer_loss.view(B, k).contiguous(), log_first=True, softmax=True)
         return torch.gather(topk_ids, 1, rerank), probs
 
+    @_bound
     def image_embeds(self, mode_key: str = "gating"):
         """fp32 image_embeds of the last forward in that activation set (final-norm output recomputed from its input)."""
         V = self.acts[mode_key]["vit"]
@@ -942,6 +972,7 @@ class AlbefDatEngine:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {n: grp.view(n) for grp in self.ad for n in grp.names}
 
+    @_bound
     def load_tensors(self, tensors: Dict[str, torch.Tensor]):
         sd = self.state_dict()
         touched = set()

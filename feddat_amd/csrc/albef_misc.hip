@@ -113,7 +113,7 @@ __global__ __launch_bounds__(LM_NT) void lm_loss_kernel(const float* __restrict_
                                                         long ldl, const long* __restrict__ labels,
                                                         const float* __restrict__ row_w, const float* __restrict__ row_kl,
                                                         int V, float T, float kl_scale, bf16* __restrict__ dlogits, long ldd,
-                                                        float* __restrict__ row_terms) {
+                                                        float* __restrict__ row_terms, const float grad_scale) {
     __shared__ float red[LM_NT / 64];
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* l = logits + (size_t)r * ldl;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(LM_NT) void lm_loss_kernel(const float* __restrict_
         const float d = lv - m1;
         float gv = w * (__expf(d) * i1 - (v == lab ? 1.f : 0.f));
         if (t) gv += ks * (__expf(d * invT) * ip - __expf((tv - mt) * invT) * iq);
-        return 0.5f * gv;
+        return (0.5f * grad_scale) * gv;      // grad_scale: the caller's power-of-two loss scale (fp16 operand build), else 1
     };
     for (int v = 4 * tid; v < V4; v += 4 * LM_NT) {          // (ldd % 4 == 0 and dlogits 8-byte aligned: launcher)
         const f32x4 lv = *reinterpret_cast<const f32x4*>(l + v);
@@ -357,14 +357,14 @@ extern "C" int feddat_segment_sum_rows(const float* src, const int* seg_offsets,
 
 extern "C" int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
                                       const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale,
-                                      void* dlogits_bf16, long ldd, float* scalars, hipStream_t stream) {
-    FD_CHECK_ARG(logits && labels && row_weight && scalars && R > 0 && V > 0 && ldl >= V && temp > 0.f);
+                                      float grad_scale, void* dlogits_bf16, long ldd, float* scalars, hipStream_t stream) {
+    FD_CHECK_ARG(logits && labels && row_weight && scalars && R > 0 && V > 0 && ldl >= V && temp > 0.f && grad_scale > 0.f);
     FD_CHECK_ARG(!dlogits_bf16 || ldd >= V);
     float* row_terms = scalars + 4;       // scalars: 4 + 2 R floats
     FD_CHECK_ARG(ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0 && (!teacher || ((uintptr_t)teacher & 15) == 0));
     FD_CHECK_ARG(!dlogits_bf16 || (ldd % 4 == 0 && ((uintptr_t)dlogits_bf16 & 7) == 0));
     hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(LM_NT), 0, stream, logits, teacher, ldl, labels, row_weight, row_kl, V, temp,
-                       kl_scale, (bf16*)dlogits_bf16, ldd, row_terms);
+                       kl_scale, (bf16*)dlogits_bf16, ldd, row_terms, grad_scale);
     hipLaunchKernelGGL(lm_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, R, kl_scale, scalars);
     FD_LAUNCH_RET();
 }

@@ -461,9 +461,10 @@ int feddat_vqa_score_accumulate(const float* logits, const float* target, int B,
  * kl_scale = temp^2 / N (N answers); row_kl (optional fp32 [R], NULL = all ones) multiplies a row's KL term and its gradient --
  * 0 for rows that exist only because a batch was padded to a static frame (the reference pads to the longest of the batch:
  * albef.py:56-57), N_frame / n_batch elsewhere.  dlogits_bf16 [R, ldd] (may be NULL) gets zeros in columns [V, ldd) so that it can be
- * the K-padded operand of the LM-head backward GEMM.  scalars: 4 + 2 R floats; [0] = loss, [1] = kl, [2] = L. */
+ * the K-padded operand of the LM-head backward GEMM.  scalars: 4 + 2 R floats; [0] = loss, [1] = kl, [2] = L.  * grad_scale (ABI 7): factor on dL/dlogits only (the losses in `scalars` are unscaled): the power-of-two loss scale of a
+ * caller that runs the backward in the fp16 operand build (1 otherwise); it leaves through feddat_wgrad_seg.grad_unscale. */
 int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
-                           const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale,
+                           const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale, float grad_scale,
                            void* dlogits_bf16, long ldd, float* scalars, hipStream_t stream);
 /* ALBEF.rank_answer's selections (src/modeling/models/albef_model.py:171-228; eval loop task_trainer.py:159-204).
  * feddat_softmax_gather_rows: out[r, j] = softmax(logits[r * row_stride + 0 .. V))[ids[j * id_stride]]  -- the probability of
