@@ -305,7 +305,7 @@ def build_parser() -> argparse.ArgumentParser:
                    help="ALBEF only: override depths for quick runs, e.g. vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2")
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
     p.add_argument("--mixed_precision", default="fp16", choices=["fp16", "bf16"],
-                   help="16-bit MFMA operand format of the ViLT engine, named like accelerate's setting: fp16 (the reference's "
+                   help="16-bit MFMA operand format of the ViLT / ALBEF engine, named like accelerate's setting: fp16 (the reference's "
                         "accelerate_config.yaml:8; static 2^14 loss scale) or bf16")
     p.add_argument("--exchange", default="rccl_cabi", choices=["rccl_cabi", "torch"],
                    help="the round's FedAvg collective: rccl_cabi = feddat_fedavg_allreduce on a communicator made through "
@@ -377,7 +377,8 @@ def main(argv=None):
             params = albef_spec.random_init(seed=args.seed, image=args.image_size, **dims)
         model = create_albef_continual_learner_model(params, dev, args.batch_size, args.batch_size, lr=args.lr,
                                                      image=args.image_size, dropout=args.albef_dropout,
-                                                     seed=args.seed + 7919 * rank, **dims)
+                                                     seed=args.seed + 7919 * rank,
+                                                     operands={"fp16": "f16", "bf16": "bf16"}[args.mixed_precision], **dims)
         Trainer = AlbefTaskTrainer
     else:
         if pretrained:       # load_vilt_encoder (vilt.py:387-420): HF directory / state dict + modality-embedding expansion

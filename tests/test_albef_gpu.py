@@ -50,14 +50,17 @@ def test_small_forward_three_modes_vs_reference_and_oracle(eng_mod, golden_dir):
     assert (img.cpu() - torch.from_numpy(g["fwd.gating.image_embeds"])).abs().max() < 5e-2
 
 
-def test_small_train_steps_vs_reference_and_oracle(eng_mod, golden_dir):
-    """4 train_steps on every code path (ragged questions / answers, k = [2, 1, 3], weights != 1): losses and the update of
+@pytest.mark.parametrize("operands", ["bf16", "f16"])
+def test_small_train_steps_vs_reference_and_oracle(eng_mod, golden_dir, operands):
+    """(operands: the bf16 build, and the fp16 build with its 2^14 loss scale on dL/dlogits -- round 5.)
+    4 train_steps on every code path (ragged questions / answers, k = [2, 1, 3], weights != 1): losses and the update of
     every adapter_0 / adapter_1 tensor of the three towers, against the reference's run (G10) and the oracle."""
     g = load(golden_dir, "g10_albef_small.npz")
     d = A.AlbefDims(**SMALL)
     P = A.make_params(d)
     P0 = {k: v.clone() for k, v in P.items()}
-    eng = _small_engine(eng_mod, P, 3, 6, 12, 5)
+    eng = _small_engine(eng_mod, P, 3, 6, 12, 5, operands=operands)
+    assert eng.op_dtype == {"bf16": torch.bfloat16, "f16": torch.float16}[operands]
     client = A.AlbefDatClient(P, d, lr=1e-4, steps_per_epoch=4)
     eng.begin_local_update(steps_per_epoch=4)
     for s in range(4):
@@ -86,11 +89,14 @@ def test_small_train_steps_vs_reference_and_oracle(eng_mod, golden_dir):
     for k in sd:
         if "adapter_2" in k:
             assert torch.equal(sd[k].cpu(), P[k]), k           # frozen teacher = adapter_1 at the start of the round
-    print(f"ALBEF small, 4 steps: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f}")
+    print(f"ALBEF small, 4 steps, {operands} operands: worst max |ddW| {worst_max:.2e}, worst mean ratio {worst_ratio:.3f}")
+    if operands == "f16":
+        assert worst_ratio < 0.02, worst_ratio            # several times tighter than the bf16 build (0.039)
 
 
-def test_round_of_40_steps_vs_reference_golden(eng_mod, golden_dir):
-    """north-star at round length for the ALBEF path: 40 train_steps (hipGraph replay; schedule past its warm-up) of the
+@pytest.mark.parametrize("operands", ["bf16", "f16"])
+def test_round_of_40_steps_vs_reference_golden(eng_mod, golden_dir, operands):
+    """(both operand formats.)  north-star at round length for the ALBEF path: 40 train_steps (hipGraph replay; schedule past its warm-up) of the
     small configuration against the reference's own run (G11): loss trajectory, and per adapter_0 / adapter_1 tensor of the
     three towers |ddW|.max < 1e-3, |ddW|.mean <= 0.1 |dW_ref|.mean, update norm within 5 %."""
     g = load(golden_dir, "g11_albef_round40.npz")
@@ -98,7 +104,7 @@ def test_round_of_40_steps_vs_reference_golden(eng_mod, golden_dir):
     d = A.AlbefDims(**SMALL)
     P = A.make_params(d)
     P0 = {k: v.clone() for k, v in P.items()}
-    eng = _small_engine(eng_mod, P, 3, 6, 12, 5)
+    eng = _small_engine(eng_mod, P, 3, 6, 12, 5, operands=operands)
     eng.begin_local_update(steps_per_epoch=steps, num_epochs=1)
     worst_loss = 0.0
     for s in range(steps):
@@ -122,7 +128,7 @@ def test_round_of_40_steps_vs_reference_golden(eng_mod, golden_dir):
         assert nerr < 0.05, (k, nerr)
         worst_max, worst_ratio = max(worst_max, float(err.max())), max(worst_ratio, float(err.mean()) / move)
         worst_norm = max(worst_norm, nerr)
-    print(f"ALBEF small, {steps} steps vs reference: worst max |ddW| {worst_max:.2e}, mean ratio {worst_ratio:.3f}, "
+    print(f"ALBEF small, {steps} steps vs reference, {operands} operands: worst max |ddW| {worst_max:.2e}, mean ratio {worst_ratio:.3f}, "
           f"norm error {worst_norm:.3f}, loss trajectory within {worst_loss:.2e}")
 
 

@@ -114,3 +114,13 @@ def test_bench_albef_flop_count():
     assert 0.80 < 5 * vit_fwd / ref < 0.95             # 3 fwd + ~2 bwd of the ViT against everything
     assert 0.75 < exe / ref < 0.82
     assert 6.0e11 < ref < 6.8e11
+
+
+def test_bench_help_renders():
+    """argparse interpolates '%' in help strings: `bench.py --help` must not raise (it did in round 4)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--operands" in r.stdout, r.stderr[-500:]

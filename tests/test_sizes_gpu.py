@@ -106,7 +106,7 @@ def test_fp8_b64_12_layers_vs_oracle(engine):
           f"cosine {worst_cos:.3f}")
 
 
-def _albef_full_size_vs_oracle(B, steps, seed0, graph_from, max_bound=1e-3, ratio_bound=0.15, what=""):
+def _albef_full_size_vs_oracle(B, steps, seed0, graph_from, max_bound=1e-3, ratio_bound=0.15, what="", operands="bf16"):
     """configs[3]'s real architecture: `steps` train_steps of an AlbefDatEngine at batch B next to the oracle stepping the same
     batches (the round's own schedule: steps_per_epoch = steps); losses every step, updates of every trainable tensor at the end."""
     if not torch.cuda.is_available():
@@ -115,7 +115,7 @@ def _albef_full_size_vs_oracle(B, steps, seed0, graph_from, max_bound=1e-3, rati
     d = A.AlbefDims()
     P = A.make_params(d)
     P0 = {k: v.clone() for k, v in P.items()}
-    eng = albef_engine.AlbefDatEngine(P, DEV, batch=B, n_answers=B)
+    eng = albef_engine.AlbefDatEngine(P, DEV, batch=B, n_answers=B, operands=operands)
     client = A.AlbefDatClient(P, d, lr=1e-4, steps_per_epoch=steps)
     eng.begin_local_update(steps_per_epoch=steps)
     torch.set_num_threads(min(torch.get_num_threads(), 64))
@@ -140,10 +140,13 @@ def _albef_full_size_vs_oracle(B, steps, seed0, graph_from, max_bound=1e-3, rati
     return worst_max, worst_ratio, moved
 
 
-def test_albef_full_size_b8_four_steps_vs_oracle():
-    """ViT-B/16 (577 tokens) + BERT-base 12 + 6 layers + 30 522-way head at B = 8 (4 616-row image GEMMs: the large-M tile
+@pytest.mark.parametrize("operands", ["bf16", "f16"])
+def test_albef_full_size_b8_four_steps_vs_oracle(operands):
+    """(both operand formats; fp16 = the fp16 library + 2^14 loss scale through feddat_lm_loss_fwd_bwd's grad_scale.)  ViT-B/16 (577 tokens) + BERT-base 12 + 6 layers + 30 522-way head at B = 8 (4 616-row image GEMMs: the large-M tile
     plans, not the few-row kernel a B = 2 test exercises), 4 train_steps (eager, then hipGraph replay)."""
-    _albef_full_size_vs_oracle(8, 4, 880, graph_from=2)
+    mx, ratio, _ = _albef_full_size_vs_oracle(8, 4, 880, graph_from=2, operands=operands, what=f"({operands} operands) ")
+    if operands == "f16":
+        assert ratio < 0.03, ratio
 
 
 def test_albef_bench_size_b32_two_steps_vs_oracle():
