@@ -186,6 +186,7 @@ class AlbefTaskTrainer(TaskTrainer):
                 if self.args.debug > 0 and step > self.args.debug:
                     break
                 self.train_step(model, step, batch, optimizer, None, hooks=None, epoch=epoch)
+        eng.assert_finite()
         return 0.0, model
 
     def train_step(self, model, step, batch, optimizer=None, scheduler=None, hooks=None, epoch=None):
