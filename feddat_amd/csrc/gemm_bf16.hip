@@ -1419,8 +1419,8 @@ static const V2Kernel (*v2_kernel_table())[7] {
     return kernels;
 }
 
-static const V2Kernel (*v3_kernel_table())[5] {        // [0]: 192-row tiles (RT = 6), [1]: 256 (RT = 8), [2]: 160 (RT = 5), [3]: 224 (RT = 7), [4]: 128 (RT = 4)
-    static const V2Kernel kernels[5][5] = {
+static const V2Kernel (*v3_kernel_table())[5] {        // [0]: 192-row tiles (RT = 6), [1]: 256 (RT = 8), [2]: 160 (RT = 5), [3]: 224 (RT = 7)
+    static const V2Kernel kernels[4][5] = {
         {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 6>,
          gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 6>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 6>},
         {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 8>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 8>,
@@ -1428,17 +1428,15 @@ static const V2Kernel (*v3_kernel_table())[5] {        // [0]: 192-row tiles (RT
         {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 5>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 5>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 5>,
          gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 5>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 5>},
         {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 7>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 7>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 7>,
-         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 7>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 7>},
-        {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 4>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 4>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 4>,
-         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 4>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 4>}};
+         gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 7>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 7>}};
     return kernels;
 }
 static int v3_lds(int which) {
-    return which == 1 ? V3Cfg<8>::LDS : which == 2 ? V3Cfg<5>::LDS : which == 3 ? V3Cfg<7>::LDS : which == 4 ? V3Cfg<4>::LDS : V3Cfg<6>::LDS;
+    return which == 1 ? V3Cfg<8>::LDS : which == 2 ? V3Cfg<5>::LDS : which == 3 ? V3Cfg<7>::LDS : V3Cfg<6>::LDS;
 }
 
 int fd_prepare_gemm_kernels() {
-    for (int w = 0; w < 5; ++w)
+    for (int w = 0; w < 4; ++w)
         for (int e = 0; e < 5; ++e)
             if (fd_set_max_lds((const void*)v3_kernel_table()[w][e], v3_lds(w)) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     for (int w = 0; w < 2; ++w)
@@ -1644,9 +1642,8 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             o.tn_per = tiles_n / o.nx;
             return (o.tiles_m * tiles_n + n_cu - 1) / n_cu;     // rounds of the persistent grid
         };
-        GemmArgsV2 a3 = a2, a4 = a2, a5 = a2, a7 = a2, a128 = a2;
-        const int rounds3 = plan(192, a3), rounds4 = plan(256, a4), rounds5 = plan(160, a5), rounds7 = plan(224, a7),
-                  rounds128 = plan(128, a128);
+        GemmArgsV2 a3 = a2, a4 = a2, a5 = a2, a7 = a2;
+        const int rounds3 = plan(192, a3), rounds4 = plan(256, a4), rounds5 = plan(160, a5), rounds7 = plan(224, a7);
         // a 256-row tile costs about 1.2x a 192-row tile (48 vs 36 MFMAs per k-tile and wave, L phase 20 vs 18 reads)
         bool wm4 = rounds4 * 12 < rounds3 * 10;
         if (epi == FEDDAT_EPI_MUL_DGELU) wm4 = false;      // its 256-row instantiation spills (180 B of scratch per lane and tile)
@@ -1681,15 +1678,11 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             // 224-row tiles
             const int cost68 = rt8 ? rounds4 * 120 : rounds3 * 100;
             const bool odd_ok = !(dbg & (32 | 64 | (1 << 27)));
-            // 128-row tiles (RT = 4, ~0.78 of a 192-row tile's time): launches that are ONE partial round of the larger tiles --
-            // layer 0's 5 920 x 768 products (124 tiles of 192 rows / 148 of 160 on 256 CUs -> 188 of 128), the 4 608-row patch
-            // embedding -- finish with the tile, so the smaller tile is the shorter launch
-            const bool rt4 = odd_ok && rounds128 * 78 < cost68 && rounds128 * 78 < rounds5 * 87 && rounds128 * 78 < rounds7 * 110;
-            const bool rt5 = odd_ok && !rt4 && rounds5 * 87 < cost68 && rounds5 * 87 <= rounds7 * 110;
-            const bool rt7 = odd_ok && !rt4 && !rt5 && rounds7 * 110 < cost68;
-            const int which = rt4 ? 4 : rt5 ? 2 : rt7 ? 3 : rt8 ? 1 : 0;
+            const bool rt5 = odd_ok && rounds5 * 87 < cost68 && rounds5 * 87 <= rounds7 * 110;
+            const bool rt7 = odd_ok && !rt5 && rounds7 * 110 < cost68;
+            const int which = rt5 ? 2 : rt7 ? 3 : rt8 ? 1 : 0;
             const V2Kernel k3 = v3_kernel_table()[which][epi];
-            a2 = rt4 ? a128 : rt5 ? a5 : rt7 ? a7 : rt8 ? a4 : a3;
+            a2 = rt5 ? a5 : rt7 ? a7 : rt8 ? a4 : a3;
             const int lds3 = v3_lds(which);
             if (fd_set_max_lds((const void*)k3, lds3) != FEDDAT_OK) return FEDDAT_ELAUNCH;
             const int total3 = a2.tiles_m * (N / V2_BN);

@@ -95,7 +95,7 @@ def test_gemm_epilogues(L, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(11849, 3072, 768), (5920, 2304, 768), (11840, 768, 3072), (1030, 192, 64), (18464, 768, 768), (18464, 2304, 768),
-                                   (5920, 768, 3072), (4608, 768, 3072), (5920, 768, 768)])      # the last three: 128-row tiles (RT = 4, round 5)
+                                   (5920, 768, 3072), (4608, 768, 3072), (5920, 768, 768)])      # the last three: one partial round of tiles (160-row plan)
 def test_gemm_kernel_variants_bit_identical(L, M, N, K):
     """The two persistent kernels (v2: two wave groups per SIMD; v3: one wave per SIMD, inline-asm MFMAs with AGPR
     accumulators) and the tile heights of each (192 / 256 rows; v3 also 160 rows where they fill the rounds of the 256 CUs
