@@ -29,8 +29,10 @@ def _port():
         return s.getsockname()[1]
 
 
+# heterogeneous clients (SURVEY 8d config 3 in small): different len(loader) AND each client's answers from its own Dirichlet(0.5)
+# label prior, so the two clients' adapter_1 updates really disagree before they are averaged
 COMMON = ["--num_layers", "2", "--image_size", "224", "--batch_size", "2", "--synthetic_steps", "3,2", "--comm_rounds", "2",
-          "--save_every", "1"]
+          "--save_every", "1", "--synthetic_label_alpha", "0.5"]
 
 
 @pytest.mark.timeout(900)
