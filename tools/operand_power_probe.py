@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Why is the fp16-operand step ~2 % slower than the bf16 one when every kernel is the same code at the same MFMA rate?
-(profiles/r05_ab_operands.txt: the GEMM launches are 3-4 % longer inside the replayed graph, equal when bracketed eagerly.)
+(profiles/r05_operand_power_probe.txt: the GEMM launches are 3-4 % longer inside the replayed graph, equal when bracketed eagerly.)
 
 Probe: the SAME fp16 library and kernels, fed operands whose low mantissa bits are zero -- frozen weights rounded to bf16
 values before the engine converts them to fp16 -- next to the plain fp16 and bf16 engines, all as hipGraph replays, interleaved
