@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
     const bool up = prob & 1;
     const float* big = up ? sg.dy : sg.x;
     const float* sm = up ? sg.z : sg.dz;
-    const float unscale = sg.grad_unscale != 0.0f ? sg.grad_unscale : 1.0f;      // 1 / loss scale (a power of two: exact)
+    float unscale = sg.grad_unscale != 0.0f ? sg.grad_unscale : 1.0f;      // 1 / loss scale (a power of two: exact)
+    if (sg.grad_unscale_dev) unscale *= *sg.grad_unscale_dev;               // ... of the dynamic loss scale (device state)
     const float alpha = (up ? sg.scale : 1.0f) * unscale;
     const int T = sg.rows;
     int tps = (T + NBLK * 4 - 1) / (NBLK * 4);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
 }
 
 // grad layer layout: [wd (R x H) | bd (R) | wu (H x R) | bu (H)]
-__device__ __forceinline__ void wgrad_reduce_one(const float* __restrict__ partials, float* __restrict__ gl, int seg, int i) {
+__device__ __forceinline__ bool wgrad_reduce_one(const float* __restrict__ partials, float* __restrict__ gl, int seg, int i) {
     const float* Pd = partials + (size_t)(2 * seg) * NBLK * PSTRIDE;       // dW_down problem
     const float* Pu = partials + (size_t)(2 * seg + 1) * NBLK * PSTRIDE;   // dW_up^T problem
     float sd = 0.f, su = 0.f;
@@ -214,6 +215,7 @@ __device__ __forceinline__ void wgrad_reduce_one(const float* __restrict__ parti
     } else {
         gl[R * H + R + H * R + (i - R * H - R)] = su;  // bu[c] = s * sum dy
     }
+    return !(fabsf(sd) <= 3.4e38f) || !(fabsf(su) <= 3.4e38f);      // inf / NaN in what was written (GradScaler's inf check)
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradLaunch L) {
@@ -227,11 +229,14 @@ struct WgradReduceBatch {
     const float* partials;
     long stride;
     int nseg;
+    int* nonfinite;           // [nseg] or NULL: OR-ed with 1 when a segment's gradients hold an inf / NaN
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WgradReduceBatch B) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
     if (i < PSTRIDE)
-        wgrad_reduce_one(B.partials + (size_t)blockIdx.z * B.stride, B.grads[blockIdx.z * B.nseg + blockIdx.y], blockIdx.y, i);
+        bad = wgrad_reduce_one(B.partials + (size_t)blockIdx.z * B.stride, B.grads[blockIdx.z * B.nseg + blockIdx.y], blockIdx.y, i);
+    if (B.nonfinite && __ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(B.nonfinite + blockIdx.y, 1);
 }
 
 }  // namespace
@@ -270,6 +275,15 @@ extern "C" int feddat_adapter_wgrad_reduce(float* const* grads_dev, int n, int n
     FD_CHECK_ARG(grads_dev && partials && n > 0 && n <= 65535 && nseg >= 1 && nseg <= 2);
     FD_CHECK_ARG(partials_stride >= (long)nseg * 2 * NBLK * PSTRIDE);
     hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((PSTRIDE + 255) / 256, nseg, n), dim3(256), 0, stream,
-                       WgradReduceBatch{grads_dev, partials, partials_stride, nseg});
+                       WgradReduceBatch{grads_dev, partials, partials_stride, nseg, nullptr});
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_adapter_wgrad_reduce_checked(float* const* grads_dev, int n, int nseg, const float* partials,
+                                                   long partials_stride, int* nonfinite, hipStream_t stream) {
+    FD_CHECK_ARG(grads_dev && partials && n > 0 && n <= 65535 && nseg >= 1 && nseg <= 2 && nonfinite);
+    FD_CHECK_ARG(partials_stride >= (long)nseg * 2 * NBLK * PSTRIDE);
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((PSTRIDE + 255) / 256, nseg, n), dim3(256), 0, stream,
+                       WgradReduceBatch{grads_dev, partials, partials_stride, nseg, nonfinite});
     FD_LAUNCH_RET();
 }

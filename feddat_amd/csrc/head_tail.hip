@@ -28,6 +28,7 @@ struct HtJob {
     int mode;                  // 0: the block's waves split K (summed through LDS in wave order); 1: the waves take
                                //    consecutive j-groups, each over the whole K (short contractions: K = batch)
     float alpha;
+    const float* alpha_dev;    // optional device factor on alpha (the dynamic loss scale)
     const float* bias_j;
     float* out; long ldo;
     float* colsum;             // colsum[i] = alpha * sum_k A'[i][k]  (A' = A after the prologue)
@@ -205,6 +206,7 @@ __device__ __forceinline__ void ht_body(const HtJob& p, const int wid, float* ht
             asum += src[JT * 4];
         }
     }
+    const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;      // (a power of two: the product is exact)
 #pragma unroll
     for (int t = 0; t < JT; ++t) {
         if (!jv[t]) continue;
@@ -213,13 +215,13 @@ __device__ __forceinline__ void ht_body(const HtJob& p, const int wid, float* ht
         for (int e = 0; e < 4; ++e) {
             const int io = itile * 16 + 4 * g + e;
             if (io >= p.I) continue;
-            float v = p.alpha * acc[t][e] + bj;
+            float v = alpha * acc[t][e] + bj;
             if (p.epi == FEDDAT_HT_EPI_TANH) v = tanhf(v);
             if (p.epi == FEDDAT_HT_EPI_MUL_DGELU) v *= gelu_grad_f(p.aux[(size_t)io * p.ld_aux + j[t]]);
             p.out[(size_t)io * p.ldo + j[t]] = v;
         }
     }
-    if (p.colsum && jgrp == 0 && g == 0 && iv) p.colsum[i] = p.alpha * asum;
+    if (p.colsum && jgrp == 0 && g == 0 && iv) p.colsum[i] = alpha * asum;
 }
 
 __global__ __launch_bounds__(HT_NW * 64) void ht_gemm_kernel(const HtLaunch L) {
@@ -352,7 +354,8 @@ __global__ __launch_bounds__(256) void ht_ln_bwd_full_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void dat_loss_single_kernel(const float* __restrict__ logits,
                                                                const float* __restrict__ teacher,
                                                                const float* __restrict__ target, int B, int C, float temp,
-                                                               float* __restrict__ dlogits, float* __restrict__ scalars) {
+                                                               float* __restrict__ dlogits, float* __restrict__ scalars,
+                                                               int* __restrict__ nonfinite) {
     extern __shared__ float terms[];       // [2 B]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float it = 1.0f / temp;
@@ -423,6 +426,8 @@ __global__ __launch_bounds__(1024) void dat_loss_single_kernel(const float* __re
         scalars[0] = l_bce;
         scalars[1] = l_kl;
         scalars[2] = 0.5f * (l_bce + l_kl);
+        // GradScaler's inf check, at its source: a non-finite loss means non-finite gradients in every parameter it reaches
+        if (nonfinite && !(fabsf(l_bce + l_kl) <= 3.4e38f)) atomicOr(nonfinite, 1);
     }
 }
 
@@ -449,6 +454,15 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwMulti a) {
     const int blk = (int)blockIdx.x - (k ? a.block_end[k - 1] : 0);
     const long i = ((long)blk * 256 + threadIdx.x) * 4;
     if (i >= G.n) return;
+    // dynamic loss scale (ABI 8): restore / skip decisions are block-uniform device flags (head_tail.hip)
+    if (G.bak_mode == 2 && G.restore_if && *G.restore_if) {
+        *reinterpret_cast<f32x4*>(G.p + i) = *reinterpret_cast<const f32x4*>(G.bak + i);
+        *reinterpret_cast<f32x4*>(G.m + i) = *reinterpret_cast<const f32x4*>(G.bak + G.n + i);
+        *reinterpret_cast<f32x4*>(G.v + i) = *reinterpret_cast<const f32x4*>(G.bak + 2 * G.n + i);
+        return;
+    }
+    const bool skip = (G.skip_if[0] && *G.skip_if[0]) || (G.skip_if[1] && *G.skip_if[1]);
+    if (skip && G.bak_mode != 1) return;
     const int sched_t = G.state[0] + G.d_sched;
     const int t = G.state[1] + G.d_adam + 1;
     const float lr = a.base_lr * ht_poly_lambda(sched_t, a.warmup, a.total);
@@ -473,6 +487,12 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwMulti a) {
     f32x4 pi = *reinterpret_cast<const f32x4*>(G.p + i);
     f32x4 mi = *reinterpret_cast<const f32x4*>(G.m + i);
     f32x4 vi = *reinterpret_cast<const f32x4*>(G.v + i);
+    if (G.bak_mode == 1) {
+        *reinterpret_cast<f32x4*>(G.bak + i) = pi;
+        *reinterpret_cast<f32x4*>(G.bak + G.n + i) = mi;
+        *reinterpret_cast<f32x4*>(G.bak + 2 * G.n + i) = vi;
+        if (skip) return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         pi[e] = pi[e] * (1.0f - lr * wd[e]);
@@ -499,6 +519,40 @@ __global__ void step_tick_multi_kernel(const TickMulti t) {
     }
 }
 
+// End of one dat train_step under a dynamic loss scale: counter ticks by what was applied, GradScaler.update(), flags cleared
+// (semantics: include/feddat_hip.h, feddat_dat_step_finish).
+__global__ void dat_step_finish_kernel(int* head_state, int* ad1_state, int* ad0_state, int* flags, float* scaler_f,
+                                       int* scaler_i, float growth, float backoff, int growth_interval) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int fB = flags[0], fA = flags[1];
+    const int applied = fA ? 0 : fB ? 1 : 2;
+    head_state[0] += applied;
+    head_state[1] += applied;
+    ad1_state[0] += applied;
+    ad1_state[1] += applied >= 1 ? 1 : 0;
+    ad0_state[0] += applied;
+    ad0_state[1] += applied == 2 ? 1 : 0;
+    float scale = scaler_f[0];
+    int tracker = scaler_i[0];
+    if (applied < 2) {
+        scale = fmaxf(scale * backoff, 6.103515625e-05f);
+        tracker = 0;
+        scaler_i[1] += 2 - applied;
+        scaler_i[2] += 1;
+    } else {
+        tracker += 2;
+        if (tracker >= growth_interval) {
+            scale = fminf(scale * growth, 1073741824.0f);
+            tracker = 0;
+        }
+    }
+    scaler_f[0] = scale;
+    scaler_f[1] = 1.0f / scale;
+    scaler_i[0] = tracker;
+    flags[0] = 0;
+    flags[1] = 0;
+}
+
 int ht_fill(HtJob& j, const feddat_ht_job& s) {
     if (!(s.A && s.B && s.out && s.I > 0 && s.J > 0 && s.K > 0 && s.ldo >= s.J && (s.mode == 0 || s.mode == 1)))
         return FEDDAT_EINVAL;
@@ -509,7 +563,7 @@ int ht_fill(HtJob& j, const feddat_ht_job& s) {
     if (s.epi == FEDDAT_HT_EPI_MUL_DGELU && !(s.aux && s.ld_aux >= s.J)) return FEDDAT_EINVAL;
     if (s.pro < 0 || s.pro > FEDDAT_HT_PRO_TANH_BWD || s.epi < 0 || s.epi > FEDDAT_HT_EPI_MUL_DGELU) return FEDDAT_EINVAL;
     j.A = s.A; j.sa_i = s.sa_i; j.sa_k = s.sa_k; j.B = s.B; j.sb_k = s.sb_k; j.sb_j = s.sb_j;
-    j.I = s.I; j.J = s.J; j.K = s.K; j.mode = s.mode; j.alpha = s.alpha; j.bias_j = s.bias_j; j.out = s.out; j.ldo = s.ldo;
+    j.I = s.I; j.J = s.J; j.K = s.K; j.mode = s.mode; j.alpha = s.alpha; j.alpha_dev = s.alpha_dev; j.bias_j = s.bias_j; j.out = s.out; j.ldo = s.ldo;
     j.colsum = s.colsum; j.pro = s.pro; j.pro_a = s.pro_a; j.pro_b = s.pro_b; j.pro_eps = s.pro_eps;
     j.stats_out = s.stats_out; j.epi = s.epi; j.aux = s.aux; j.ld_aux = s.ld_aux;
     j.avec = s.sa_k == 1 && s.K % 4 == 0 && s.sa_i % 4 == 0 && ((uintptr_t)s.A & 15) == 0 &&
@@ -567,7 +621,24 @@ extern "C" int feddat_dat_loss_fwd_bwd_single(const float* logits, const float* 
                                               float temp, float* dlogits, float* scalars, hipStream_t stream) {
     FD_CHECK_ARG(logits && teacher && target && dlogits && scalars && B > 0 && B <= 4096 && C > 0 && C <= 128 && temp > 0.f);
     hipLaunchKernelGGL(dat_loss_single_kernel, dim3(1), dim3(1024), 2 * B * sizeof(float), stream, logits, teacher, target, B,
-                       C, temp, dlogits, scalars);
+                       C, temp, dlogits, scalars, (int*)nullptr);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_dat_loss_fwd_bwd_checked(const float* logits, const float* teacher, const float* target, int B, int C,
+                                               float temp, float* dlogits, float* scalars, int* nonfinite, hipStream_t stream) {
+    FD_CHECK_ARG(logits && teacher && target && dlogits && scalars && B > 0 && B <= 4096 && C > 0 && C <= 128 && temp > 0.f);
+    hipLaunchKernelGGL(dat_loss_single_kernel, dim3(1), dim3(1024), 2 * B * sizeof(float), stream, logits, teacher, target, B,
+                       C, temp, dlogits, scalars, nonfinite);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_dat_step_finish(int* head_state, int* ad1_state, int* ad0_state, int* flags, float* scaler_f,
+                                      int* scaler_i, float growth, float backoff, int growth_interval, hipStream_t stream) {
+    FD_CHECK_ARG(head_state && ad1_state && ad0_state && flags && scaler_f && scaler_i && growth >= 1.0f && backoff > 0.f &&
+                 backoff <= 1.0f && growth_interval > 0);
+    hipLaunchKernelGGL(dat_step_finish_kernel, dim3(1), dim3(64), 0, stream, head_state, ad1_state, ad0_state, flags, scaler_f,
+                       scaler_i, growth, backoff, growth_interval);
     FD_LAUNCH_RET();
 }
 
@@ -580,6 +651,8 @@ extern "C" int feddat_adamw_multi(const feddat_adamw_group* groups, int ngroups,
         const feddat_adamw_group& G = groups[k];
         FD_CHECK_ARG(G.p && G.g && G.m && G.v && G.n > 0 && G.n % 4 == 0 && G.seg_off && G.seg_wd && G.nseg > 0 && G.state);
         FD_CHECK_ARG((((uintptr_t)G.p | (uintptr_t)G.g | (uintptr_t)G.m | (uintptr_t)G.v) & 15) == 0);
+        FD_CHECK_ARG(G.bak_mode >= 0 && G.bak_mode <= 2 && (G.bak_mode == 0 || (G.bak && ((uintptr_t)G.bak & 15) == 0)) &&
+                     (G.bak_mode != 2 || G.restore_if));
         a.grp[k] = G;
         blocks += (int)((G.n / 4 + 255) / 256);
         a.block_end[k] = blocks;

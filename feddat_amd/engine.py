@@ -78,7 +78,8 @@ class ViltDatEngine:
                  text_len: int = 40, layers: int = 12, num_labels: int = 100, lr: float = 1e-4,
                  weight_decay: float = 1e-2, adam_eps: float = 1e-8, wgrad_splits: int = 16, fp8: bool = False,
                  fp8_ffn_chain: bool = True, gelu_codes: bool = True, operands: Optional[str] = None,
-                 loss_scale: Optional[float] = None, fp8_mx_dqkv: bool = True):
+                 loss_scale: Optional[float] = None, fp8_mx_dqkv: bool = True, dynamic_loss_scale: Optional[bool] = None,
+                 scale_growth_interval: int = 2000):
         """operands: "f16" (the default) or "bf16" (the default with fp8=True, configs[4]).  "f16": every 16-bit MFMA operand of the step -- frozen weights and their transposes, LayerNorm outputs,
         qkv, probabilities, ctx, gelu(u), the adapters' operand copies, and every gradient operand of the dX products and of
         the attention backward -- is IEEE half instead of bf16 (libfeddat_hip_f16.so: v_mfma_f32_16x16x32_f16, the same MFMA
@@ -86,9 +87,15 @@ class ViltDatEngine:
         accelerate_config.yaml:8).  The backward then carries a power-of-two `loss_scale` (default 2^14; 1 for bf16): the
         gradient entering the backbone (d pooler-input) is multiplied by it where it is produced, every kernel of the backward
         is linear in the gradient, and the factor leaves exactly where the adapter weight gradients are formed
-        (feddat_wgrad_seg.scale); the task head's own gradients never see it.  What the reference's GradScaler does
-        dynamically (task_trainer.py:302,323) is static here: the scaled gradients of this path span 1e-4 .. 1e1 at the
-        default, eleven binades inside either end of fp16's range.
+        (feddat_wgrad_seg.scale); the task head's own gradients never see it.  The scaled gradients of this path span
+        1e-4 .. 1e1 at the default, eleven binades inside either end of fp16's range.
+        dynamic_loss_scale (default: on with "f16" operands): the reference's GradScaler (accelerate, mixed_precision fp16:
+        accelerate_config.yaml:8; task_trainer.py:302-308,323-328) ON THE DEVICE, inside the captured step -- `loss_scale` is
+        only the initial value (GradScaler's own is 65536); a non-finite adapter gradient (feddat_adapter_wgrad_reduce_checked)
+        or loss (feddat_dat_loss_fwd_bwd_checked) skips that sub-step's optimizer AND scheduler step and halves the scale,
+        `scale_growth_interval` clean sub-steps double it (feddat_dat_step_finish; DESIGN.md section 5b says where this
+        differs from GradScaler: an overflow in sub-step A voids the whole batch).  With no overflow the step is bit-identical
+        to the static scale.  A fresh scaler per local update, like the reference's fresh Accelerator per round (main.py:435).
         fp8=True (BASELINE.json configs[4]): four frozen products per layer run on the block-scaled fp8 MFMA with e4m3
         operands -- forward QKV and FFN1 (activations quantised per token row by the LayerNorm kernel that produces them) and
         the dX products FFN2^T and attention-output^T (the gradient rows quantised per row: by feddat_quant_rows_fp8 behind the
@@ -114,6 +121,8 @@ class ViltDatEngine:
         # feddat_attn_bwd_fp8mx) and QKV^T runs on the block-scaled fp8 MFMA with those scales (feddat_gemm_fp8mx_nt): the seventh
         # of the eight frozen products per layer, and half the bytes of the backward's largest write
         self.fp8_mx_dqkv = bool(fp8) and bool(fp8_mx_dqkv)
+        self.dynamic_scale = bool(operands == "f16" if dynamic_loss_scale is None else dynamic_loss_scale)
+        self.scale_growth, self.scale_backoff, self.scale_growth_interval = 2.0, 0.5, int(scale_growth_interval)
         self._init(params, tasks, device, batch, res, text_len, layers, num_labels, lr, weight_decay, adam_eps, wgrad_splits,
                    fp8, fp8_ffn_chain, gelu_codes)
 
@@ -333,6 +342,13 @@ class ViltDatEngine:
         self.sched = dict(warmup=1, total=2)
         self.opt_adapters = (0, 1)
         self.task = self.tasks[0]
+        # dynamic loss scale (GradScaler on the device): {scale, 1 / scale}; {growth tracker, skipped sub-steps, batches with a
+        # skip, -}; overflow flags {sub-step B = adapter_0 pass, sub-step A = adapter_1 pass}; the head's p | m | v before its
+        # sub-step-A update (restored when A turns out to have overflowed in the backbone's backward)
+        self.scaler_f = torch.tensor([self.loss_scale, 1.0 / self.loss_scale], dtype=torch.float32, device=dev)
+        self.scaler_i = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.ovf_flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.head_bak = {t: torch.empty(3 * self.head[t].p.numel(), device=dev) for t in self.tasks} if self.dynamic_scale else {}
 
     # ------------------------------------------------------------------------------------------ adapters
     def _alloc_pack(self, a, i):
@@ -681,7 +697,7 @@ class ViltDatEngine:
         # operands): every kernel below is linear in it, and feddat_wgrad_seg.grad_unscale takes it out again
         if self.fused_tail:      # d(pooler input) = (dpooled * (1 - pooled^2)) W_pool in one launch
             L.head_gemm(L.ht_job(self.dpooled, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, pro=L.HT_PRO_TANH_BWD,
-                                 pro_a=self.pooled, alpha=self.loss_scale))
+                                 pro_a=self.pooled, **self._scale_in()))
         else:
             L.tanh_bwd(self.pooled, self.dpooled, self.dpre)
             self._sg(self.dpre, H, 1, self.pool_w, H, 1, nb, H, H, self.dcls_ln, ksplit=4, alpha=self.loss_scale)
@@ -762,7 +778,7 @@ class ViltDatEngine:
         if key not in self._segs_cache:
             n = self.ad_layer_numel
             segs = [dict(x=t["h3"][r0:], dy=self.dcls[r0:], z=self.z[r0:], dz=self.dz[r0:],
-                         grad=self.ad[ad].g[i * n:(i + 1) * n], rows=B, scale=sc, grad_unscale=1.0 / self.loss_scale)
+                         grad=self.ad[ad].g[i * n:(i + 1) * n], rows=B, scale=sc, **self._scale_out())
                     for ad, r0, sc in ((0, 0, 0.5), (1, B, 1.0)) if ad in self.opt_adapters]
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
         if self._segs_cache[key] is not None:
@@ -814,8 +830,7 @@ class ViltDatEngine:
             for a, row0, xrow0, sc in ((0, 0, 0, 0.5), (1, R, R + x_delta_s, 1.0)):
                 if a in self.opt_adapters:
                     segs.append(dict(x=x[xrow0:], dy=dy[row0:], z=self.z[row0:], dz=self.dz[row0:],
-                                     grad=self.ad[a].g[layer * n:(layer + 1) * n], rows=R, scale=sc,
-                                     grad_unscale=1.0 / self.loss_scale))
+                                     grad=self.ad[a].g[layer * n:(layer + 1) * n], rows=R, scale=sc, **self._scale_out()))
             self._segs_cache[key] = L.make_wgrad_segs(segs) if segs else None
         return self._segs_cache[key]
 
@@ -832,7 +847,29 @@ class ViltDatEngine:
             n = self.ad_layer_numel
             ptrs = [self.ad[a].g[i * n:(i + 1) * n].data_ptr() for i in range(self.nl) for a in ads]
             self._segs_cache[key] = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
-        L.adapter_wgrad_reduce(self._segs_cache[key], self.nl, len(ads), self.wpart_all, self.wpart_stride)
+        if self._dyn():      # + GradScaler's inf check where the loss scale leaves the gradients: flags[a] for adapter a
+            L.adapter_wgrad_reduce_checked(self._segs_cache[key], self.nl, len(ads), self.wpart_all, self.wpart_stride,
+                                           self.ovf_flags[ads[0]:])
+        else:
+            L.adapter_wgrad_reduce(self._segs_cache[key], self.nl, len(ads), self.wpart_all, self.wpart_stride)
+
+    def _dyn(self) -> bool:
+        """Dynamic loss scale in effect (it rides on the fused tail's multi-group AdamW launch)."""
+        return self.dynamic_scale and self.fused_tail
+
+    def _scale_in(self):
+        """How the loss scale enters the backbone's backward (factor of the pooler-backward product)."""
+        return dict(alpha=1.0, alpha_dev=self.scaler_f[0:1]) if self._dyn() else dict(alpha=self.loss_scale)
+
+    def _scale_out(self):
+        """... and how it leaves, where the adapter weight gradients are formed."""
+        return dict(grad_unscale=1.0, grad_unscale_dev=self.scaler_f[1:2]) if self._dyn() else \
+            dict(grad_unscale=1.0 / self.loss_scale)
+
+    def scaler_state(self) -> Dict[str, float]:
+        """Host copy of the loss scaler (one device read-back): current scale, growth tracker, skipped sub-steps / batches."""
+        f, i = self.scaler_f.tolist(), self.scaler_i.tolist()
+        return dict(scale=f[0], growth_tracker=i[0], skipped_substeps=i[1], skipped_batches=i[2], dynamic=self._dyn())
 
     def _adapter_wgrads(self, layer: int, x, x_delta_s: int, dy):
         """dW_up = s dy^T z, db_up = s sum_t dy, dW_down = dz^T x, db_down = sum_t dz (autograd of adapter.py:125-146)
@@ -860,22 +897,30 @@ class ViltDatEngine:
         self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))
         self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))
         self.head[task].state.copy_(torch.tensor([0, 0], dtype=torch.int32))
+        # a fresh GradScaler per local update (the reference builds a fresh Accelerator per round: main.py:435)
+        self.scaler_f.copy_(torch.tensor([self.loss_scale, 1.0 / self.loss_scale], dtype=torch.float32))
+        self.scaler_i.zero_()
+        self.ovf_flags.zero_()
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.use_layer_calls, self.fp8,
-               self.fp8_ffn_chain, self.fused_tail, self.cls_attention, self.operands, self.loss_scale, self.fp8_mx_dqkv)        # host-side switches that change the launch list are part of the signature
+               self.fp8_ffn_chain, self.fused_tail, self.cls_attention, self.operands, self.loss_scale, self.fp8_mx_dqkv,
+               self._dyn(), self.scale_growth_interval)        # host-side switches that change the launch list are part of the signature
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig
 
-    def _adamw_group(self, grp: FlatGroup, d_sched: int = 0, d_adam: int = 0):
-        return L.adamw_group(grp.p, grp.g, grp.m, grp.v, grp.seg_off, self._wd_vec(grp), grp.state, d_sched, d_adam)
+    def _adamw_group(self, grp: FlatGroup, d_sched: int = 0, d_adam: int = 0, **kw):
+        return L.adamw_group(grp.p, grp.g, grp.m, grp.v, grp.seg_off, self._wd_vec(grp), grp.state, d_sched, d_adam, **kw)
 
     def _adamw_many(self, groups):
         L.adamw_multi(groups, self.lr, self.sched["warmup"], self.sched["total"], 0.9, 0.98, self.eps)
 
     def _loss(self, logits, teacher, slot):
-        if self.fused_tail:
+        if self._dyn():      # + non-finite loss -> the sub-step's overflow flag (p1 = sub-step A, p2 = B)
+            flag = self.ovf_flags[1:2] if slot == "p1" else self.ovf_flags[0:1]
+            L.dat_loss_fwd_bwd_checked(logits, teacher, self.inp["target"], self.dlogits, self.loss_buf[slot], flag)
+        elif self.fused_tail:
             L.dat_loss_fwd_bwd_single(logits, teacher, self.inp["target"], self.dlogits, self.loss_buf[slot])
         else:
             L.dat_loss_fwd_bwd(logits, teacher, self.inp["target"], self.dlogits, self.loss_buf[slot])
@@ -893,7 +938,11 @@ class ViltDatEngine:
         logits_all, logits_1 = logits_both[:B], logits_both[B:]
         self._loss(logits_1, logits_all, "p1")
         self._head_bwd(pooled_s, "p1", task, self.dpooled[B:])
-        if self.fused_tail:
+        dyn = self._dyn()
+        fB, fA = self.ovf_flags[0:1], self.ovf_flags[1:2]
+        if dyn:      # sub-step A's head update: skipped on a non-finite loss; the old p | m | v are kept for the restore below
+            self._adamw_many([self._adamw_group(hp, skip_if=(fA,), bak=self.head_bak[task], bak_mode=1)])
+        elif self.fused_tail:
             self._adamw_many([self._adamw_group(hp)])       # sub-step 2b; its counters are ticked once, at the end of the step
         else:
             self._adamw(hp)
@@ -907,13 +956,26 @@ class ViltDatEngine:
         if self.fused_tail:
             # adapter_1 (2b), head (2b + 1: reads its counters one ahead), adapter_0 (2b + 1) in ONE launch, then the bf16
             # operand copies, then ONE tick for all counters
-            groups = ([self._adamw_group(self.ad[1])] if 1 in self.opt_adapters else []) + [self._adamw_group(hp, 1, 1)] + \
-                ([self._adamw_group(self.ad[0])] if 0 in self.opt_adapters else [])
+            if dyn:
+                # GradScaler's skips as device predicates: A overflowed (flag A) -> nothing of this batch is applied: adapter_1
+                # and adapter_0 stay, the head returns to its state before sub-step A; only B overflowed -> A stands, the head's
+                # second update and adapter_0's are skipped.  feddat_dat_step_finish ticks the counters by what was applied
+                # (a skipped optimizer step skips its scheduler tick), updates the scale and clears the flags.
+                groups = ([self._adamw_group(self.ad[1], skip_if=(fA,))] if 1 in self.opt_adapters else []) + \
+                    [self._adamw_group(hp, 1, 1, skip_if=(fB,), bak=self.head_bak[task], bak_mode=2, restore_if=fA)] + \
+                    ([self._adamw_group(self.ad[0], skip_if=(fA, fB))] if 0 in self.opt_adapters else [])
+            else:
+                groups = ([self._adamw_group(self.ad[1])] if 1 in self.opt_adapters else []) + [self._adamw_group(hp, 1, 1)] + \
+                    ([self._adamw_group(self.ad[0])] if 0 in self.opt_adapters else [])
             self._adamw_many(groups)
             for a in (1, 0):
                 if a in self.opt_adapters:
                     self.repack_adapter(a)
-            L.step_tick_multi([hp.state, self.ad[1].state, self.ad[0].state], [2, 2, 2], [2, 1, 1])
+            if dyn:
+                L.dat_step_finish(hp.state, self.ad[1].state, self.ad[0].state, self.ovf_flags, self.scaler_f, self.scaler_i,
+                                  self.scale_growth, self.scale_backoff, self.scale_growth_interval)
+            else:
+                L.step_tick_multi([hp.state, self.ad[1].state, self.ad[0].state], [2, 2, 2], [2, 1, 1])
             return
         if 1 in self.opt_adapters:
             self._adamw(self.ad[1])
@@ -954,6 +1016,7 @@ class ViltDatEngine:
         run so that capturing does not advance training."""
         groups = [self.ad[0], self.ad[1], self.head[self.task]]
         saved = [(g.p.clone(), g.m.clone(), g.v.clone(), g.state.clone()) for g in groups]
+        saved_scaler = (self.scaler_f.clone(), self.scaler_i.clone(), self.ovf_flags.clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -972,24 +1035,36 @@ class ViltDatEngine:
             g.m.copy_(m)
             g.v.copy_(v)
             g.state.copy_(st)
+        self.scaler_f.copy_(saved_scaler[0])
+        self.scaler_i.copy_(saved_scaler[1])
+        self.ovf_flags.copy_(saved_scaler[2])
         for a in (0, 1):
             self.repack_adapter(a)
         torch.cuda.synchronize()
         self.graph = graph
 
     def assert_finite(self):
-        """The static loss scale has no GradScaler behind it that would skip an overflowed step (task_trainer.py:302 via
-        accelerate): if a gradient operand left fp16's range the update turned non-finite.  One host read-back of the trainable
-        state, meant to be called once per local update (TaskTrainer.train does); raises with what to change."""
-        for name, grp in (("adapter_0", self.ad[0]), ("adapter_1", self.ad[1]), ("head", self.head[self.task])):
-            if not bool(torch.isfinite(grp.p).all()):
-                raise L.FeddatHipError(
-                    f"non-finite values in {name} after the local update: with operands={self.operands!r} the backward carries a "
-                    f"static loss scale of {self.loss_scale:g}; this model's gradients leave fp16's range at that scale -- "
-                    "construct the engine with a smaller power of two (loss_scale=...) or operands='bf16'")
+        """Last line of defence.  With the dynamic loss scale (the default for fp16 operands) an overflowed sub-step is skipped
+        on the device like GradScaler does (task_trainer.py:302 via accelerate) and this never fires; with a STATIC scale
+        (dynamic_loss_scale=False, or the unfused tail) a gradient operand that left fp16's range turns the update non-finite.
+        One host read-back of the trainable state, meant to be called once per local update (TaskTrainer.train does; train.main
+        agrees on the outcome across ranks BEFORE the FedAvg collective); raises with what to change."""
+        bad = self.nonfinite_groups()
+        if bad:
+            raise L.FeddatHipError(
+                f"non-finite values in {', '.join(bad)} after the local update: with operands={self.operands!r} the backward "
+                f"carries a {'dynamic' if self._dyn() else 'static'} loss scale (initial value {self.loss_scale:g}); "
+                + ("the scaler skips overflowed steps, so the non-finite values entered through the inputs or the weights"
+                   if self._dyn() else
+                   "this model's gradients leave fp16's range at that scale -- construct the engine with "
+                   "dynamic_loss_scale=True, a smaller power of two (loss_scale=...) or operands='bf16'"))
+
+    def nonfinite_groups(self):
+        """Names of the trainable groups holding an inf / NaN (one host read-back each); [] = all finite."""
+        return [name for name, grp in (("adapter_0", self.ad[0]), ("adapter_1", self.ad[1]), ("head", self.head[self.task]))
+                if not bool(torch.isfinite(grp.p).all())]
 
     # ------------------------------------------------------------------------------------------ inference
-    @_bound
     @_bound
     @torch.no_grad()
     def forward(self, batch: Dict[str, torch.Tensor], mode: str, task: Optional[str] = None):

@@ -25,7 +25,7 @@ EPI_BF16, EPI_RESID_F32, EPI_GELU, EPI_MUL_DGELU, EPI_F32, EPI_GELU_G8, EPI_MUL_
 F8_ACT_SCALE, F8_GRAD_HEADROOM = 0.125, 4.0      # FEDDAT_F8_ACT_SCALE / FEDDAT_F8_GRAD_HEADROOM
 G8_LO, G8_STEP = -0.135, 0.005        # FEDDAT_G8_LO / FEDDAT_G8_STEP: gelu' ~ G8_LO + G8_STEP * code
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 
 
@@ -37,7 +37,7 @@ class AdapterSeg(C.Structure):
 
 class WgradSeg(C.Structure):
     _fields_ = [("x", vp), ("dy", vp), ("z", vp), ("dz", vp), ("grad", vp), ("rows", i32), ("scale", f32),
-                ("grad_unscale", f32), ("reserved", i32)]
+                ("grad_unscale", f32), ("reserved", i32), ("grad_unscale_dev", vp)]
 
 
 class ViltLayerWeights(C.Structure):
@@ -58,12 +58,13 @@ class HtJob(C.Structure):            # feddat_ht_job
     _fields_ = [("A", vp), ("sa_i", i64), ("sa_k", i64), ("B", vp), ("sb_k", i64), ("sb_j", i64), ("I", i32), ("J", i32),
                 ("K", i32), ("mode", i32), ("alpha", f32), ("bias_j", vp), ("out", vp), ("ldo", i64), ("colsum", vp),
                 ("pro", i32), ("pro_a", vp), ("pro_b", vp), ("pro_eps", f32), ("stats_out", vp), ("epi", i32), ("aux", vp),
-                ("ld_aux", i64)]
+                ("ld_aux", i64), ("alpha_dev", vp)]
 
 
 class AdamwGroup(C.Structure):       # feddat_adamw_group
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("seg_off", vp), ("seg_wd", vp), ("nseg", i32),
-                ("state", vp), ("d_sched", i32), ("d_adam", i32)]
+                ("state", vp), ("d_sched", i32), ("d_adam", i32), ("skip_if", vp * 2), ("bak", vp), ("bak_mode", i32),
+                ("restore_if", vp)]
 
 
 HT_PRO_NONE, HT_PRO_LN, HT_PRO_TANH_BWD = 0, 1, 2
@@ -128,6 +129,7 @@ _SIGS = {
     "feddat_adapter_wgrad": [C.POINTER(WgradSeg), i32, vp, i64, i32, i32, vp],
     "feddat_adapter_wgrad_partial": [C.POINTER(WgradSeg), i32, vp, i64, i32, i32, vp],
     "feddat_adapter_wgrad_reduce": [vp, i32, i32, vp, i64, vp],
+    "feddat_adapter_wgrad_reduce_checked": [vp, i32, i32, vp, i64, vp, vp],
     "feddat_vilt_layer_fwd": [vp, C.POINTER(ViltLayerWeights), C.POINTER(ViltLayerActs), i32, i32, i32, vp, i32,
                               C.POINTER(AdapterSeg), i32, vp, vp, vp],
     "feddat_vilt_layer_bwd": [vp, C.POINTER(ViltLayerWeights), C.POINTER(ViltLayerActs), C.POINTER(ViltLayerGrads), i32, i32,
@@ -136,6 +138,8 @@ _SIGS = {
     "feddat_reduce_partials": [vp, i64, i32, i64, vp, vp],
     "feddat_dat_loss_fwd_bwd": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
     "feddat_dat_loss_fwd_bwd_single": [vp, vp, vp, i32, i32, f32, vp, vp, vp],
+    "feddat_dat_loss_fwd_bwd_checked": [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp],
+    "feddat_dat_step_finish": [vp, vp, vp, vp, vp, vp, f32, f32, i32, vp],
     "feddat_head_gemm": [C.POINTER(HtJob), i32, vp],
     "feddat_head_ln_gelu": [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp],
     "feddat_head_ln_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
@@ -569,6 +573,9 @@ def make_wgrad_segs(segs: Sequence[dict]):
     for s, d in zip(arr, segs):
         s.x, s.dy, s.z, s.dz, s.grad = (d[k].data_ptr() for k in ("x", "dy", "z", "dz", "grad"))
         s.rows, s.scale, s.grad_unscale = d["rows"], d["scale"], d.get("grad_unscale", 1.0)
+        t = d.get("grad_unscale_dev")          # device float: 1 / the dynamic loss scale (ABI 8)
+        s.grad_unscale_dev = t.data_ptr() if t is not None else None
+    arr._keep = [d.get("grad_unscale_dev") for d in segs]
     return arr
 
 
@@ -587,6 +594,14 @@ def adapter_wgrad_reduce(grads_dev, n, nseg, partials, stride):
     _dev(grads_dev, partials)
     _chk(load().feddat_adapter_wgrad_reduce(_p(grads_dev), n, nseg, _p(partials), stride, _stream()),
          "feddat_adapter_wgrad_reduce")
+
+
+def adapter_wgrad_reduce_checked(grads_dev, n, nseg, partials, stride, nonfinite):
+    """feddat_adapter_wgrad_reduce + GradScaler's inf check: nonfinite (int32 device tensor, >= nseg elements) is OR-ed per segment."""
+    _dev(grads_dev, partials, nonfinite)
+    assert nonfinite.dtype == torch.int32 and nonfinite.numel() >= nseg
+    _chk(load().feddat_adapter_wgrad_reduce_checked(_p(grads_dev), n, nseg, _p(partials), stride, _p(nonfinite), _stream()),
+         "feddat_adapter_wgrad_reduce_checked")
 
 
 def adapter_wgrad(segs_arr, partials, H=768, r=48):
@@ -645,17 +660,17 @@ def dat_loss_fwd_bwd(logits, teacher, target, dlogits, scalars, temp=3.0):
 
 
 def ht_job(A, sa_i, sa_k, B, sb_k, sb_j, I, J, K, out, ldo=None, mode=0, alpha=1.0, bias_j=None, colsum=None, pro=HT_PRO_NONE,
-           pro_a=None, pro_b=None, pro_eps=0.0, stats_out=None, epi=HT_EPI_NONE, aux=None, ld_aux=0) -> HtJob:
+           pro_a=None, pro_b=None, pro_eps=0.0, stats_out=None, epi=HT_EPI_NONE, aux=None, ld_aux=0, alpha_dev=None) -> HtJob:
     """One product of feddat_head_gemm (include/feddat_hip.h: feddat_ht_job); keeps its tensors alive."""
     _dev(A, B, out)
     j = HtJob()
-    j._keep = (A, B, out, bias_j, colsum, pro_a, pro_b, stats_out, aux)
+    j._keep = (A, B, out, bias_j, colsum, pro_a, pro_b, stats_out, aux, alpha_dev)
     ptr = lambda t: t.data_ptr() if t is not None else None
     j.A, j.sa_i, j.sa_k, j.B, j.sb_k, j.sb_j = ptr(A), sa_i, sa_k, ptr(B), sb_k, sb_j
     j.I, j.J, j.K, j.mode, j.alpha = I, J, K, mode, alpha
     j.bias_j, j.out, j.ldo, j.colsum = ptr(bias_j), ptr(out), (J if ldo is None else ldo), ptr(colsum)
     j.pro, j.pro_a, j.pro_b, j.pro_eps, j.stats_out = pro, ptr(pro_a), ptr(pro_b), pro_eps, ptr(stats_out)
-    j.epi, j.aux, j.ld_aux = epi, ptr(aux), ld_aux
+    j.epi, j.aux, j.ld_aux, j.alpha_dev = epi, ptr(aux), ld_aux, ptr(alpha_dev)
     return j
 
 
@@ -686,10 +701,36 @@ def dat_loss_fwd_bwd_single(logits, teacher, target, dlogits, scalars, temp=3.0)
                                                _stream()), "feddat_dat_loss_fwd_bwd_single")
 
 
-def adamw_group(p, g, m, v, seg_off, seg_wd, state, d_sched=0, d_adam=0) -> AdamwGroup:
+def dat_loss_fwd_bwd_checked(logits, teacher, target, dlogits, scalars, nonfinite, temp=3.0):
+    """dat_loss_fwd_bwd_single that also ORs 1 into nonfinite[0] (int32 device tensor) when the loss is inf / NaN."""
+    _dev(logits, teacher, target, nonfinite)
+    B, Cn = logits.shape
+    assert scalars.numel() >= 4 and nonfinite.dtype == torch.int32
+    _chk(load().feddat_dat_loss_fwd_bwd_checked(_p(logits), _p(teacher), _p(target), B, Cn, temp, _p(dlogits), _p(scalars),
+                                                _p(nonfinite), _stream()), "feddat_dat_loss_fwd_bwd_checked")
+
+
+def dat_step_finish(head_state, ad1_state, ad0_state, flags, scaler_f, scaler_i, growth=2.0, backoff=0.5, growth_interval=2000):
+    """End of a dat train_step under the dynamic loss scale (include/feddat_hip.h: feddat_dat_step_finish)."""
+    _dev(head_state, ad1_state, ad0_state, flags, scaler_f, scaler_i)
+    _chk(load().feddat_dat_step_finish(_p(head_state), _p(ad1_state), _p(ad0_state), _p(flags), _p(scaler_f), _p(scaler_i),
+                                       growth, backoff, growth_interval, _stream()), "feddat_dat_step_finish")
+
+
+def adamw_group(p, g, m, v, seg_off, seg_wd, state, d_sched=0, d_adam=0, skip_if=(), bak=None, bak_mode=0,
+                restore_if=None) -> AdamwGroup:
+    """skip_if: up to two int32 device tensors (the update is skipped when either is non-zero); bak / bak_mode / restore_if: the
+    save (1) / conditional restore (2) of p | m | v around an update that may have to be undone (feddat_adamw_group, ABI 8)."""
     _dev(p, g, m, v, seg_off, seg_wd, state)
     G = AdamwGroup()
-    G._keep = (p, g, m, v, seg_off, seg_wd, state)
+    G._keep = (p, g, m, v, seg_off, seg_wd, state, tuple(skip_if), bak, restore_if)
+    for k, t in enumerate(skip_if):
+        G.skip_if[k] = t.data_ptr()
+    if bak is not None:
+        assert bak.numel() >= 3 * p.numel() and bak_mode in (1, 2)
+        G.bak, G.bak_mode = bak.data_ptr(), bak_mode
+    if restore_if is not None:
+        G.restore_if = restore_if.data_ptr()
     G.p, G.g, G.m, G.v, G.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
     G.seg_off, G.seg_wd, G.nseg, G.state, G.d_sched, G.d_adam = (seg_off.data_ptr(), seg_wd.data_ptr(), seg_wd.numel(),
                                                                    state.data_ptr(), d_sched, d_adam)

@@ -130,8 +130,17 @@ class TaskTrainer:
                 if self.args.debug > 0 and step > self.args.debug:     # task_trainer.py:82-83
                     break
                 loss = self.train_step(model, step, batch, optimizer, scheduler, hooks=None, epoch=epoch)
-        eng.assert_finite()        # one read-back per local update: a loss scale too large for this model's gradients is an error
+        self._finite_check(eng)    # one read-back per local update
         return 0.0, model
+
+    def _finite_check(self, eng):
+        """Non-finite trainable state after a local update is an error.  Standalone it raises here; under main() with several
+        ranks it is only RECORDED (self.nonfinite) and main() agrees on it across ranks before the FedAvg collective, so that
+        every rank raises together instead of one raising while its peers wait in the all-reduce."""
+        if getattr(self, "defer_finite_check", False):
+            self.nonfinite = eng.nonfinite_groups()
+        else:
+            eng.assert_finite()
 
     def train_step(self, model: ViltContinualLearner, step, batch, optimizer=None, scheduler=None, hooks=None,
                    epoch=None):
@@ -186,7 +195,7 @@ class AlbefTaskTrainer(TaskTrainer):
                 if self.args.debug > 0 and step > self.args.debug:
                     break
                 self.train_step(model, step, batch, optimizer, None, hooks=None, epoch=epoch)
-        eng.assert_finite()
+        self._finite_check(eng)
         return 0.0, model
 
     def train_step(self, model, step, batch, optimizer=None, scheduler=None, hooks=None, epoch=None):
@@ -434,6 +443,7 @@ def main(argv=None):
             personal_params[t].update({k: v.to(dev) for k, v in pers[t].items()})
         first_round = last + 1
     for comm_round in range(first_round, args.comm_rounds):
+        nonfinite = []
         for k, task_key in enumerate(my_tasks):
             eng.comm_flat().copy_(server_flat)                      # main.py:472 deepcopy(server)
             eng.repack_adapter(1)
@@ -441,12 +451,21 @@ def main(argv=None):
             model.adapter_requires_grad = dict(server_flags)
             trainer = Trainer(args, task_key, data[task_key], data[task_key][:2], log)
             trainer.dropout_epoch = comm_round * len(tasks) + tasks.index(task_key)     # fresh dropout masks per round and client
+            trainer.defer_finite_check = world > 1
             trainer.train(model, comm_round)
+            nonfinite += [f"{task_key}:{g}" for g in getattr(trainer, "nonfinite", [])]
             personal_params[task_key] = personal(model.state_dict())     # main.py:493-497
             # local pre-sum in client order, then (if distributed) one all-reduce: main.py:50-65
             L.fedavg_accumulate(acc, eng.comm_flat(), 1.0, float(len(tasks)), k == 0)
         if not my_tasks:
             acc.zero_()
+        if world > 1:       # every rank learns whether ANY rank's local update went non-finite, and all raise together
+            bad = torch.tensor([1.0 if nonfinite else 0.0], device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if bad.item() > 0:
+                raise L.FeddatHipError(f"round {comm_round}: non-finite trainable state after the local update on "
+                                       + (f"this rank ({', '.join(nonfinite)})" if nonfinite else "another rank")
+                                       + "; no rank enters the FedAvg all-reduce")
         if rccl is not None:
             rccl.fedavg_allreduce(acc, rccl_scratch, 1.0, 1.0)      # RCCL over xGMI on the 3.58 MB device buffer
         elif world > 1:

@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define FEDDAT_ELAUNCH 2
 #define FEDDAT_ETIMEOUT 3   /* feddat_comm_create_timeout only */
 
-#define FEDDAT_ABI_VERSION 7   /* 7: feddat_operand_format (bf16 / fp16 operand builds of the same ABI); 6: feddat_attn_cls_fwd / _bwd (token-0-only attention of the last layer), fused step tail (feddat_head_gemm, feddat_head_ln_gelu, feddat_head_ln_bwd_full, feddat_dat_loss_fwd_bwd_single, feddat_adamw_multi, feddat_step_tick_multi), feddat_vqa_score_accumulate, feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
+#define FEDDAT_ABI_VERSION 8   /* 8: dynamic loss scale (GradScaler semantics on the device): feddat_wgrad_seg.grad_unscale_dev, feddat_ht_job.alpha_dev, feddat_adamw_group.skip_if / bak / restore_if, feddat_adapter_wgrad_reduce_checked, feddat_dat_loss_fwd_bwd_checked, feddat_dat_step_finish; 7: feddat_operand_format (bf16 / fp16 operand builds of the same ABI); 6: feddat_attn_cls_fwd / _bwd (token-0-only attention of the last layer), fused step tail (feddat_head_gemm, feddat_head_ln_gelu, feddat_head_ln_bwd_full, feddat_dat_loss_fwd_bwd_single, feddat_adamw_multi, feddat_step_tick_multi), feddat_vqa_score_accumulate, feddat_comm_create_timeout (FEDDAT_ETIMEOUT), feddat_set_debug_flags rejects the timing-only ablation bits (production build); 5: 8-bit gelu' epilogues (FEDDAT_EPI_GELU_G8 / _MUL_G8; feddat_vilt_layer_acts.u), feddat_adapter_wgrad_partial / _reduce, wgrad_reduce_now; 4: dropout entry points (feddat_dropout, feddat_attn2_*_dropout), feddat_comm_info; 3: feddat_ctx, feddat_set_debug_flags, feddat_comm_*, feddat_fedavg_allreduce, z_save / z_saved */
 int feddat_abi_version(void);
 #define FEDDAT_OPERANDS_BF16 0
 #define FEDDAT_OPERANDS_FP16 1
@@ -285,6 +285,7 @@ typedef struct {
     float scale;
     float grad_unscale;
     int reserved;
+    const float* grad_unscale_dev;   /* ABI 8: optional DEVICE float multiplied onto grad_unscale at run time (1 / the dynamic loss scale) */
 } feddat_wgrad_seg;
 long feddat_adapter_wgrad_workspace_elems(int nseg);
 int feddat_adapter_wgrad(const feddat_wgrad_seg* segs, int nseg, float* partials, long partials_elems, int H, int r,
@@ -298,6 +299,12 @@ int feddat_adapter_wgrad_partial(const feddat_wgrad_seg* segs, int nseg, float* 
                                  hipStream_t stream);
 int feddat_adapter_wgrad_reduce(float* const* grads_dev, int n, int nseg, const float* partials, long partials_stride,
                                 hipStream_t stream);
+/* ABI 8: the same reduction that also reports non-finite gradients -- nonfinite[s] (DEVICE int per segment) is OR-ed with 1
+ * when any gradient element of segment s (any launch) is inf / NaN; it is never cleared here.  This is the inf check of
+ * torch.cuda.amp.GradScaler.unscale_ (what accelerator.backward + optimizer.step run under fp16: task_trainer.py:302-308,
+ * 323-328), made where the loss scale leaves the gradients. */
+int feddat_adapter_wgrad_reduce_checked(float* const* grads_dev, int n, int nseg, const float* partials, long partials_stride,
+                                        int* nonfinite, hipStream_t stream);
 /* fp32 masters -> bf16 MFMA operand copies (r*H elements each).  All four are stored FRAGMENT-MAJOR -- the 64 lanes of
  * a wave read 64 consecutive 16-byte pieces, i.e. one contiguous 1 KiB burst per weight load -- with the contraction
  * slots of wd / wuT permuted along H (feature c at 32*(c/32) + 8*((c%16)/4) + 4*((c%32)/16) + c%4) so that they coincide
@@ -413,6 +420,7 @@ typedef struct feddat_ht_job {
     float* stats_out;
     int epi;
     const float* aux; long ld_aux;
+    const float* alpha_dev;    /* ABI 8: optional DEVICE float multiplied onto alpha at run time (the dynamic loss scale) */
 } feddat_ht_job;
 int feddat_head_gemm(const feddat_ht_job* jobs, int njobs, hipStream_t stream);
 /* y = LayerNorm(x) (stats [rows, 2] = {mean, rstd}), gelu_out = gelu(y): clf_norm0 + clf_actv0 (vilt.py:205-206) */
@@ -424,6 +432,10 @@ int feddat_head_ln_bwd_full(const float* dy, const float* x, const float* stats,
 /* feddat_dat_loss_fwd_bwd (below) as ONE launch; bit-identical outputs; scalars needs only 4 floats */
 int feddat_dat_loss_fwd_bwd_single(const float* logits, const float* teacher, const float* target, int B, int C, float temp,
                                    float* dlogits, float* scalars, hipStream_t stream);
+/* ABI 8: the same launch; *nonfinite (DEVICE int, may be NULL) is OR-ed with 1 when the loss L is inf / NaN (GradScaler would
+ * find the non-finite gradients this produces and skip the step) */
+int feddat_dat_loss_fwd_bwd_checked(const float* logits, const float* teacher, const float* target, int B, int C, float temp,
+                                    float* dlogits, float* scalars, int* nonfinite, hipStream_t stream);
 /* feddat_adamw_flat for up to FEDDAT_ADAMW_MAX_GROUPS parameter groups in one launch (n % 4 == 0, 16-byte aligned
  * buffers).  A group reads its schedule index / Adam step count at (state[0] + d_sched, state[1] + d_adam), so two
  * updates of one group inside a step (the task head: sub-steps 2b and 2b + 1) need no counter tick between them.
@@ -433,10 +445,30 @@ typedef struct feddat_adamw_group {
     float* p; const float* g; float* m; float* v; long n;
     const long* seg_off; const float* seg_wd; int nseg;
     const int* state; int d_sched, d_adam;
+    /* ABI 8 (all optional, NULL / 0 = the unconditional update): GradScaler's "skip the optimizer step of an overflowed
+     * backward" without leaving the hipGraph.  skip_if[k]: DEVICE ints; the group is left untouched when either is non-zero.
+     * bak (3 n floats): bak_mode 1 = the group's p | m | v BEFORE this update are stored there (also when skipped);
+     * bak_mode 2 = when *restore_if != 0 the group's p | m | v are restored from bak instead of being updated. */
+    const int* skip_if[2];
+    float* bak; int bak_mode;
+    const int* restore_if;
 } feddat_adamw_group;
 int feddat_adamw_multi(const feddat_adamw_group* groups, int ngroups, float base_lr, int warmup, int total, float beta1,
                        float beta2, float eps, hipStream_t stream);
 int feddat_step_tick_multi(int* const* states, const int* d_sched, const int* d_adam, int n, hipStream_t stream);
+/* ABI 8: end of one dat train_step under a DYNAMIC loss scale (torch.cuda.amp.GradScaler as accelerate drives it for
+ * mixed_precision fp16: accelerate_config.yaml:8, task_trainer.py:302-308,323-328), one 1-block launch, everything on the device:
+ *   flags[0] = sub-step B (P2: adapter_0 + head) saw a non-finite gradient / loss, flags[1] = sub-step A (P1: adapter_1 + head);
+ *   applied = flags[1] ? 0 : flags[0] ? 1 : 2 sub-steps took their optimizer + scheduler step (an overflow in A voids the whole
+ *   batch: B's forward already used A's head update -- DESIGN.md section 5b);
+ *   counters {sched_t, adam_t}: head += {applied, applied}; adapter_1 += {applied, applied >= 1}; adapter_0 += {applied, applied == 2}
+ *   (a skipped optimizer step skips its scheduler tick: accelerate/scheduler.py);
+ *   scaler_f = {scale, 1 / scale}: any flag -> scale *= backoff (0.5), growth tracker = 0; else tracker += 2 and, once it reaches
+ *   growth_interval, scale *= growth (2), tracker = 0 (GradScaler defaults: 65536 / 2 / 0.5 / 2000); scale stays within
+ *   [2^-14, 2^30]; scaler_i = {tracker, skipped sub-steps so far, batches with a skip so far, reserved};
+ *   flags are cleared for the next step. */
+int feddat_dat_step_finish(int* head_state, int* ad1_state, int* ad0_state, int* flags, float* scaler_f, int* scaler_i,
+                           float growth, float backoff, int growth_interval, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  loss.  L = (BCEWithLogits_mean(logits,target) * C + 9 * KL_batchmean(log_softmax(logits/3) ||

@@ -437,9 +437,15 @@ class DatClient:
     def lr_now(self) -> float:
         return self.lr * poly_lr_lambda(self.sched_t, self.warmup, self.max_steps)
 
-    def train_step(self, batch):
+    def train_step(self, batch, overflow=(False, False)):
         """task_trainer.py:280-330 (dat branch). Returns (loss_0, logits_all, logits_1, logits_0)
-        where loss_0 is what the reference returns: the BCE*num_labels term of P2 alone (:319,330)."""
+        where loss_0 is what the reference returns: the BCE*num_labels term of P2 alone (:319,330).
+        overflow = (A, B): what the reference does under mixed_precision fp16 (accelerate_config.yaml:8) when the scaled
+        backward of sub-step A (P1) / B (P2) produces an inf / NaN gradient -- torch.cuda.amp.GradScaler.step() does NOT call
+        optimizer.step() (accelerator.backward / optimizer.step: task_trainer.py:302-308,323-328) and accelerate's scheduler
+        wrapper does not tick (accelerate/scheduler.py: `if self.step_with_optimizer and ... optimizer.step_was_skipped: return`);
+        nothing else changes -- on this fp32 CPU path the gradients themselves are of course finite, the flag only injects the
+        skip.  (The halved loss scale has no effect on an fp32 trajectory.)"""
         P, d, task = self.P, self.d, self.task
         target = batch["target_scores"]
         with torch.no_grad():                                           # P0 :283-287
@@ -454,9 +460,10 @@ class DatClient:
             P[n].requires_grad_(False)
         if 1 not in self.opt_adapters:
             g1 = {n: g for n, g in g1.items() if "adapter_1_" not in n}
-        with torch.no_grad():
-            self.opt.step(P, g1, self.lr_now())
-        self.sched_t += 1
+        if not overflow[0]:
+            with torch.no_grad():
+                self.opt.step(P, g1, self.lr_now())
+            self.sched_t += 1
         n0 = trainable_names(P, task, 0)                                 # P2 :311-328
         for n in n0:
             P[n].requires_grad_(True)
@@ -467,9 +474,10 @@ class DatClient:
             P[n].requires_grad_(False)
         if 0 not in self.opt_adapters:
             g0 = {n: g for n, g in g0.items() if "adapter_0_" not in n}
-        with torch.no_grad():
-            self.opt.step(P, g0, self.lr_now())
-        self.sched_t += 1
+        if not overflow[1]:
+            with torch.no_grad():
+                self.opt.step(P, g0, self.lr_now())
+            self.sched_t += 1
         loss_0 = F.binary_cross_entropy_with_logits(logits_0.detach(), target, reduction="mean") * target.shape[1]
         self.last_L1, self.last_L0 = float(L1), float(L0)
         return loss_0, logits_all, logits_1.detach(), logits_0.detach()

@@ -267,16 +267,23 @@ def golden_g8(out, steps=40):
     print("G8 losses", losses[:3], "...", losses[-3:])
 
 
-def golden_g8b(out, steps=80, batch=32, snaps=(20, 40, 60, 80)):
+def golden_g8b(out, steps=80, batch=32, snaps=(20, 40, 60, 80), seed0=8000, all_elements=False):
     """G8b: the same realistic local round as G8, at configs[1]/[2]'s OWN batch size (B = 32, 384x384, S = 185) on the
     reference: len(loader) = steps, num_epochs = 15 (task_trainer.py:53-59: 1200 ticks, warm-up 120 ticks = 60 batches
     at steps = 80).  The update dW = W_after_n - W_init is stored at every n in `snaps`, so one fixture serves all round
-    lengths: per adapter_0 / adapter_1 / head tensor its L2 norm, mean |dW|, max |dW| and 1024 strided samples."""
+    lengths: per adapter_0 / adapter_1 / head tensor its L2 norm, mean |dW|, max |dW| and 1024 strided samples.
+    seed0: batch seeds seed0 .. seed0 + steps - 1 (8000 = the original fixture; any other value goes into the file name).
+    all_elements: additionally store EVERY element of every trainable tensor's update at the last snapshot and at its
+    half, as float16 of dW * 256 (|dW| <= 1e-2: the encoding error is < 3e-6 absolute, 300x below the 1e-3 bar) in a second
+    file g8b_round<N>_b<B>_all.npz, so that the GPU suite checks the tail of the distribution without stepping the oracle."""
     d = O.ViltDims(layers=12)
     model = build_reference_model(d, ["art"], bias_std=0.02)
     init = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    batches = [O.synthetic_batch(batch, 384, 8000 + s) for s in range(steps)]
-    rec = {"steps": np.array(steps), "batch": np.array(batch), "snaps": np.array(snaps)}
+    batches = [O.synthetic_batch(batch, 384, seed0 + s) for s in range(steps)]
+    rec = {"steps": np.array(steps), "batch": np.array(batch), "snaps": np.array(snaps), "seed0": np.array(seed0)}
+    full = {"steps": np.array(steps), "batch": np.array(batch), "seed0": np.array(seed0), "scale": np.array(256.0)}
+    full_snaps = (snaps[len(snaps) // 2 - 1], snaps[-1]) if all_elements else ()
+    full["snaps"] = np.array(full_snaps)
 
     def cap(step, m):
         n = step + 1
@@ -291,11 +298,82 @@ def golden_g8b(out, steps=80, batch=32, snaps=(20, 40, 60, 80)):
                 rec[f"s{n}::dmean::" + k] = np_(dw.abs().mean())
                 rec[f"s{n}::dmax::" + k] = np_(dw.abs().max())
                 rec[f"s{n}::dsamp::" + k] = np_(dw[idx])
+                if n in full_snaps:
+                    full[f"s{n}::dall::" + k] = (dw * 256.0).to(torch.float16).numpy().reshape(tuple(v.shape))
 
     losses, _ = ref_local_update(model, "art", batches, lr=1e-4, capture=cap)
     rec["losses"] = np.array(losses, np.float32)
-    np.savez_compressed(os.path.join(out, f"g8b_round{steps}_b{batch}.npz"), **rec)
+    tag = "" if seed0 == 8000 else f"_seed{seed0}"
+    np.savez_compressed(os.path.join(out, f"g8b_round{steps}_b{batch}{tag}.npz"), **rec)
+    if all_elements:
+        np.savez_compressed(os.path.join(out, f"g8b_round{steps}_b{batch}{tag}_all.npz"), **full)
     print("G8b losses", losses[:3], "...", losses[-3:])
+
+
+G15_OVERFLOW = {2: (True, False), 4: (False, True), 5: (True, True)}      # step -> (sub-step A, sub-step B) overflowed
+
+
+def golden_g15(out):
+    """G15: what the reference does when a scaled fp16 backward overflows -- pinned on accelerate's OWN optimizer / scheduler
+    wrappers (accelerate.optimizer.AcceleratedOptimizer + accelerate.scheduler.AcceleratedScheduler around the reference's
+    create_optimizer / HF poly schedule, torch.amp.GradScaler with its defaults), which is what accelerator.prepare() puts
+    around them under mixed_precision fp16 (accelerate_config.yaml:8; task_trainer.py:63,302-308,323-328).  CPU fp32 arithmetic
+    (the only kind this container has); the overflow is INJECTED: accelerator.backward = scaler.scale(loss).backward() as in
+    accelerate, then one adapter gradient element is set to inf in the sub-steps listed in G15_OVERFLOW.  2-layer model,
+    B = 4, 224 x 224, 7 steps.  Stored: losses, the scale and the scheduler index after every step, final trainable tensors."""
+    from accelerate import Accelerator
+    from accelerate.optimizer import AcceleratedOptimizer
+    from accelerate.scheduler import AcceleratedScheduler
+    from transformers import get_polynomial_decay_schedule_with_warmup
+    Accelerator(cpu=True)                       # initialises accelerate's process state (no mixed precision on CPU)
+    d = O.ViltDims(layers=2)
+    model = build_reference_model(d, ["art"], bias_std=0.02)
+    steps = 7
+    batches = [O.synthetic_batch(4, 224, 1500 + s) for s in range(steps)]
+    sd = model.state_dict()
+    for name in sd.keys():
+        if "adapter_1" in name:
+            sd[name.replace("adapter_1", "adapter_2")].data.copy_(sd[name].data.clone())
+    for n, p in model.named_parameters():
+        if "adapter_2" in n:
+            p.requires_grad = False
+    tr = make_trainer("art", 1e-4, steps, 15)
+    scaler = torch.amp.GradScaler("cpu")        # defaults: 65536, x2 / x0.5, growth interval 2000
+    calls = {"n": 0}
+
+    class Acc:
+        device = torch.device("cpu")
+
+        @staticmethod
+        def backward(loss):
+            scaler.scale(loss).backward()       # accelerate.Accelerator.backward under fp16
+            step, sub = divmod(calls["n"], 2)
+            calls["n"] += 1
+            if G15_OVERFLOW.get(step, (False, False))[sub]:
+                name = "adapter_1" if sub == 0 else "adapter_0"
+                tgt = [p for n, p in model.named_parameters() if name + "_up.weight" in n and p.grad is not None][0]
+                tgt.grad.view(-1)[7] = float("inf")
+    tr.accelerator = Acc()
+    opt = tr.create_optimizer(model, "dat")
+    sch = get_polynomial_decay_schedule_with_warmup(opt, num_warmup_steps=int(tr.max_steps * tr.warmup_ratio),
+                                                    num_training_steps=tr.max_steps, lr_end=0, power=1)
+    aopt = AcceleratedOptimizer(opt, device_placement=False, scaler=scaler)
+    asch = AcceleratedScheduler(sch, aopt, step_with_optimizer=True, split_batches=False)
+    model.zero_grad()
+    w = _Wrap(model)
+    rec = {"losses": [], "scale": [], "sched_t": []}
+    for step, b in enumerate(batches):
+        rec["losses"].append(float(tr.train_step(w, step, dict(b), aopt, asch)))
+        rec["scale"].append(scaler.get_scale())
+        rec["sched_t"].append(sch.last_epoch)
+    rec = {k: np.array(v, np.float32) for k, v in rec.items()}
+    rec["overflow_steps"] = np.array(sorted(G15_OVERFLOW), np.int64)
+    rec["overflow_ab"] = np.array([G15_OVERFLOW[k] for k in sorted(G15_OVERFLOW)], np.int64)
+    for k, v in model.state_dict().items():
+        if "adapter_0" in k or "adapter_1" in k or k.startswith("task_layer.art."):
+            put(rec, "after." + k, v)
+    np.savez_compressed(os.path.join(out, "g15_scaler_skip.npz"), **rec)
+    print("G15 losses", rec["losses"], "scale", rec["scale"], "sched_t", rec["sched_t"])
 
 
 def golden_g13(out):
@@ -360,12 +438,17 @@ def main():
     if "--only-g8" in sys.argv:          # [--steps N]: the same round at another length (g8_round<N>.npz; 80 = the longest
         steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 40      # len(loader) of configs[2])
         if "--batch" in sys.argv:        # --batch 32: the round at configs[1]'s own batch (g8b_round<N>_b<B>.npz,
-            golden_g8b(out, steps, int(sys.argv[sys.argv.index("--batch") + 1]))      # updates stored every 20 steps)
+            seed0 = int(sys.argv[sys.argv.index("--seed0") + 1]) if "--seed0" in sys.argv else 8000
+            golden_g8b(out, steps, int(sys.argv[sys.argv.index("--batch") + 1]), seed0=seed0,      # updates stored every 20 steps)
+                       all_elements="--all-elements" in sys.argv)
             return
         golden_g8(out, steps)
         return
     if "--only-g13" in sys.argv:
         golden_g13(out)
+        return
+    if "--only-g15" in sys.argv:
+        golden_g15(out)
         return
     if "--only-g6" in sys.argv:          # the other fixtures are unchanged; regenerate just this one
         golden_g6(out)
@@ -535,6 +618,7 @@ def main():
     np.savez_compressed(os.path.join(out, "g4_vilt12_384.npz"), **rec)
     golden_g6(out)
     golden_g8(out)
+    golden_g15(out)
     print("G4 losses", losses)
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)) // 1024, "KiB")

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol(f16):
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/feddat_hip.h but not exported"
-    assert lib.feddat_abi_version() == 7
+    assert lib.feddat_abi_version() == 8
     assert lib.feddat_operand_format() == (1 if f16 else 0)
     # the MFMA opcode is the build's operand format's, never the other one's (device code is embedded in the .so)
     import subprocess

@@ -284,14 +284,16 @@ def test_both_operand_formats_in_one_process_interleaved():
 
 
 def test_an_overflowing_loss_scale_is_reported_not_trained_through():
-    """No GradScaler skips an overflowed step here (the scale is static): a scale that pushes the gradient operands out of fp16's
-    range must surface as an error at the end of the local update, not as silently corrupted adapters.  2^36 x the ~1e-3
-    gradients of this model overflows 65 504; the default 2^14 does not."""
+    """With a STATIC scale (dynamic_loss_scale=False; the default is the device-side GradScaler of tests/test_dynscale_gpu.py) no
+    overflowed step is skipped: a scale that pushes the gradient operands out of fp16's range must surface as an error at the
+    end of the local update, not as silently corrupted adapters.  2^36 x the ~1e-3 gradients of this model overflows 65 504;
+    the default 2^14 does not."""
     from feddat_amd import engine, lib
     d = O.ViltDims(layers=2)
     for scale, ok in ((16384.0, True), (2.0 ** 36, False)):
         P = O.make_params(d, ["art"], bias_std=0.02)
-        eng = engine.ViltDatEngine(P, ["art"], DEV, batch=3, res=224, layers=2, operands="f16", loss_scale=scale)
+        eng = engine.ViltDatEngine(P, ["art"], DEV, batch=3, res=224, layers=2, operands="f16", loss_scale=scale,
+                                   dynamic_loss_scale=False)
         eng.begin_local_update("art", steps_per_epoch=2)
         for s in range(2):
             eng.train_step(_dev(O.synthetic_batch(3, 224, 300 + s)))

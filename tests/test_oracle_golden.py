@@ -96,6 +96,32 @@ def test_g3q_optimizer_membership_follows_flags(golden_dir):
             assert torch.equal(P[k], P0[k])
 
 
+def test_g15_gradscaler_skip_semantics(golden_dir):
+    """What the reference does when a scaled fp16 backward overflows, pinned on accelerate's own AcceleratedOptimizer /
+    AcceleratedScheduler + torch.amp.GradScaler around the reference's train_step (oracle/make_golden.py: golden_g15, overflow
+    injected into sub-step A of step 2, B of step 4, both of step 5): the oracle's train_step(overflow=(A, B)) -- skip that
+    sub-step's optimizer AND scheduler step, nothing else -- reproduces the weights and the scheduler index."""
+    g = load(golden_dir, "g15_scaler_skip.npz")
+    d = O.ViltDims(layers=2)
+    P = O.make_params(d, ["art"], bias_std=0.02)
+    steps = len(g["losses"])
+    ovf = {int(s): tuple(bool(x) for x in ab) for s, ab in zip(g["overflow_steps"], g["overflow_ab"])}
+    client = O.DatClient(P, d, "art", lr=1e-4, steps_per_epoch=steps)
+    losses, sched = [], []
+    for s in range(steps):
+        losses.append(float(client.train_step(O.synthetic_batch(4, 224, 1500 + s), overflow=ovf.get(s, (False, False)))[0]))
+        sched.append(client.sched_t)
+    assert sched == [int(x) for x in g["sched_t"]], (sched, g["sched_t"])
+    assert np.allclose(losses, g["losses"], rtol=2e-5, atol=1e-4), (losses, g["losses"])
+    keys = [k[len("after."):] for k in g if k.startswith("after.")] + \
+           [k.split("::", 1)[1][len("after."):] for k in g if k.startswith("samp::after.")]
+    assert len(keys) > 20
+    for k in keys:
+        assert max_abs_diff_vs_golden(g, "after." + k, P[k]) < TOL_W, k
+    # GradScaler's own bookkeeping, for the record of what the device-side scaler mirrors: x0.5 per overflowed sub-step
+    assert [float(x) for x in g["scale"]] == [65536.0, 65536.0, 32768.0, 32768.0, 16384.0, 4096.0, 4096.0]
+
+
 def test_g5_fedavg_and_round(golden_dir):
     g = load(golden_dir, "g5_fedavg.npz")
     keys = [k[4:] for k in g if k.startswith("avg.")]
