@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -267,33 +268,42 @@ def hetero_steps(K, rank):
 
 
 def make_exchange(eng, world, rank, dist):
-    """The round's FedAvg exchange.  Real launch (one GPU per rank, backend "nccl"): the C-ABI collective
-    feddat_fedavg_allreduce on a communicator made through feddat_comm_* (RCCL bound by dlopen, unique id shipped over the
-    torch.distributed rendezvous) -- not torch.distributed's all_reduce.  The single-GPU test rig (several ranks on one
-    device, backend gloo: RCCL refuses two ranks per device) keeps the torch.distributed path."""
+    """The round's FedAvg exchange.  Real launch (one GPU per rank): the C-ABI collective feddat_fedavg_allreduce on a
+    communicator made through feddat_comm_* (RCCL bound by dlopen, unique id shipped over the torch.distributed rendezvous) --
+    not torch.distributed's all_reduce.  The torch.distributed group is only the HOST-side rendezvous (barriers, the id, the
+    per-rank rows) and defaults to gloo, so each GPU holds exactly ONE RCCL communicator -- this one -- and a failure of RCCL
+    cannot be confused with a failure of the rendezvous (FEDDAT_DIST_BACKEND=nccl puts the rendezvous on RCCL as well).  The
+    single-GPU test rig (FEDDAT_FORCE_DEVICE: several ranks on one device, where RCCL refuses the duplicate device) keeps the
+    torch.distributed path."""
     if dist is None:
         return None, None
     from feddat_amd.fedavg import allreduce_average, make_rccl_comm
     nbytes = eng.comm_flat().numel() * 4
     why = "single-GPU test rig"
-    if dist.get_backend() == "nccl":
+    if os.environ.get("FEDDAT_FORCE_DEVICE") is None:
         comm, err = None, ""
+        t_init = time.perf_counter()
         try:
             comm = make_rccl_comm(world, rank)
             info = comm.info()
         except Exception as e:      # noqa: BLE001 -- reported on the line; the ranks agree on the fallback below
             comm, err = None, f"{type(e).__name__}: {e}"
-        ok = torch.tensor([1.0 if comm is not None else 0.0], device=eng.dev)
+        init_ms = (time.perf_counter() - t_init) * 1e3
+        ok = torch.tensor([1.0 if comm is not None else 0.0], device=eng.dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
         if float(ok) > 0:
             v = info["rccl_version"]
             desc = {"library": "RCCL %d.%d.%d (C ABI: feddat_fedavg_allreduce)" % (v // 10000, v // 100 % 100, v % 100),
                     "rccl_version": v, "path": "feddat_comm_create_timeout -> ncclCommInitRank -> feddat_fedavg_allreduce",
+                    "rendezvous": "torch.distributed " + dist.get_backend() + " (host side only)",
+                    "rccl_communicators_per_gpu": 2 if dist.get_backend() == "nccl" else 1, "init_ms": round(init_ms, 1),
                     "ranks_requested": world, "ranks_in_communicator": info["ranks"], "payload_bytes": nbytes, "per_round": 1}
             if info["ranks"] != world:      # a communicator that does not span --gpus ranks measures something else: fail loudly
                 raise SystemExit(f"bench.py: feddat_comm_info reports {info['ranks']} ranks in the communicator, --gpus {world} "
                                  f"were asked for (rank {rank}); refusing to print a throughput line")
             return (lambda: allreduce_average(eng, world, comm=comm)), desc
+        if comm is not None:
+            comm.close()
         why = "C-ABI communicator unavailable on some rank" + (f" ({err[:200]})" if err else "")
     desc = {"library": "torch.distributed " + dist.get_backend() + f" ({why})", "path": "torch.distributed.all_reduce",
             "ranks_requested": world, "ranks_in_communicator": dist.get_world_size(), "payload_bytes": nbytes, "per_round": 1,
@@ -509,7 +519,7 @@ def bench_albef(args, world, rank, dev, dist):
                                    f"batch={B}/client, {args.res}x{args.res}, 25-token questions, one 4-token answer each, "
                                    f"BERT dropout {args.albef_dropout}" + (" (0 = the parity configuration, SURVEY 8d)"
                                                                             if args.albef_dropout == 0 else "") +
-                                   f", {'fp16 MFMA operands (loss scale 2^14)' if eng.operands == 'f16' else 'bf16 MFMA operands'}",
+                                   f", {'fp16 MFMA operands (static loss scale 2^14)' if eng.operands == 'f16' else 'bf16 MFMA operands (the ALBEF engine default: 7.6e-4 on the reference 40-step full-size round, fp16: 3.2e-4)'}",
                        "clients": world, "hip_graph": use_graph, "hetero_steps": bool(args.hetero), "collective": coll,
                        "last_loss_0": round(loss, 4)},
             "samples_per_sec_per_gpu": round(sps / world, 2),
@@ -550,7 +560,9 @@ def roofline_block(L, eng, batches, gemms):
         kt["frac"] = round(ach * tsum / (kt["ms_per_step"] * 1e-3) / PEAK_BF16, 4)
     second = in_step_info.pop("second", None)
     return {"kernel_trace": kt, "second": second,
-            "kernel": "gemm_nt_v3_kernel / gemm_nt_v2_kernel (K1, frozen-linear bf16 MFMA GEMM; all launches of one train_step, "
+            "kernel": "gemm_nt_v3_kernel / gemm_nt_v2_kernel (K1, frozen-linear "
+                      + ("fp8 (e4m3, block-scaled) + bf16" if eng.fp8 else "fp16" if eng.operands == "f16" else "bf16")
+                      + " MFMA GEMM; all launches of one train_step, "
                       "FLOP-weighted, durations measured in-step)",
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16, 4), "frac_in_step": round(ach / PEAK_BF16, 4),
@@ -627,7 +639,9 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("FEDDAT_DIST_BACKEND", "nccl")
+        # host-side rendezvous only (barriers, the communicator's unique id, the per-rank rows): gloo by default, so that the
+        # data path's C-ABI communicator is the single RCCL communicator each GPU holds (make_exchange)
+        backend = os.environ.get("FEDDAT_DIST_BACKEND", "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -720,8 +734,13 @@ def main():
                 "round): mean |ddW| / mean |dW| 0.165, update norm within 4.1 %, max |ddW| 2.9e-3 adapters / 3.9e-3 head (the default "
                 f"fp16-operand engine on the same round: 0.004, 0.2 %, 3.0e-4), batch={B}/client, ")
         else:
-            workload = (f"configs[1]: ViLT-B/32 FedDAT, 1 client per MI355X, {'fp16' if eng.operands == 'f16' else 'bf16'} MFMA operands"
-                        f"{' (loss scale 2^14)' if eng.operands == 'f16' else ''}, fp32 accumulate / masters, batch={B}/client, ")
+            workload = ("configs[1]" + (" with fp16 operands (BASELINE.json's configs[1] string says bf16: same operand width and MFMA "
+                                        "rate; the bf16 step is in other_operand_format)" if eng.operands == "f16" else "")
+                        + f": ViLT-B/32 FedDAT, 1 client per MI355X, {'fp16' if eng.operands == 'f16' else 'bf16'} MFMA operands"
+                        + (f" (dynamic loss scale, GradScaler semantics on the device, initial 2^{int(math.log2(eng.loss_scale))})"
+                           if eng.operands == "f16" and eng.scaler_state()["dynamic"] else
+                           f" (static loss scale 2^{int(math.log2(eng.loss_scale))})" if eng.operands == "f16" else "")
+                        + f", fp32 accumulate / masters, batch={B}/client, ")
         workload += "384x384 synthetic + 40-token questions, MKD on" + (
             f"; {world} clients + FedAvg all-reduce per round (configs[2])" if world > 1 else "")
         out = {

@@ -45,7 +45,11 @@ class AlbefDatEngine:
                  operands: str = "bf16", loss_scale: Optional[float] = None):
         """operands="f16": every 16-bit MFMA operand in IEEE half (libfeddat_hip_f16.so) with a power-of-two loss scale on
         dL/dlogits (feddat_lm_loss_fwd_bwd's grad_scale, default 2^14) that leaves through feddat_wgrad_seg.grad_unscale -- the
-        ViLT engine's scheme (engine.ViltDatEngine); the default here stays bf16."""
+        ViLT engine's scheme (engine.ViltDatEngine, there with the dynamic scaler).  The default here is bf16 -- in this class, in
+        train.main (--encoder_name albef_no_distill without --mixed_precision) and in bench.py --workload albef alike: against the
+        reference's own full-size 40-step round (tests/golden/g11b_albef_full_round40.npz) bf16 operands land at 7.6e-4 on the
+        worst adapter element (mean ratio 0.024), inside north_star's 1e-3; fp16 operands at 3.2e-4 (0.005) for ~2 % of the step
+        (tests/test_sizes_gpu.py::test_albef_full_size_round_of_40_steps_vs_reference_golden asserts both)."""
         if operands not in L.OPERAND_DTYPE:
             raise L.FeddatHipError(f"operands must be 'bf16' or 'f16', got {operands!r}")
         self.operands, self.op_dtype = operands, L.OPERAND_DTYPE[operands]

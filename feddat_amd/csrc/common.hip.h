@@ -59,7 +59,8 @@ int fd_set_max_lds(const void* kernel, int bytes);     // hipFuncAttributeMaxDyn
 // tools/ through lib.use_ablation_build()).  The production library compiles them out: FD_ABL(x) is the constant 0 there, and
 // feddat_set_debug_flags rejects every bit outside FD_DEBUG_SELECT_BITS, which only choose among kernels that give the same
 // (bit-identical) results: 1 / 2 everything on the two-group / one-wave-per-SIMD GEMM kernel (2 in attention.hip: the
-// two-role backward), 32 / 64 force 192- / 256-row tiles, 128 no small-tile kernel, 256 the K = 32 fp8 MFMA, bit 23 one
+// two-role backward), 1 | 2 together the DUAL form of the persistent GEMM (two independent 128 x 192 workgroups per CU; with 64:
+// only where it has at least two rounds of tiles), 32 / 64 force 192- / 256-row tiles, 128 no small-tile kernel, 256 the K = 32 fp8 MFMA, bit 23 one
 // attention-backward block per pair, bit 27 no 160-row GEMM tiles, bits 28..31 cap the persistent GEMM grid at 16 x value workgroups.
 #ifdef FEDDAT_ABLATE
 #define FD_ABL(x) (x)

@@ -970,6 +970,15 @@ __device__ __forceinline__ void mfma_agpr_first(f32x4& c, const bf16x8& a, const
     asm volatile(FD_MFMA_16X16X32_ASM " %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
+// the same with the accumulators in ordinary VGPRs (DUAL: 256 registers per wave, which hipcc splits 128 / 128 as soon as one
+// operand is constrained to an AGPR -- with "v" the whole budget is one file)
+__device__ __forceinline__ void mfma_vgpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile(FD_MFMA_16X16X32_ASM " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_vgpr_first(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile(FD_MFMA_16X16X32_ASM " %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
+
 // (A variant that DEFERRED a tile's epilogue into the next tile's k-loop was built on this kernel -- accumulators copied
 // aside at the boundary, one twelfth of the stores per k-tile between the MFMAs -- and was bit-exact, but slower: on this ISA
 // loads and stores share vmcnt and complete out of order with respect to each other, so with one store in flight every
@@ -990,9 +999,15 @@ template <int RT> struct V3Cfg {
 // sub-tiles' conversions / activation math and their 8-byte row-per-lane stores (inline asm: invisible to hipcc's vmcnt
 // bookkeeping, so the staging loads keep their counted waits) plus the aux / residual loads.  Answers one question before
 // the real thing is built: does the k-loop absorb the epilogue's issue slots and stores?
-template <int EPI, int RT, int FAKE = 0>
-__global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
+// DUAL (round 6, "v4"): the same kernel as TWO independent 4-wave workgroups per CU (RT = 4: 128 x 192 tiles, 64 x 96 per wave,
+// 256 registers per wave, 2 x 80 KiB of LDS -- the epilogue's staging buffer aliases the k-tile stage the tile has just
+// consumed).  The two workgroups share nothing and drift apart by themselves: whenever one is in its epilogue (VALU / LDS /
+// stores) the other has the matrix pipe to itself, so the epilogues -- 25-30 % of the code-epilogue launches, which nothing
+// overlapped -- run under the neighbour's k-loop.  Same k order as every other tile height: bit-identical results.
+template <int EPI, int RT, int FAKE = 0, bool DUAL = false>
+__global__ __launch_bounds__(256, DUAL ? 2 : 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     using Cfg = V3Cfg<RT>;
+    static_assert(!DUAL || (RT == 4 && 4 * V2_EPI_WAVE <= Cfg::STAGE), "the dual form: 128-row tiles, staging inside one stage");
     constexpr int NP = Cfg::NP, NM = 6 * RT;                  // MFMAs per k-half
     // one filler per MFMA.  Half 0 has NM slots: the NP fragment reads of half 1, then every piece's write into the other
     // stage (all NP of them: the stage must be complete at the barrier) and as many reloads as still fit (LH0); the
@@ -1086,8 +1101,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
     stream_advance();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (!DUAL) {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) read_frag(0, 0, q);
+        for (int q = 0; q < NP; ++q) read_frag(0, 0, q);
+    }
 
     auto fake_slice = [&](const int sidx, const int kt) {       // FAKE only: sub-tile (2 sidx, sidx) stands in for slice kt
         const int row = min(m0 + wm * (16 * RT) + 32 * sidx + frow, g.M - 1);
@@ -1113,9 +1130,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
         const bf16* dst = g.out_bf16 + (size_t)row * g.ldo16 + col;
         asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(o16) : "memory");
     };
-    // one k-tile; FIRST: the tile's first k-tile, whose half 0 starts the accumulators from the constant 0
-    auto k_tile = [&](auto first_tag, const int st, const int kt = 0) {
+    // one k-tile; FIRST: the tile's first k-tile, whose half 0 starts the accumulators from the constant 0.
+    // MODE 0: the continuous k-tile stream across tiles (stream_advance).  DUAL, where every tile is self-contained (prologue,
+    // k-loop, epilogue: nothing but the accumulators is live across the epilogue, which therefore has the wave's whole VGPR half):
+    // MODE 1 = a k-tile with both successors (writes k-tile kt + 1, loads kt + 2), 2 = the penultimate (no loads), 3 = the last
+    // (MFMAs and its own half-1 fragments only).
+    auto k_tile = [&](auto first_tag, const int st, const int kt, auto mode_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool WR = MODE != 3, LD = MODE < 2, NXT = MODE != 3;
+        if (MODE != 0) l_kt = kt + 2;
         // ---- half 0: MFMA (i, j) then filler #(6 i + j): NP fragment reads, then per piece its write and its reload
 #pragma unroll
         for (int i = 0; i < RT; ++i)
@@ -1129,14 +1153,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
                     read_frag(st, 1, f);
                 } else if (f < NP + 2 * LH0) {             // k-tile j+1 -> the other stage, piece by piece, each register
                     const int q = f - NP;                  // refilled with k-tile j+2 right behind its write (all writes in a
-                    if ((q & 1) == 0) lwrite_piece(q >> 1, st ^ 1);   // row, then the loads, with the barrier pulled forward:
-                    else gload_piece(q >> 1);              // 10 % slower -- the four waves' writes collide)
+                    if ((q & 1) == 0) { if (WR) lwrite_piece(q >> 1, st ^ 1); }   // row, then the loads, with the barrier pulled forward:
+                    else { if (LD) gload_piece(q >> 1); }  // 10 % slower -- the four waves' writes collide)
                 } else if (f < 2 * NP + LH0) {             // (RT = 5) the last pieces' writes; their reloads wait for half 1
-                    lwrite_piece(f - NP - LH0, st ^ 1);
+                    if (WR) lwrite_piece(f - NP - LH0, st ^ 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        if (LH0 == NP) stream_advance();
+        if (LH0 == NP && MODE == 0) stream_advance();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // ---- half 1: the fragments of the next k-tile's half 0 behind the first two MFMA rows
@@ -1148,35 +1172,120 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_v3_kernel(GemmArgsV2 a) {
                 const int f = 6 * i + j;
                 __builtin_amdgcn_sched_barrier(0);
                 if (LH0 < NP && f < NP - LH0) {            // deferred reloads (same stream position as half 0's), then advance
-                    gload_piece(LH0 + f);
-                    if (f == NP - LH0 - 1) stream_advance();
+                    if (LD) gload_piece(LH0 + f);
+                    if (f == NP - LH0 - 1 && MODE == 0) stream_advance();
                 }
-                if (f >= 12 && f < 12 + NP) read_frag(st ^ 1, 0, f - 12);
+                if (NXT && f >= 12 && f < 12 + NP) read_frag(st ^ 1, 0, f - 12);
                 if (FAKE && RT == 6 && (f == 28 || f == 30 || f == 32) && kt < 12) fake_slice((f - 28) / 2, kt);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
-
-    char* stg = smem + Cfg::EPI_OFF + wave * V2_EPI_WAVE;
-    int it = 0;
-    for (int tile = 0; tile < my_tiles; ++tile) {
-        k_tile(std::true_type{}, it & 1, 0);
-        ++it;
-        for (int kt = 1; kt < nk; ++kt, ++it) k_tile(std::false_type{}, it & 1, kt);
+    auto run_epilogue = [&](char* stg) {
         // The compiler cannot see that the asm blocks are MFMAs: it would read their results right behind them.  The wait
         // states are attached to the accumulators themselves (in / out operands), row by row.
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
-            asm volatile("s_nop 15\n\ts_nop 15"
-                         : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
+        for (int i = 0; i < RT; ++i) {
+            if (DUAL)
+                asm volatile("s_nop 15\n\ts_nop 15"
+                             : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]), "+v"(acc[i][4]), "+v"(acc[i][5]));
+            else
+                asm volatile("s_nop 15\n\ts_nop 15"
+                             : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
+        }
         if (!FD_ABL(a.dbg & 8) && !FAKE) {
             const int mb = m0 + wm * (16 * RT), nb = n0 + wn * 96, me = m_last + 1;
-            if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU)
+            if (EPI == FEDDAT_EPI_BF16 || EPI == FEDDAT_EPI_GELU || EPI == FEDDAT_EPI_MUL_DGELU || EPI == FEDDAT_EPI_GELU_G8 ||
+                EPI == FEDDAT_EPI_MUL_G8)
                 v2_epilogue_bf16<EPI, RT, true>(g, acc, stg, mb, nb, me, lane);
             else
                 v2_epilogue<EPI, RT>(g, acc, stg, mb, nb, me, lane);
         }
-        if (tile + 1 < my_tiles) v2_tile_coords(a, bid + (tile + 1) * grid, total, m0, n0, m_last);
+    };
+
+    if constexpr (DUAL) {
+        // Every tile on its own: prologue (k-tile 0 -> stage 0, k-tile 1 in flight, fragments of half 0), k-loop, epilogue; nothing
+        // but the accumulators is live across the epilogue.  ONE fragment set (128 VGPRs per wave next to 128 AGPRs: two sets +
+        // the staging registers do not fit): half 0's MFMAs carry the whole staging of the k-tile as fillers (10 writes, 10
+        // loads in 24 slots), then the half-1 fragments are read into the same registers ahead of the barrier, half 1's MFMAs
+        // run bare, and the next k-tile's half-0 fragments follow them -- the two fragment waits per k-tile are covered by the
+        // OTHER workgroup's wave on the same SIMD, not by this wave's own MFMAs.  The staging buffer of the epilogue aliases the
+        // stage of k-tile nk - 2 (dead since that k-tile's barrier; nothing is written into it afterwards); the barrier behind
+        // the epilogue releases both stages for the next tile's prologue.
+        bf16x8 ga[RT], gb[6];
+        auto rd = [&](int stage, int ks) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                gb[j] = *reinterpret_cast<const bf16x8*>(smem + stage * Cfg::STAGE + Cfg::TILE_A + frag_off[ks] + (wn * 96 + j * 16) * 128);
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                ga[i] = *reinterpret_cast<const bf16x8*>(smem + stage * Cfg::STAGE + frag_off[ks] + (wm * (16 * RT) + i * 16) * 128);
+        };
+        auto k_tile_d = [&](auto first_tag, const int st, const int kt, auto mode_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr int MODE = decltype(mode_tag)::value;       // 1: writes k-tile kt + 1, loads kt + 2; 2: no loads; 3: the last
+            constexpr bool WR = MODE != 3, LD = MODE < 2;
+            l_kt = kt + 2;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    if (FIRST) mfma_vgpr_first(acc[i][j], gb[j], ga[i]);
+                    else mfma_vgpr(acc[i][j], gb[j], ga[i]);
+                    const int f = 6 * i + j;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (f < 2 * NP) {
+                        if ((f & 1) == 0) { if (WR) lwrite_piece(f >> 1, st ^ 1); }
+                        else { if (LD) gload_piece(f >> 1); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            rd(st, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    mfma_vgpr(acc[i][j], gb[j], ga[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if (WR) rd(st ^ 1, 0);
+        };
+        static_assert(2 * NP <= NM, "the whole staging of a k-tile rides behind half 0's MFMAs");
+        for (int tile = 0; tile < my_tiles; ++tile) {
+            if (tile) {
+                v2_tile_coords(a, bid + tile * grid, total, m0, n0, m_last);
+                piece_ptrs(m0, m_last, n0);
+                l_kt = 0;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) gload_piece(p);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) lwrite_piece(p, 0);
+                l_kt = 1;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) gload_piece(p);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            rd(0, 0);
+            k_tile_d(std::true_type{}, 0, 0, std::integral_constant<int, 1>{});
+            for (int kt = 1; kt < nk - 2; ++kt) k_tile_d(std::false_type{}, kt & 1, kt, std::integral_constant<int, 1>{});
+            k_tile_d(std::false_type{}, (nk - 2) & 1, nk - 2, std::integral_constant<int, 2>{});
+            k_tile_d(std::false_type{}, (nk - 1) & 1, nk - 1, std::integral_constant<int, 3>{});
+            run_epilogue(smem + (nk & 1) * Cfg::STAGE + wave * V2_EPI_WAVE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        char* stg = smem + Cfg::EPI_OFF + wave * V2_EPI_WAVE;
+        int it = 0;
+        for (int tile = 0; tile < my_tiles; ++tile) {
+            k_tile(std::true_type{}, it & 1, 0, std::integral_constant<int, 0>{});
+            ++it;
+            for (int kt = 1; kt < nk; ++kt, ++it) k_tile(std::false_type{}, it & 1, kt, std::integral_constant<int, 0>{});
+            run_epilogue(stg);
+            if (tile + 1 < my_tiles) v2_tile_coords(a, bid + (tile + 1) * grid, total, m0, n0, m_last);
+        }
     }
 }
 
@@ -1431,8 +1540,30 @@ static const V2Kernel (*v3_kernel_table())[5] {        // [0]: 192-row tiles (RT
          gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 7>, gemm_nt_v3_kernel<FEDDAT_EPI_F32, 7>}};
     return kernels;
 }
+// "v4": two independent 128-row workgroups per CU (gemm_nt_v3_kernel<E, 4, 0, true>), every epilogue incl. the 8-bit codes
+static const V2Kernel* v4_kernel_table() {
+    static const V2Kernel kernels[7] = {
+        gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 4, 0, true>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 4, 0, true>,
+        gemm_nt_v3_kernel<FEDDAT_EPI_GELU, 4, 0, true>, gemm_nt_v3_kernel<FEDDAT_EPI_MUL_DGELU, 4, 0, true>,
+        gemm_nt_v3_kernel<FEDDAT_EPI_F32, 4, 0, true>, gemm_nt_v3_kernel<FEDDAT_EPI_GELU_G8, 4, 0, true>,
+        gemm_nt_v3_kernel<FEDDAT_EPI_MUL_G8, 4, 0, true>};
+    return kernels;
+}
+constexpr int V4_LDS = 2 * V3Cfg<4>::STAGE;      // 80 KiB: two workgroups fill the CU's 160 KiB exactly
 static int v3_lds(int which) {
     return which == 1 ? V3Cfg<8>::LDS : which == 2 ? V3Cfg<5>::LDS : which == 3 ? V3Cfg<7>::LDS : V3Cfg<6>::LDS;
+}
+
+// diagnostics: resident workgroups per CU the runtime grants the dual form (2 = the design point; 1 = it degenerates into a
+// one-wave-per-SIMD kernel with 128-row tiles)
+extern "C" int feddat_gemm_dual_blocks_per_cu(int* out) {
+    FD_CHECK_ARG(out);
+    const V2Kernel k = v4_kernel_table()[FEDDAT_EPI_BF16];
+    if (fd_set_max_lds((const void*)k, V4_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k, 256, V4_LDS) != hipSuccess) return FEDDAT_ELAUNCH;
+    *out = n;
+    return FEDDAT_OK;
 }
 
 int fd_prepare_gemm_kernels() {
@@ -1443,6 +1574,8 @@ int fd_prepare_gemm_kernels() {
         for (int e = 0; e < 7; ++e)
             if (fd_set_max_lds((const void*)v2_kernel_table()[w][e], w ? V2Cfg<4>::LDS : V2Cfg<3>::LDS) != FEDDAT_OK)
                 return FEDDAT_ELAUNCH;
+    for (int e = 0; e < 7; ++e)
+        if (fd_set_max_lds((const void*)v4_kernel_table()[e], V4_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     if (fd_set_max_lds((const void*)gemm_nt_mid_kernel, MID_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     return fd_set_max_lds((const void*)gemm_nt_kernel, 4 * TILE_BYTES);
 }
@@ -1578,7 +1711,9 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     if (use_v2 && M < 4096 && epi != FEDDAT_EPI_GELU_G8 && epi != FEDDAT_EPI_MUL_G8 && !(fd_debug_flags() & 1)) {
         int n_cu = 0;
         if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
-        small_grid = ((M + 191) / 192) * (N / V2_BN) * 10 < n_cu * 6;
+        // (debug flag 128 = "no small-tile kernel": such launches stay on the persistent kernel instead of falling through to the
+        //  128 x 128 kernel, which needs N % 128 == 0 -- N = 192 x odd would silently lose its tail columns there)
+        small_grid = ((M + 191) / 192) * (N / V2_BN) * 10 < n_cu * 6 && !(fd_debug_flags() & 128);
         if (small_grid) use_v2 = false;
     }
     FD_CHECK_ARG((N % BN == 0 || use_v2 || ((M < 1024 || small_grid) && N % 64 == 0)) && K % BK == 0);
@@ -1618,7 +1753,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
     if (use_v2) {
         GemmArgsV2 a2;
         a2.g = g;
-        const int dbg = fd_debug_flags();      // tools/ ablations only (feddat_set_debug_flags); 0 in production
+        int dbg = fd_debug_flags();            // tools/ ablations only (feddat_set_debug_flags); 0 in production
         a2.dbg = dbg;
         int n_cu = 0;
         if (fd_device_cus(&n_cu) != FEDDAT_OK) return FEDDAT_ELAUNCH;
@@ -1642,6 +1777,25 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
             o.tn_per = tiles_n / o.nx;
             return (o.tiles_m * tiles_n + n_cu - 1) / n_cu;     // rounds of the persistent grid
         };
+        // The DUAL form (selection flags 1 | 2 together: every persistent launch; 1 | 2 | 64: only launches of at least two full
+        // rounds of the doubled grid, e.g. N = 3072 at M = 11 840: 96 x 16 tiles = 3.0 rounds of 512): two independent 128-row
+        // workgroups per CU.  Measured, not the default: profiles/r06_gemm_dual_ab.txt, DESIGN.md section 7e.
+        if ((dbg & 3) == 3) {
+            GemmArgsV2 a1 = a2;
+            const int cu1 = n_cu;
+            n_cu *= 2;
+            plan(128, a1);
+            n_cu = cu1;
+            const int total1 = a1.tiles_m * tiles_n;
+            if (!(dbg & 64) || total1 >= 4 * n_cu) {
+                const V2Kernel k4 = v4_kernel_table()[epi];
+                if (fd_set_max_lds((const void*)k4, V4_LDS) != FEDDAT_OK) return FEDDAT_ELAUNCH;
+                hipLaunchKernelGGL(k4, dim3(total1 < 2 * n_cu ? total1 : 2 * n_cu), dim3(256), V4_LDS, stream, a1);
+                FD_LAUNCH_RET();
+            }
+            dbg &= ~3;              // not taken: the production routing below
+            a2.dbg = dbg;
+        }
         GemmArgsV2 a3 = a2, a4 = a2, a5 = a2, a7 = a2;
         const int rounds3 = plan(192, a3), rounds4 = plan(256, a4), rounds5 = plan(160, a5), rounds7 = plan(224, a7);
         // a 256-row tile costs about 1.2x a 192-row tile (48 vs 36 MFMAs per k-tile and wave, L phase 20 vs 18 reads)
@@ -1656,7 +1810,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         // nothing cache-warm, it is behind (86 / 89 us against 82 / 81: tools/step_breakdown.py --detail); debug flag 1
         // keeps everything on v2, flag 2 forces v3
         const bool v3_pick = epi != FEDDAT_EPI_GELU && epi != FEDDAT_EPI_MUL_DGELU && !g8;
-        if (g8 && (dbg & (2 | 512))) return FEDDAT_EINVAL;      // the code epilogues exist on the two-group kernel only
+        if (g8 && (dbg & (2 | 512))) return FEDDAT_EINVAL;      // the code epilogues exist on the two-group (and the dual) kernel only
 #ifdef FEDDAT_ABLATE
         if (dbg & 512) {        // tools/gemm_defer_probe.py: the deferred-epilogue timing probe (RT = 6; wrong results)
             static const V2Kernel fk[5] = {gemm_nt_v3_kernel<FEDDAT_EPI_BF16, 6, 1>, gemm_nt_v3_kernel<FEDDAT_EPI_RESID_F32, 6, 1>,
@@ -1706,6 +1860,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         hipLaunchKernelGGL(gemm_nt_mid_kernel, dim3(tm * (N / 64)), dim3(256), MID_LDS, stream, g);
         FD_LAUNCH_RET();
     }
+    FD_CHECK_ARG(v1_ok);      // the 128 x 128 kernel has no column tail
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
     if (fd_set_max_lds((const void*)gemm_nt_kernel, 4 * TILE_BYTES) != FEDDAT_OK) return FEDDAT_ELAUNCH;
     hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, stream, g);

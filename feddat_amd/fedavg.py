@@ -67,7 +67,11 @@ def make_rccl_comm(world: int, rank: int):
     # every rank says whether it can bind RCCL BEFORE anyone enters the collective ncclCommInitRank: a rank without a loadable
     # librccl makes all ranks fail fast here, together, instead of its peers waiting out the bootstrap watchdog
     flags = [None] * world
-    dist.all_gather_object(flags, bool(L.rccl_available()))
+    try:                    # the gather below is a collective: EVERY rank must reach it, whatever went wrong locally
+        mine = bool(L.rccl_available())
+    except Exception:       # noqa: BLE001 -- e.g. the library itself is missing on this rank
+        mine = False
+    dist.all_gather_object(flags, mine)
     if not all(flags):
         raise L.FeddatHipError(f"RCCL is not loadable on rank(s) {[r for r, f in enumerate(flags) if not f]}")
 

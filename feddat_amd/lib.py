@@ -95,6 +95,7 @@ _SIGS = {
     "feddat_comm_info": [vp, vp, vp, vp],
     "feddat_gemm_bf16_nt": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
     "feddat_gemm_skinny_workspace_elems": [i32, i32, i32],
+    "feddat_gemm_dual_blocks_per_cu": [vp],
     "feddat_gemm_fp8_nt": [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp],
     "feddat_layernorm_bwd_dx_fp8": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp],
     "feddat_gemm_fp8mx_nt": [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp],
@@ -283,10 +284,18 @@ class Context:
             pass
 
 
+def gemm_dual_blocks_per_cu() -> int:
+    """Workgroups per CU the runtime grants the dual form of the persistent GEMM (diagnostics)."""
+    n = C.c_int(0)
+    _chk(load().feddat_gemm_dual_blocks_per_cu(C.byref(n)), "feddat_gemm_dual_blocks_per_cu")
+    return n.value
+
+
 def rccl_available() -> bool:
     """True when the library could bind RCCL in this process (feddat_comm_info without a communicator: version only)."""
     v = C.c_int(0)
-    return load().feddat_comm_info(None, C.byref(v), None, None) == 0 and v.value > 0
+    return load().feddat_comm_info(None, C.byref(v), None, None) == 0      # (ELAUNCH when RCCL could not be bound; the version
+    #                                                                          symbol itself is optional: diagnostics only)
 
 
 class RcclComm:

@@ -314,9 +314,11 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--albef_dims", type=str, default="",
                    help="ALBEF only: override depths for quick runs, e.g. vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2")
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
-    p.add_argument("--mixed_precision", default="fp16", choices=["fp16", "bf16"],
-                   help="16-bit MFMA operand format of the ViLT / ALBEF engine, named like accelerate's setting: fp16 (the reference's "
-                        "accelerate_config.yaml:8; static 2^14 loss scale) or bf16")
+    p.add_argument("--mixed_precision", default=None, choices=["fp16", "bf16"],
+                   help="16-bit MFMA operand format of the engine, named like accelerate's setting.  Default: fp16 for ViLT (the "
+                        "reference's accelerate_config.yaml:8; dynamic loss scale with GradScaler semantics on the device) -- the format "
+                        "that meets the 1e-3 round-length bar at 80 steps --, bf16 for ALBEF (7.6e-4 after the reference's own "
+                        "full-size 40-step round, tests/golden/g11b; fp16 there: 3.2e-4, static 2^14 loss scale)")
     p.add_argument("--exchange", default="rccl_cabi", choices=["rccl_cabi", "torch"],
                    help="the round's FedAvg collective: rccl_cabi = feddat_fedavg_allreduce on a communicator made through "
                         "the C ABI (RCCL bound by dlopen; also taken with ONE rank, where it is the identity); torch = "
@@ -340,6 +342,8 @@ def main(argv=None):
         raise L.FeddatHipError("only --optimizer_mode dat is on the MI355X hot path (SURVEY.md section 2, row 13)")
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
     log = logging.getLogger("feddat_amd")
+    if args.mixed_precision is None:       # one default per engine, the same as bench.py's and the engines' own
+        args.mixed_precision = "bf16" if "albef" in args.encoder_name else "fp16"
     from . import weights
     # a checkpoint that was asked for must exist (local path; no network): never a silent random initialisation
     pretrained = weights.resolve(args.pretrained_model_name)
@@ -418,7 +422,10 @@ def main(argv=None):
     # the exchange: one C-ABI collective per round (main.py:510 get_average_net -> feddat_fedavg_allreduce); the local
     # pre-sum below has already applied num / total, so the collective runs with num = total = 1 (a plain SUM)
     rccl, rccl_scratch = None, None
-    if args.exchange == "rccl_cabi" and (world == 1 or dist.get_backend() == "nccl"):
+    # (one GPU per rank: whatever backend the torch.distributed group uses for its host-side rendezvous -- with "gloo" the C-ABI
+    #  communicator is the ONLY RCCL communicator on the device; FEDDAT_FORCE_DEVICE = the several-ranks-on-one-GPU test rig,
+    #  where RCCL refuses the duplicate device)
+    if args.exchange == "rccl_cabi" and (world == 1 or os.environ.get("FEDDAT_FORCE_DEVICE") is None):
         from .fedavg import make_rccl_comm
         # one rank: the collective is the identity and nothing may depend on librccl being loadable (the communicator is
         # still made when it can be, so the single-GPU run exercises the same entry points)
@@ -460,7 +467,7 @@ def main(argv=None):
         if not my_tasks:
             acc.zero_()
         if world > 1:       # every rank learns whether ANY rank's local update went non-finite, and all raise together
-            bad = torch.tensor([1.0 if nonfinite else 0.0], device=dev)
+            bad = torch.tensor([1.0 if nonfinite else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if bad.item() > 0:
                 raise L.FeddatHipError(f"round {comm_round}: non-finite trainable state after the local update on "

@@ -139,6 +139,9 @@ int feddat_layernorm_fwd_fp8(const float* x, long x_stride, const float* gamma, 
  * `workspace` (feddat_gemm_skinny_workspace_elems(M, N, K) floats), summed in a fixed order by a second kernel that
  * applies the epilogue.  Requirements: N % 64 == 0, K % 64 == 0, lda/ldb % 8 == 0. */
 long feddat_gemm_skinny_workspace_elems(int M, int N, int K);
+/* ABI 8, diagnostics: workgroups per CU the runtime grants the DUAL form of the persistent GEMM (two independent 128 x 192
+ * workgroups per CU, 80 KiB of LDS and 256 registers per wave each; feddat_set_debug_flags 1 | 2 [| 64]) on the current device. */
+int feddat_gemm_dual_blocks_per_cu(int* out);
 int feddat_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
                                const float* bias, const float* resid, int ldr, const void* aux, int ldaux,
                                float* out_f32, int ldo32, void* out_bf16, int ldo16, void* out2_bf16, int ldo2,
@@ -493,7 +496,8 @@ int feddat_vqa_score_accumulate(const float* logits, const float* target, int B,
  * kl_scale = temp^2 / N (N answers); row_kl (optional fp32 [R], NULL = all ones) multiplies a row's KL term and its gradient --
  * 0 for rows that exist only because a batch was padded to a static frame (the reference pads to the longest of the batch:
  * albef.py:56-57), N_frame / n_batch elsewhere.  dlogits_bf16 [R, ldd] (may be NULL) gets zeros in columns [V, ldd) so that it can be
- * the K-padded operand of the LM-head backward GEMM.  scalars: 4 + 2 R floats; [0] = loss, [1] = kl, [2] = L.  * grad_scale (ABI 7): factor on dL/dlogits only (the losses in `scalars` are unscaled): the power-of-two loss scale of a
+ * the K-padded operand of the LM-head backward GEMM.  scalars: 4 + 2 R floats; [0] = loss, [1] = kl, [2] = L.
+ * grad_scale (ABI 7): factor on dL/dlogits only (the losses in `scalars` are unscaled): the power-of-two loss scale of a
  * caller that runs the backward in the fp16 operand build (1 otherwise); it leaves through feddat_wgrad_seg.grad_unscale. */
 int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
                            const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale, float grad_scale,

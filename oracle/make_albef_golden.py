@@ -187,7 +187,7 @@ class _Acc:
         loss.backward()
 
 
-def ref_local_update(model, batches, lr, num_epochs=15):
+def ref_local_update(model, batches, lr, num_epochs=15, capture=None):
     from transformers import get_polynomial_decay_schedule_with_warmup
     sd = model.state_dict()
     for name in sd.keys():                            # task_trainer.py:36-45
@@ -208,7 +208,12 @@ def ref_local_update(model, batches, lr, num_epochs=15):
                                                     num_training_steps=tr.max_steps, lr_end=0, power=1)
     model.zero_grad()
     w = _Wrap(model)
-    return [float(tr.train_step(w, s, dict(b), opt, sch)) for s, b in enumerate(batches)]
+    losses = []
+    for s, b in enumerate(batches):
+        losses.append(float(tr.train_step(w, s, dict(b), opt, sch)))
+        if capture is not None:
+            capture(s, model)
+    return losses
 
 
 def np_(t):
@@ -356,6 +361,38 @@ def golden_round(out, steps=40):
           "mean |dW|", float(np.mean([rec[k] for k in rec if k.startswith("dmean::")])))
 
 
+def golden_round_full(out, steps=40, batch=4, snaps=(20, 40)):
+    """G11b: a local round at realistic length on the reference at FULL size (ViT-B/16 at 384 = 577 tokens, BERT-base 12 + 6
+    layers, vocab 30522; B = 4, 25-token questions, one 4-token answer each = SURVEY 8d config 4's shapes; dropout 0 = its
+    parity configuration): `steps` train_steps of ALBEFContinualLearner + TaskTrainer.train_step (albef_model.py:69-145,
+    task_trainer.py:280-330), num_epochs = 15 like G8 (steps = 40: 600 scheduler ticks, warm-up 60 ticks = 30 batches, the last
+    10 batches at the peak lr), the update of every adapter_0 /
+    adapter_1 tensor after each n in `snaps` as norm / mean / max / 1024 samples (like G8b for ViLT)."""
+    d = A.AlbefDims()
+    model = build_reference_model(d)
+    for n, p in model.named_parameters():
+        if "adapter" in n:
+            p.requires_grad = True
+    batches = [A.synthetic_batch(batch, d, 7700 + s) for s in range(steps)]
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rec = {"steps": np.array(steps, np.int64), "batch": np.array(batch, np.int64), "snaps": np.array(snaps, np.int64)}
+
+    def cap(step, m):
+        n = step + 1
+        print("G11b step", n, flush=True)
+        if n not in snaps:
+            return
+        for k, v in m.state_dict().items():
+            if "adapter_0" in k or "adapter_1" in k:
+                dw = (v.detach() - init[k]).flatten()
+                idx = torch.linspace(0, dw.numel() - 1, min(1024, dw.numel())).long()
+                rec[f"s{n}::dnorm::" + k], rec[f"s{n}::dmean::" + k] = np_(dw.norm()), np_(dw.abs().mean())
+                rec[f"s{n}::dmax::" + k], rec[f"s{n}::dsamp::" + k] = np_(dw.abs().max()), np_(dw[idx])
+    rec["losses"] = np.array(ref_local_update(model, batches, lr=1e-4, num_epochs=15, capture=cap), np.float32)
+    np.savez_compressed(os.path.join(out, f"g11b_albef_full_round{steps}.npz"), **rec)
+    print("G11b losses first/last", rec["losses"][:3], rec["losses"][-3:])
+
+
 def golden_dropout(out, steps=3, p=0.1, seed=77):
     """G12: train_steps of the small configuration UNDER model.train() with the reference's dropout probabilities
     (hidden_dropout_prob = attention_probs_dropout_prob = 0.1, src/configs/model_configs.py:44-46; task_trainer.py:75) -- the
@@ -437,6 +474,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-g11" in sys.argv:
         golden_round(out)
+        sys.exit(0)
+    if "--only-g11b" in sys.argv:          # full size, 40 steps: ~1 CPU-hour
+        golden_round_full(out)
         sys.exit(0)
     golden_small(out)
     golden_round(out)

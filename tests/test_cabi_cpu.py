@@ -103,12 +103,13 @@ def test_production_library_has_no_wrong_result_ablations():
     L = ctypes.CDLL(path)
     for wrong in (4, 8, 16, 512, 1 << 10, 1 << 16, 1 << 20, 2 << 20, 4 << 20, 1 << 24, 2 << 24, 4 << 24):
         assert L.feddat_set_debug_flags(wrong) == 1, wrong           # FEDDAT_EINVAL
-    for ok in (0, 1, 2, 32, 64, 128, 256, 1 << 23, 8 << 28, 1 | 32):
+    for ok in (0, 1, 2, 3, 3 | 64, 32, 64, 128, 256, 1 << 23, 8 << 28, 1 | 32):
         assert L.feddat_set_debug_flags(ok) == 0, ok
     L.feddat_set_debug_flags(0)
     # gemm_nt_v3_kernel<EPI, RT, FAKE = 1> is the deferred-epilogue probe: no such instantiation in the production object
     syms = subprocess.run(["strings", path], capture_output=True, text=True).stdout
-    assert "gemm_nt_v3_kernelILi0ELi6ELi0EE" in syms
-    assert "gemm_nt_v3_kernelILi0ELi6ELi1EE" not in syms
+    assert "gemm_nt_v3_kernelILi0ELi6ELi0ELb0EE" in syms           # <EPI, RT, FAKE = 0, DUAL = false>
+    assert "gemm_nt_v3_kernelILi0ELi4ELi0ELb1EE" in syms           # the DUAL form (selection flags 1 | 2; bit-identical results)
+    assert "gemm_nt_v3_kernelILi0ELi6ELi1E" not in syms
     src = open(os.path.join(ROOT, "feddat_amd", "lib.py")).read()
     assert "FEDDAT_GEMM_DEBUG" not in src and "environ" not in src

@@ -126,9 +126,37 @@ def test_gemm_kernel_variants_bit_identical(L, M, N, K):
         return [o0, o1, o2, u2, o3, o4]
     ref = run(1 | 32)                      # v2, 192-row tiles
     assert rel_err(ref[0], A.float() @ B.float().t() + bias) < 1.5e-2
-    for flags in (1 | 64, 2 | 32, 2 | 64, 2, 1 << 27, 0):      # v2 256-row, v3 192 / 256 / best-fit rows, no 160-row tiles, production
+    # v2 256-row, v3 192 / 256 / best-fit rows, no 160-row tiles, production, and (round 6) the DUAL form: two independent
+    # 128 x 192 workgroups per CU (3 = flags 1 | 2 together: every persistent launch; 3 | 64: those with >= 2 rounds of the doubled grid)
+    for flags in (1 | 64, 2 | 32, 2 | 64, 2, 1 << 27, 0, 3, 3 | 64):
         for a_, b_ in zip(ref, run(flags)):
             assert torch.equal(a_, b_), flags
+
+
+@pytest.mark.parametrize("M,N,K", [(11840, 3072, 768), (2051, 384, 192)])
+def test_gemm_dual_form_code_epilogues_bit_identical(L, M, N, K):
+    """The 8-bit gelu' code epilogues (FFN1: GELU + codes; FFN2^T: . code) on the DUAL form of the persistent kernel against the
+    two-group kernel they run on in production; the runtime must grant the design's two workgroups per CU."""
+    assert L.gemm_dual_blocks_per_cu() == 2
+    g = torch.Generator(device="cpu").manual_seed(M + N + 1)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    B = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    codes = torch.randint(0, 256, (M, N), generator=g, dtype=torch.uint8).to(DEV)
+
+    def run(flags):
+        L.set_debug_flags(flags)
+        try:
+            o, c, o2 = (torch.zeros(M, N, dtype=torch.bfloat16, device=DEV), torch.zeros(M, N, dtype=torch.uint8, device=DEV),
+                        torch.zeros(M, N, dtype=torch.bfloat16, device=DEV))
+            L.gemm_bf16_nt(A, B, L.EPI_GELU_G8, bias=bias, out_bf16=o, out2_bf16=c)
+            L.gemm_bf16_nt(A, B, L.EPI_MUL_G8, aux=codes, out_bf16=o2)
+            torch.cuda.synchronize()
+        finally:
+            L.set_debug_flags(0)
+        return o, c, o2
+    for a_, b_ in zip(run(0), run(3)):
+        assert torch.equal(a_, b_)
 
 
 def test_gemm_rejects_bad_shapes(L):

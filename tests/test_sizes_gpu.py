@@ -9,6 +9,7 @@
                                                  PER ELEMENT (|out - ref| <= atol + rtol |ref|): the max/max figure of
                                                  test_gemm_epilogues is blind to errors confined to small outputs.
 """
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -160,6 +161,56 @@ def test_albef_full_size_round_of_20_steps_vs_oracle():
     5 batches at the peak lr): north_star's bound on every adapter tensor of the 30 modules after the round."""
     _, _, moved = _albef_full_size_vs_oracle(4, 20, 6100, graph_from=1, ratio_bound=0.12, what="round, ")
     assert moved > 5e-4
+
+
+@pytest.mark.parametrize("operands", ["f16", "bf16"])
+def test_albef_full_size_round_of_40_steps_vs_reference_golden(golden_dir, operands):
+    """Round 6 (G11b): the REFERENCE's own 40-step round of the full-size ALBEF (ALBEFContinualLearner + TaskTrainer.train_step,
+    albef_model.py:69-145, task_trainer.py:280-330; ViT-B/16 at 384, BERT-base 12 + 6 layers, vocab 30522; B = 4, 25-token
+    questions, one 4-token answer each; num_epochs = 15: 600 scheduler ticks, 60 warm-up ticks, the last 10 batches at the
+    peak lr; oracle/make_albef_golden.py --only-g11b -> tests/golden/g11b_albef_full_round40.npz) replayed on AlbefDatEngine as
+    one hipGraph per step: north_star's 1e-3 on the reference's samples of all 240 adapter_0 / adapter_1 tensors after 20 and
+    40 steps, plus bulk statistics and the loss trajectory.  Both operand formats; the engine's default is the one listed first."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from feddat_amd import albef_engine
+    from tests.golden_util import load
+    g = load(golden_dir, "g11b_albef_full_round40.npz")
+    steps, B = int(g["steps"]), int(g["batch"])
+    assert (steps, B) == (40, 4)
+    d = A.AlbefDims()
+    P = A.make_params(d)
+    P0 = {k: v.clone() for k, v in P.items()}
+    eng = albef_engine.AlbefDatEngine(P, DEV, batch=B, n_answers=B, operands=operands)
+    eng.begin_local_update(steps_per_epoch=steps, num_epochs=15)
+    keys = [k.split("::", 2)[2] for k in g if k.startswith("s40::dsamp::")]
+    assert len(keys) == 240
+    losses = []
+    for s in range(steps):
+        out = eng.train_step(_dev(A.synthetic_batch(B, d, 7700 + s)), use_graph=True)
+        losses.append(float(out[0]))
+        if s + 1 not in (20, 40):
+            continue
+        n, sd = s + 1, eng.state_dict()
+        worst = dict(max=0.0, ratio=0.0, norm=0.0, moved=0.0, over=0)
+        for k in keys:
+            dw = (sd[k].cpu() - P0[k]).flatten()
+            ref = torch.from_numpy(g[f"s{n}::dsamp::{k}"])
+            err = (dw[torch.linspace(0, dw.numel() - 1, min(1024, dw.numel())).long()] - ref).abs()
+            worst["max"] = max(worst["max"], float(err.max()))
+            worst["ratio"] = max(worst["ratio"], float(err.mean()) / max(float(ref.abs().mean()), 1e-12))
+            worst["norm"] = max(worst["norm"], abs(float(dw.norm()) - float(g[f"s{n}::dnorm::{k}"])) / float(g[f"s{n}::dnorm::{k}"]))
+            worst["moved"] = max(worst["moved"], float(g[f"s{n}::dmax::{k}"]))
+            worst["over"] += int((err > 1e-3).sum())
+        print(f"ALBEF full size, {operands}, {n} steps vs the reference's round: max |ddW| {worst['max']:.2e}, mean ratio "
+              f"{worst['ratio']:.4f}, norm {worst['norm']:.4f}, samples > 1e-3: {worst['over']}, the reference moves the adapters by up "
+              f"to {worst['moved']:.2e}")
+        assert worst["moved"] > (3e-4 if n == 20 else 1.5e-3)
+        assert worst["max"] < 1e-3 and worst["over"] == 0, (operands, n, worst)
+        assert worst["ratio"] < (0.05 if operands == "f16" else 0.12) and worst["norm"] < (0.02 if operands == "f16" else 0.05), (operands, n, worst)
+    rel = np.abs(np.array(losses) - g["losses"]) / np.maximum(np.abs(g["losses"]), 1.0)
+    print("ALBEF full-size round: loss trajectory worst rel diff", float(rel.max()))
+    assert rel.max() < 1e-2
 
 
 PROD = [(11840, 2304, 768), (11840, 768, 768), (11840, 3072, 768), (11840, 768, 3072), (11840, 768, 2304)]

@@ -96,8 +96,11 @@ def main():
     args = ap.parse_args()
     from feddat_amd import engine, lib as L, vilt_spec
     if args.debug_flags & ~(1 | 2 | 32 | 64 | 128 | 256 | (1 << 23) | (0xf << 28)):
+        if args.operands != "bf16":      # the ablation build exists for bf16 operands only: say so instead of timing un-ablated kernels
+            raise SystemExit("timing-only ablation flags need --operands bf16 (libfeddat_hip_ablate.so is a bf16-operand build)")
         L.use_ablation_build()      # timing-only probes: libfeddat_hip_ablate.so (python -m feddat_amd.build --ablate)
-    L.set_debug_flags(args.debug_flags)
+    with L.operands(args.operands):     # the debug flags are per library: set them in the one the engine below runs in
+        L.set_debug_flags(args.debug_flags)
     dev = torch.device("cuda", 0)
     params = vilt_spec.random_init(12, ["c0"], seed=0)
     eng = engine.ViltDatEngine(params, ["c0"], dev, batch=args.batch, res=args.res, layers=12, operands=args.operands)
