@@ -1780,7 +1780,7 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
         // The DUAL form (selection flags 1 | 2 together: every persistent launch; 1 | 2 | 64: only launches of at least two full
         // rounds of the doubled grid, e.g. N = 3072 at M = 11 840: 96 x 16 tiles = 3.0 rounds of 512): two independent 128-row
         // workgroups per CU.  Measured, not the default: profiles/r06_gemm_dual_ab.txt, DESIGN.md section 7e.
-        if ((dbg & 3) == 3) {
+        if ((dbg & 3) == 3 && K / BK >= 3) {      // (its self-contained tiles need a first, a penultimate and a last k-tile)
             GemmArgsV2 a1 = a2;
             const int cu1 = n_cu;
             n_cu *= 2;
@@ -1793,7 +1793,9 @@ extern "C" int feddat_gemm_bf16_nt(const void* A, int lda, const void* B, int ld
                 hipLaunchKernelGGL(k4, dim3(total1 < 2 * n_cu ? total1 : 2 * n_cu), dim3(256), V4_LDS, stream, a1);
                 FD_LAUNCH_RET();
             }
-            dbg &= ~3;              // not taken: the production routing below
+        }
+        if ((dbg & 3) == 3) {       // not taken: the production routing below
+            dbg &= ~3;
             a2.dbg = dbg;
         }
         GemmArgsV2 a3 = a2, a4 = a2, a5 = a2, a7 = a2;

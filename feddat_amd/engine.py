@@ -143,6 +143,10 @@ class ViltDatEngine:
         self.lr, self.wd, self.eps = lr, weight_decay, adam_eps
         self.fp8 = bool(fp8)
         self.fp8_ffn_chain = bool(fp8_ffn_chain)      # fp8: also FFN2 forward and FFN1^T (their A operands leave as e4m3)
+        # fp8 attribution switches (tools/fp8_noise_attribution.py; production = both True): the backward's dX products on e4m3
+        # gradient rows / the forward's products on e4m3 activations
+        self.fp8_backward = True
+        self.fp8_forward = True
         self.ksplit = wgrad_splits
         self.ln_eps = 1e-12
         dev = self.dev
@@ -499,9 +503,9 @@ class ViltDatEngine:
         L.gemm_bf16_nt(x16, W["w1"], L.EPI_GELU_G8 if g8 else L.EPI_GELU, bias=W["b1"], out_bf16=f16, out2_bf16=u)
         L.gemm_bf16_nt(f16, W["w2"], L.EPI_RESID_F32, bias=W["b2"], resid=h2, out_f32=h3)
 
-    def _fp8_rows(self, rows: int) -> bool:
+    def _fp8_rows(self, rows: int, bwd: bool = False) -> bool:
         """fp8 products are used where feddat_gemm_fp8_nt applies (M >= 1024); smaller launches stay bf16."""
-        return self.fp8 and rows >= 1024
+        return self.fp8 and rows >= 1024 and (self.fp8_backward if bwd else self.fp8_forward)
 
     @_bound
     def _forward_dual(self):
@@ -714,7 +718,7 @@ class ViltDatEngine:
         for i in range(top - 1, 0, -1):
             # one C-ABI call per layer (feddat_vilt_layer_bwd): adapter backward + its weight gradients, FFN2^T (. gelu'),
             # FFN1^T, LN2 backward (+ residual), attention-out^T, attention backward, QKV^T, LN1 backward (+ residual)
-            if self._fp8_rows(R2):      # configs[4]: FFN2^T and attention-output^T on the fp8 MFMA, e4m3 gradient rows
+            if self._fp8_rows(R2, bwd=True):      # configs[4]: FFN2^T and attention-output^T on the fp8 MFMA, e4m3 gradient rows
                 a, W = self.act[i], self.layers[i]
                 L.adapter_bwd_fp8(cur, oth, self.g8, self.gsc, self._segs(i, False, True), R2, z_saved=self.zsave[i],
                                   z_out=self.z, dz_out=self.dz)
@@ -739,7 +743,7 @@ class ViltDatEngine:
                 L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
                 cur, oth = oth, cur
                 continue
-            if not self.use_layer_calls:
+            if not self.use_layer_calls or self.fp8:
                 a, W = self.act[i], self.layers[i]
                 L.adapter_bwd(None, cur, oth, self._segs(i, False, True), R2, dx_bf16=self.dh16, z_out=self.z,
                               dz_out=self.dz, z_saved=self.zsave[i])
