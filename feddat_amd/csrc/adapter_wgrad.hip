@@ -6,7 +6,9 @@
 // accuracy to ~2^-16 relative per product, fp32 accumulation; details at the loop): lane (index, token group) =
 // (lane & 15, lane >> 4) holds 8 consecutive tokens of its index, so the token-major activations are consumed as they
 // lie in HBM, no transposes.  A wave owns 64 columns x all 48 bottleneck units for a range of tokens: 8 float4 loads of
-// `big` feed 4 interleaved column tiles, 24 dword loads of `small` feed the 3 r-tiles -> 48 MFMAs per 32 tokens.  The 4
+// `big` feed 4 interleaved column tiles and (round 6) 8 three-dword loads of `small` feed 3 interleaved unit groups of 16 (unit
+// 3 q + v is row q of group v) -> 48 MFMAs per 32 tokens.  The 24 single-dword loads per round that three CONTIGUOUS 16-unit tiles
+// took were three quarters of the kernel's VMEM instructions for an eighth of its bytes.  The 4
 // waves of a block own 4 consecutive token ranges and are summed through LDS; the NBLK blocks per column chunk leave NBLK
 // partials that the (deterministic) reduce kernel folds straight into the flat gradient buffer [wd | bd | wu | bu].
 // HBM-bound in bytes (x and dy are each read once: 2 x T x 768 x 4 B).
@@ -14,7 +16,7 @@
 
 namespace {
 
-constexpr int H = 768, R = 48, NRT = 3, CW = 64;          // columns per wave
+constexpr int H = 768, R = 48, NRT = 3, CW = 64;          // NRT interleaved unit groups (unit NRT q + v = row q of group v); columns per wave
 constexpr int NCH = H / CW;                                 // 12 column chunks
 constexpr int NBLK = 10;                                    // token-split blocks per column chunk: 12 x 10 x 4 problems = 480 blocks
 constexpr int PSTRIDE = R * H + R + H;                      // one partial: [out r x c | colsum_small | colsum_big]
@@ -79,14 +81,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
     // masked: the loop stays branch-free and the compiler's vmcnt counts exact)
     f32x4 braw[8];
     float sraw[8][NRT];
+    const int su = NRT * i16;                           // this lane's 3 consecutive units: row i16 of the 3 unit groups
     auto load_round = [&](int t0, f32x4 (&bq)[8], float (&sq)[8][NRT]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int t = t0 + 8 * g + e;
             const int tc = t < t_end ? t : 0;          // masked tokens re-read row 0 (always inside the segment)
             bq[e] = *reinterpret_cast<const f32x4*>(big + (size_t)tc * H + c0 + 4 * i16);
+            const float* sp = sm + (size_t)tc * R + su;          // 12 contiguous bytes: one global_load_dwordx3
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) sq[e][rt] = sm[(size_t)tc * R + rt * 16 + i16];
+            for (int rt = 0; rt < NRT; ++rt) sq[e][rt] = sp[rt];
         }
     };
     load_round(t_begin, braw, sraw);
@@ -176,13 +180,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
             for (int rt = 0; rt < NRT; ++rt) ssum[rt] += red_s[w][rt][i16];
         }
     }
-    // D layout: acc[rt][v] row r = rt*16 + 4*(lane>>4) + e, col (lane & 15) -> column c = c0 + 4*(lane & 15) + v
+    // D layout: acc[rt][v] row q = 4*(lane>>4) + e of unit group rt = unit NRT q + rt, col (lane & 15) -> column
+    // c = c0 + 4*(lane & 15) + v
     float* P = L.partials + ((size_t)prob * NBLK + blk) * PSTRIDE;
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int r = rt * 16 + 4 * g + e;
+            const int r = NRT * (4 * g + e) + rt;
             f32x4 o = {alpha * acc[rt][0][e], alpha * acc[rt][1][e], alpha * acc[rt][2][e], alpha * acc[rt][3][e]};
             *reinterpret_cast<f32x4*>(P + (size_t)r * H + c0 + 4 * i16) = o;
         }
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradLaunch L) {   // 2 b
         *reinterpret_cast<f32x4*>(P + R * H + R + c0 + 4 * i16) = o;
         if (chunk == 0) {
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) P[R * H + rt * 16 + i16] = unscale * ssum[rt];
+            for (int rt = 0; rt < NRT; ++rt) P[R * H + NRT * i16 + rt] = unscale * ssum[rt];
         }
     }
 }
