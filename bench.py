@@ -200,7 +200,7 @@ def profiled_traffic(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel"), 
 
 
 def profiled_kernel_time(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel", "gemm_skinny", "gemm_nt_mid_kernel", "gemm_nt_kernel"),
-                         pattern="r[0-9][0-9]_kernel_stats.csv", step_marker="step_tick_multi"):
+                         pattern="r[0-9][0-9]_kernel_stats.csv", step_marker=("dat_step_finish", "step_tick_multi")):
     """Per-step time of the dominant kernel's launches in the committed `rocprofv3 --kernel-trace --stats` summary of this
     command (profiles/*_kernel_stats.csv: the hipGraph-replayed steps under the profiler), next to the live event-bracket
     figure: the two must agree (the brackets sit around an EAGER replay, whose launches run a few per cent longer)."""
@@ -213,8 +213,8 @@ def profiled_kernel_time(kernel_substrs=("gemm_nt_v2_kernel", "gemm_nt_v3_kernel
     for r in csv.DictReader(open(files[-1])):
         if any(k in r["kernel"] for k in kernel_substrs):
             ms += float(r["total_ms"])
-        if step_marker in r["kernel"]:
-            steps = int(r["calls"])
+        if any(m in r["kernel"] for m in step_marker):      # the step's last kernel (dynamic loss scale: dat_step_finish)
+            steps = max(steps, int(r["calls"]))
     if not steps or not ms:
         return None
     out = {"ms_per_step": round(ms / steps, 3), "steps": steps, "source": os.path.basename(files[-1]),

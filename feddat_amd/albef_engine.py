@@ -989,12 +989,17 @@ class AlbefDatEngine:
     def assert_finite(self):
         """As ViltDatEngine.assert_finite: the static loss scale of operands='f16' has no GradScaler behind it; one host read-back of
         the trainable adapters per local update turns an overflow into an error that names the knob."""
-        for a in (0, 1):
-            if not bool(torch.isfinite(self.ad[a].p).all()):
-                raise L.FeddatHipError(
-                    f"non-finite values in adapter_{a} after the local update: with operands={self.operands!r} the backward carries a "
-                    f"static loss scale of {self.loss_scale:g}; construct the engine with a smaller power of two (loss_scale=...) or "
-                    "operands='bf16'")
+        bad = self.nonfinite_groups()
+        if bad:
+            raise L.FeddatHipError(
+                f"non-finite values in {', '.join(bad)} after the local update: with operands={self.operands!r} the backward carries a "
+                f"static loss scale of {self.loss_scale:g}; construct the engine with a smaller power of two (loss_scale=...) or "
+                "operands='bf16' (this engine's default)")
+
+    def nonfinite_groups(self):
+        """Names of the trainable groups holding an inf / NaN (one host read-back each); [] = all finite (train.main agrees on
+        this across ranks before the FedAvg collective)."""
+        return [f"adapter_{a}" for a in (0, 1) if not bool(torch.isfinite(self.ad[a].p).all())]
 
     def comm_flat(self) -> torch.Tensor:
         """The FedAvg payload: all adapter_1 tensors of the 30 modules back-to-back (2 236 320 floats = 8.95 MB)."""

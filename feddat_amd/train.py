@@ -137,6 +137,10 @@ class TaskTrainer:
         """Non-finite trainable state after a local update is an error.  Standalone it raises here; under main() with several
         ranks it is only RECORDED (self.nonfinite) and main() agrees on it across ranks before the FedAvg collective, so that
         every rank raises together instead of one raising while its peers wait in the all-reduce."""
+        st = eng.scaler_state() if hasattr(eng, "scaler_state") else None
+        if st and st["dynamic"] and st["skipped_substeps"]:      # what accelerate logs as "Gradient overflow. Skipping step"
+            self.logger.warning("%s: the loss scaler skipped %d optimizer sub-step(s) in %d batch(es) of this local update; scale now %g",
+                                self.task_key, st["skipped_substeps"], st["skipped_batches"], st["scale"])
         if getattr(self, "defer_finite_check", False):
             self.nonfinite = eng.nonfinite_groups()
         else:

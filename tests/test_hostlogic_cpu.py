@@ -40,6 +40,40 @@ def test_agree_on_exchange_falls_back_without_raising_on_one_rank():
     assert agree_on_exchange(lambda: sentinel, 1, logging.getLogger("t")) is sentinel
 
 
+def test_finite_check_is_deferred_to_the_collective_under_several_ranks():
+    """a rank whose local update went non-finite must not raise on its own while its peers enter the FedAvg
+    all-reduce.  Standalone TaskTrainer.train raises (engine.assert_finite); driven by train.main with several ranks it only records
+    the outcome, main() all-reduces it over the rendezvous group and every rank raises together."""
+    import logging
+    import types
+    from feddat_amd import lib as L
+    from feddat_amd.train import TaskTrainer
+
+    class Eng:
+        def __init__(self, bad):
+            self.bad = bad
+
+        def nonfinite_groups(self):
+            return list(self.bad)
+
+        def assert_finite(self):
+            if self.bad:
+                raise L.FeddatHipError("non-finite values in " + ", ".join(self.bad))
+
+        def scaler_state(self):
+            return dict(dynamic=True, skipped_substeps=3, skipped_batches=2, scale=4096.0)
+    args = types.SimpleNamespace(local_epochs=1, num_epochs=15, lr=1e-4, hip_graph=True)
+    tr = TaskTrainer(args, "art", [], [], logging.getLogger("t"))
+    tr._finite_check(Eng([]))                                   # clean: nothing happens
+    with pytest.raises(L.FeddatHipError):
+        tr._finite_check(Eng(["head"]))                         # standalone: raises here
+    tr.defer_finite_check = True
+    tr._finite_check(Eng(["head", "adapter_0"]))                # under main() with world > 1: recorded, not raised
+    assert tr.nonfinite == ["head", "adapter_0"]
+    tr._finite_check(Eng([]))
+    assert tr.nonfinite == []
+
+
 def test_bench_round_split_reports_the_heterogeneity_bound():
     import bench
     rows = [dict(rank=r, steps=s, compute_s=0.01 * s, wait_s=0.0, allreduce_ms=0.1) for r, s in enumerate([40, 50, 60, 70, 80, 40, 50, 60])]
@@ -60,7 +94,7 @@ def test_bench_reads_the_committed_profile_summaries():
     assert kt is not None and kt["steps"] >= 5 and 2.0 < kt["ms_per_step"] < 8.0
     assert bench.profiled_traffic(pattern="r[0-9][0-9]_nothing.csv") is None
     assert bench.profiled_kernel_time(pattern="r[0-9][0-9]_nothing.csv") is None
-    assert bench.profiled_kernel_time(step_marker="no_such_kernel") is None
+    assert bench.profiled_kernel_time(step_marker=("no_such_kernel",)) is None
 
 
 def test_bench_round_split_reports_allreduce_bandwidth_and_shares():
