@@ -42,10 +42,12 @@ class AlbefDatEngine:
                  vit_depth: int = 12, enc_layers: int = 12, fusion_layer: int = 6, dec_layers: int = 6, image: int = 384,
                  vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0,
                  max_pos: int = 512, dropout: float = 0.0, seed: int = 0, stack_text: bool = False,
-                 operands: str = "bf16", loss_scale: Optional[float] = None):
+                 operands: str = "bf16", loss_scale: Optional[float] = None, dynamic_loss_scale: Optional[bool] = None,
+                 scale_growth_interval: int = 2000):
         """operands="f16": every 16-bit MFMA operand in IEEE half (libfeddat_hip_f16.so) with a power-of-two loss scale on
         dL/dlogits (feddat_lm_loss_fwd_bwd's grad_scale, default 2^14) that leaves through feddat_wgrad_seg.grad_unscale -- the
-        ViLT engine's scheme (engine.ViltDatEngine, there with the dynamic scaler).  The default here is bf16 -- in this class, in
+        ViLT engine's scheme (engine.ViltDatEngine), with the same device-side dynamic scaler (dynamic_loss_scale, default on for
+        "f16").  The default operand format here is bf16 -- in this class, in
         train.main (--encoder_name albef_no_distill without --mixed_precision) and in bench.py --workload albef alike: against the
         reference's own full-size 40-step round (tests/golden/g11b_albef_full_round40.npz) bf16 operands land at 7.6e-4 on the
         worst adapter element (mean ratio 0.024), inside north_star's 1e-3; fp16 operands at 3.2e-4 (0.005) for ~2 % of the step
@@ -53,6 +55,11 @@ class AlbefDatEngine:
         if operands not in L.OPERAND_DTYPE:
             raise L.FeddatHipError(f"operands must be 'bf16' or 'f16', got {operands!r}")
         self.operands, self.op_dtype = operands, L.OPERAND_DTYPE[operands]
+        # fp16 operands: the loss scale is dynamic by default -- GradScaler on the device exactly as in ViltDatEngine (DESIGN.md
+        # section 5b).  The LM head is frozen here, so the two sub-steps share no trainable tensor: flag B (adapter_0's pass)
+        # skips adapter_0's step alone; flag A (adapter_1's pass) voids the batch like in the ViLT engine (one finish kernel).
+        self.dynamic_scale = bool(operands == "f16" if dynamic_loss_scale is None else dynamic_loss_scale)
+        self.scale_growth_interval = int(scale_growth_interval)
         self.loss_scale = float(loss_scale if loss_scale is not None else (16384.0 if operands == "f16" else 1.0))
         if self.loss_scale <= 0 or math.frexp(self.loss_scale)[0] != 0.5:
             raise L.FeddatHipError("loss_scale must be a power of two (it is removed exactly)")
@@ -196,6 +203,10 @@ class AlbefDatEngine:
             self.wpart_stride2 = L.adapter_wgrad_workspace_elems(2)
             self.wpart["both"] = torch.empty(len(self.modules) * self.wpart_stride2, device=dev)
         self.side = None           # second stream of train_step (created lazily on the engine's device)
+        self.scaler_f = torch.tensor([self.loss_scale, 1.0 / self.loss_scale], dtype=torch.float32, device=self.dev)
+        self.scaler_i = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.ovf_flags = torch.zeros(2, dtype=torch.int32, device=self.dev)      # {B: adapter_0's pass, A: adapter_1's pass}
+        self._no_head = torch.zeros(2, dtype=torch.int32, device=self.dev)       # feddat_dat_step_finish's head counters: none here
         self.drop_ctr = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] = train_steps since begin_local_update
         self._alloc()
         if self.dropout > 0:       # teacher logits of P0: the gated text pass is re-run (other masks) for P2
@@ -350,9 +361,9 @@ class AlbefDatEngine:
                 n, h, g = self.ad_numel, rows // 2, self.gs["both"]
                 self._segs_cache[key] = L.make_wgrad_segs([
                     dict(x=x, dy=dy, z=g["z"], dz=g["dz"], grad=self.ad[0].g[m * n:(m + 1) * n], rows=h, scale=0.5,
-                         grad_unscale=1.0 / self.loss_scale),
+                         **self._scale_out()),
                     dict(x=x[h:], dy=dy[h:], z=g["z"][h:], dz=g["dz"][h:], grad=self.ad[1].g[m * n:(m + 1) * n], rows=h, scale=1.0,
-                         grad_unscale=1.0 / self.loss_scale)])
+                         **self._scale_out())])
             ws = self.wpart_stride2
             L.adapter_wgrad_partial(self._segs_cache[key], self.wpart["both"][m * ws:(m + 1) * ws])
             self._wg_done["both"].append(m)
@@ -365,8 +376,7 @@ class AlbefDatEngine:
             n = self.ad_numel
             self._segs_cache[key] = L.make_wgrad_segs([dict(x=x, dy=dy, z=self.gs[mode]["z"], dz=self.gs[mode]["dz"],
                                                             grad=self.ad[a].g[m * n:(m + 1) * n], rows=rows,
-                                                            scale=0.5 if mode == "gating" else 1.0,
-                                                            grad_unscale=1.0 / self.loss_scale)])
+                                                            scale=0.5 if mode == "gating" else 1.0, **self._scale_out())])
         ws = self.wpart_stride
         L.adapter_wgrad_partial(self._segs_cache[key], self.wpart[mode][m * ws:(m + 1) * ws])
         self._wg_done[mode].append(m)
@@ -385,7 +395,10 @@ class AlbefDatEngine:
                 ptrs = [self.ad[a].g[m * n:(m + 1) * n].data_ptr() for m in ms for a in (0, 1)]
                 self._segs_cache[key] = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
             ws = self.wpart_stride2
-            L.adapter_wgrad_reduce(self._segs_cache[key], len(ms), 2, self.wpart["both"][ms[0] * ws:], ws)
+            if self.dynamic_scale:      # segments (adapter_0, adapter_1) = flags (B, A)
+                L.adapter_wgrad_reduce_checked(self._segs_cache[key], len(ms), 2, self.wpart["both"][ms[0] * ws:], ws, self.ovf_flags)
+            else:
+                L.adapter_wgrad_reduce(self._segs_cache[key], len(ms), 2, self.wpart["both"][ms[0] * ws:], ws)
             return
         a = 0 if mode == "gating" else int(mode.split("_")[1])
         ms = tuple(sorted(done))
@@ -397,11 +410,29 @@ class AlbefDatEngine:
             self._segs_cache[key] = (ptrs, contiguous)
         ptrs, contiguous = self._segs_cache[key]
         ws = self.wpart_stride
+        red = (lambda *a_: L.adapter_wgrad_reduce_checked(*a_, self.ovf_flags[a:a + 1])) if self.dynamic_scale else L.adapter_wgrad_reduce
         if contiguous:       # the usual case (all 30 modules): slots m0 .. m0 + len - 1 are one strided batch
-            L.adapter_wgrad_reduce(ptrs, len(ms), 1, self.wpart[mode][ms[0] * ws:], ws)
+            red(ptrs, len(ms), 1, self.wpart[mode][ms[0] * ws:], ws)
         else:
             for j, m in enumerate(ms):
-                L.adapter_wgrad_reduce(ptrs[j:j + 1], 1, 1, self.wpart[mode][m * ws:], ws)
+                red(ptrs[j:j + 1], 1, 1, self.wpart[mode][m * ws:], ws)
+
+    def _scale_out(self):
+        """How the loss scale leaves, where the adapter weight gradients are formed (engine.ViltDatEngine._scale_out)."""
+        return dict(grad_unscale=1.0, grad_unscale_dev=self.scaler_f[1:2]) if self.dynamic_scale else \
+            dict(grad_unscale=1.0 / self.loss_scale)
+
+    def _scale_in(self, mode: str):
+        """... and how it enters, on dL/dlogits of the pass `mode` (+ that pass's overflow flag for a non-finite loss)."""
+        if not self.dynamic_scale:
+            return dict(grad_scale=self.loss_scale)
+        a = 0 if mode == "gating" else 1
+        return dict(grad_scale=1.0, grad_scale_dev=self.scaler_f[0:1], nonfinite=self.ovf_flags[a:a + 1])
+
+    def scaler_state(self) -> Dict[str, float]:
+        """Host copy of the loss scaler (one device read-back): current scale, growth tracker, skipped sub-steps / batches."""
+        f, i = self.scaler_f.tolist(), self.scaler_i.tolist()
+        return dict(scale=f[0], growth_tracker=i[0], skipped_substeps=i[1], skipped_batches=i[2], dynamic=self.dynamic_scale)
 
     @_bound
     def copy_global_to_teacher(self):
@@ -735,10 +766,10 @@ class AlbefDatEngine:
             for half, own in ((0, "gating"), (1, "adapter_1")):
                 L.lm_loss_fwd_bwd(lg[half * R1:(half + 1) * R1], lg[(1 - half) * R1:(2 - half) * R1], self.labels, self.row_w, self.V,
                                   3.0, 9.0 / self.N, g["dlogits"][half * R1:(half + 1) * R1], self.acts[own]["loss"],
-                                  row_kl=self.row_kl, grad_scale=self.loss_scale)
+                                  row_kl=self.row_kl, **self._scale_in(own))
         else:
             L.lm_loss_fwd_bwd(S["logits"], teacher_logits, self.labels, self.row_w, self.V, 3.0, 9.0 / self.N, g["dlogits"],
-                              S["loss"], row_kl=self.row_kl, grad_scale=self.loss_scale)
+                              S["loss"], row_kl=self.row_kl, **self._scale_in(mode))
         # LM head backward (frozen): logits = LN(gelu(dense(h))) W_emb^T
         L.gemm_bf16_nt(g["dlogits"], hd["wT"], L.EPI_BF16, out_bf16=g["b1"][:R])
         L.layernorm_bwd_dx(S["tg"], S["tst"], hd["lng"], R, H, dy_bf16=g["b1"][:R], out_f32=g["d1"][:R])
@@ -774,10 +805,14 @@ class AlbefDatEngine:
         self.ad[1].state.copy_(torch.tensor([0, 0], dtype=torch.int32))       # adapter_1 is stepped at tick 2b
         self.ad[0].state.copy_(torch.tensor([1, 0], dtype=torch.int32))       # adapter_0 at tick 2b + 1
         self.drop_ctr.copy_(torch.tensor([(int(dropout_epoch) << 16) & 0x7FFFFFFF, 0], dtype=torch.int32))
+        # a fresh GradScaler per local update (the reference builds a fresh Accelerator per round: main.py:435)
+        self.scaler_f.copy_(torch.tensor([self.loss_scale, 1.0 / self.loss_scale], dtype=torch.float32))
+        self.scaler_i.zero_()
+        self.ovf_flags.zero_()
         # a captured step stays valid across local updates as long as everything it froze into kernel arguments or into its
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.dropout, self.batch_text,
-               self.operands, self.loss_scale)
+               self.operands, self.loss_scale, self.dynamic_scale, self.scale_growth_interval)
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig
@@ -850,6 +885,28 @@ class AlbefDatEngine:
         self._optimizer_tail(drop)
 
     def _optimizer_tail(self, drop: bool):
+        if self.dynamic_scale:
+            # GradScaler's skips as device predicates (engine.ViltDatEngine._step_kernels; here without a head): adapter_1 stays on
+            # flag A, adapter_0 on either flag; feddat_dat_step_finish ticks the counters by what was applied, updates the scale and
+            # clears the flags
+            fB, fA = self.ovf_flags[0:1], self.ovf_flags[1:2]
+
+            def grp(a, skip):
+                G = self.ad[a]
+                if not hasattr(G, "_wdv"):
+                    G._wdv = G.seg_wd * self.wd
+                return L.adamw_group(G.p, G.g, G.m, G.v, G.seg_off, G._wdv, G.state, skip_if=skip)
+            groups = ([grp(1, (fA,))] if 1 in self.opt_adapters else []) + ([grp(0, (fA, fB))] if 0 in self.opt_adapters else [])
+            if groups:
+                L.adamw_multi(groups, self.lr, self.sched["warmup"], self.sched["total"], 0.9, 0.98, self.eps)
+            for a in (1, 0):
+                if a in self.opt_adapters:
+                    self.repack_adapter(a)
+            L.dat_step_finish(self._no_head, self.ad[1].state, self.ad[0].state, self.ovf_flags, self.scaler_f, self.scaler_i,
+                              2.0, 0.5, self.scale_growth_interval)
+            if drop:
+                L.step_tick(self.drop_ctr, 1, 0)
+            return
         if 1 in self.opt_adapters:
             self._adamw(self.ad[1])
             self.repack_adapter(1)
@@ -883,6 +940,7 @@ class AlbefDatEngine:
         groups = [self.ad[0], self.ad[1]]
         saved = [(g.p.clone(), g.m.clone(), g.v.clone(), g.state.clone()) for g in groups]
         saved_ctr = self.drop_ctr.clone()
+        saved_scaler = (self.scaler_f.clone(), self.scaler_i.clone(), self.ovf_flags.clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -899,6 +957,9 @@ class AlbefDatEngine:
             g.v.copy_(v)
             g.state.copy_(st)
         self.drop_ctr.copy_(saved_ctr)
+        self.scaler_f.copy_(saved_scaler[0])
+        self.scaler_i.copy_(saved_scaler[1])
+        self.ovf_flags.copy_(saved_scaler[2])
         for a in (0, 1):
             self.repack_adapter(a)
         torch.cuda.synchronize()
@@ -987,14 +1048,15 @@ class AlbefDatEngine:
             self.repack_adapter(a)
 
     def assert_finite(self):
-        """As ViltDatEngine.assert_finite: the static loss scale of operands='f16' has no GradScaler behind it; one host read-back of
-        the trainable adapters per local update turns an overflow into an error that names the knob."""
+        """As ViltDatEngine.assert_finite -- the last line of defence: with the dynamic loss scale (default for operands='f16') an
+        overflowed sub-step is skipped on the device and this never fires; with a static scale (dynamic_loss_scale=False) one host
+        read-back of the trainable adapters per local update turns an overflow into an error that names the knob."""
         bad = self.nonfinite_groups()
         if bad:
             raise L.FeddatHipError(
                 f"non-finite values in {', '.join(bad)} after the local update: with operands={self.operands!r} the backward carries a "
-                f"static loss scale of {self.loss_scale:g}; construct the engine with a smaller power of two (loss_scale=...) or "
-                "operands='bf16' (this engine's default)")
+                f"{'dynamic' if self.dynamic_scale else 'static'} loss scale (initial value {self.loss_scale:g}); construct the engine "
+                "with dynamic_loss_scale=True, a smaller power of two (loss_scale=...) or operands='bf16' (this engine's default)")
 
     def nonfinite_groups(self):
         """Names of the trainable groups holding an inf / NaN (one host read-back each); [] = all finite (train.main agrees on

@@ -113,8 +113,10 @@ __global__ __launch_bounds__(LM_NT) void lm_loss_kernel(const float* __restrict_
                                                         long ldl, const long* __restrict__ labels,
                                                         const float* __restrict__ row_w, const float* __restrict__ row_kl,
                                                         int V, float T, float kl_scale, bf16* __restrict__ dlogits, long ldd,
-                                                        float* __restrict__ row_terms, const float grad_scale) {
+                                                        float* __restrict__ row_terms, float grad_scale,
+                                                        const float* __restrict__ grad_scale_dev) {
     __shared__ float red[LM_NT / 64];
+    if (grad_scale_dev) grad_scale *= *grad_scale_dev;      // the dynamic loss scale (a power of two: exact)
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* l = logits + (size_t)r * ldl;
     const float* t = teacher ? teacher + (size_t)r * ldl : nullptr;
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(LM_NT) void lm_loss_kernel(const float* __restrict_
 }
 
 // scalars[0] = sum_r w_r ce_r (the loss ALBEF.forward returns), [1] = kl_scale * sum_r kl_r, [2] = ([0] + [1]) / 2
-__global__ void lm_loss_finish(const float* __restrict__ row_terms, int R, float kl_scale, float* __restrict__ scalars) {
+__global__ void lm_loss_finish(const float* __restrict__ row_terms, int R, float kl_scale, float* __restrict__ scalars,
+                               int* __restrict__ nonfinite) {
     float ce = 0.f, kl = 0.f;
     for (int r = threadIdx.x; r < R; r += 64) {
         ce += row_terms[2 * r];
@@ -209,6 +212,7 @@ __global__ void lm_loss_finish(const float* __restrict__ row_terms, int R, float
         scalars[0] = ce;
         scalars[1] = kl * kl_scale;
         scalars[2] = 0.5f * (ce + kl * kl_scale);
+        if (nonfinite && !(fabsf(ce + kl * kl_scale) <= 3.4e38f)) atomicOr(nonfinite, 1);      // GradScaler's inf check at its source
     }
 }
 
@@ -364,7 +368,22 @@ extern "C" int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher,
     FD_CHECK_ARG(ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0 && (!teacher || ((uintptr_t)teacher & 15) == 0));
     FD_CHECK_ARG(!dlogits_bf16 || (ldd % 4 == 0 && ((uintptr_t)dlogits_bf16 & 7) == 0));
     hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(LM_NT), 0, stream, logits, teacher, ldl, labels, row_weight, row_kl, V, temp,
-                       kl_scale, (bf16*)dlogits_bf16, ldd, row_terms, grad_scale);
-    hipLaunchKernelGGL(lm_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, R, kl_scale, scalars);
+                       kl_scale, (bf16*)dlogits_bf16, ldd, row_terms, grad_scale, (const float*)nullptr);
+    hipLaunchKernelGGL(lm_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, R, kl_scale, scalars, (int*)nullptr);
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_lm_loss_fwd_bwd_dyn(const float* logits, const float* teacher, long ldl, const long* labels,
+                                          const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale,
+                                          float grad_scale, const float* grad_scale_dev, int* nonfinite, void* dlogits_bf16,
+                                          long ldd, float* scalars, hipStream_t stream) {
+    FD_CHECK_ARG(logits && labels && row_weight && scalars && R > 0 && V > 0 && ldl >= V && temp > 0.f && grad_scale > 0.f);
+    FD_CHECK_ARG(!dlogits_bf16 || ldd >= V);
+    float* row_terms = scalars + 4;       // scalars: 4 + 2 R floats
+    FD_CHECK_ARG(ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0 && (!teacher || ((uintptr_t)teacher & 15) == 0));
+    FD_CHECK_ARG(!dlogits_bf16 || (ldd % 4 == 0 && ((uintptr_t)dlogits_bf16 & 7) == 0));
+    hipLaunchKernelGGL(lm_loss_kernel, dim3(R), dim3(LM_NT), 0, stream, logits, teacher, ldl, labels, row_weight, row_kl, V, temp,
+                       kl_scale, (bf16*)dlogits_bf16, ldd, row_terms, grad_scale, grad_scale_dev);
+    hipLaunchKernelGGL(lm_loss_finish, dim3(1), dim3(64), 0, stream, row_terms, R, kl_scale, scalars, nonfinite);
     FD_LAUNCH_RET();
 }

@@ -148,6 +148,7 @@ _SIGS = {
     "feddat_step_tick_multi": [C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, vp],
     "feddat_vqa_score_accumulate": [vp, vp, i32, i32, vp, vp],
     "feddat_lm_loss_fwd_bwd": [vp, vp, i64, vp, vp, vp, i32, i32, f32, f32, f32, vp, i64, vp, vp],
+    "feddat_lm_loss_fwd_bwd_dyn": [vp, vp, i64, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, i64, vp, vp],
     "feddat_axpby3": [vp, f32, vp, f32, vp, f32, vp, vp, i64, vp],
     "feddat_vilt_stage_inputs": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "feddat_softmax_gather_rows": [vp, i64, i32, i32, vp, i64, i32, vp, vp],
@@ -767,10 +768,18 @@ def vqa_score_accumulate(logits, target, acc):
          "feddat_vqa_score_accumulate")
 
 
-def lm_loss_fwd_bwd(logits, teacher, labels, row_weight, V, temp, kl_scale, dlogits_bf16, scalars, row_kl=None, grad_scale=1.0):
-    _dev(logits, teacher, labels, row_weight, dlogits_bf16, scalars, row_kl)
+def lm_loss_fwd_bwd(logits, teacher, labels, row_weight, V, temp, kl_scale, dlogits_bf16, scalars, row_kl=None, grad_scale=1.0,
+                    grad_scale_dev=None, nonfinite=None):
+    """grad_scale_dev / nonfinite (device float / int32 tensors): the dynamic loss scale and its overflow flag (ABI 8)."""
+    _dev(logits, teacher, labels, row_weight, dlogits_bf16, scalars, row_kl, grad_scale_dev, nonfinite)
     R = logits.shape[0]
     assert scalars.numel() >= 4 + 2 * R and labels.dtype == torch.int64
+    if grad_scale_dev is not None or nonfinite is not None:
+        _chk(load().feddat_lm_loss_fwd_bwd_dyn(_p(logits), _p(teacher), logits.stride(0), _p(labels), _p(row_weight), _p(row_kl), R, V,
+                                               temp, kl_scale, float(grad_scale), _p(grad_scale_dev), _p(nonfinite), _p(dlogits_bf16),
+                                               0 if dlogits_bf16 is None else dlogits_bf16.stride(0), _p(scalars), _stream()),
+             "feddat_lm_loss_fwd_bwd_dyn")
+        return
     _chk(load().feddat_lm_loss_fwd_bwd(_p(logits), _p(teacher), logits.stride(0), _p(labels), _p(row_weight), _p(row_kl), R, V, temp,
                                        kl_scale, float(grad_scale), _p(dlogits_bf16), 0 if dlogits_bf16 is None else dlogits_bf16.stride(0),
                                        _p(scalars), _stream()), "feddat_lm_loss_fwd_bwd")

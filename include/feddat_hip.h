@@ -502,6 +502,12 @@ int feddat_vqa_score_accumulate(const float* logits, const float* target, int B,
 int feddat_lm_loss_fwd_bwd(const float* logits, const float* teacher, long ldl, const long* labels,
                            const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale, float grad_scale,
                            void* dlogits_bf16, long ldd, float* scalars, hipStream_t stream);
+/* ABI 8: the same with the DYNAMIC loss scale -- grad_scale_dev (DEVICE float, may be NULL) multiplies grad_scale at run time,
+ * *nonfinite (DEVICE int, may be NULL) is OR-ed with 1 when L is inf / NaN (feddat_dat_loss_fwd_bwd_checked's ALBEF counterpart). */
+int feddat_lm_loss_fwd_bwd_dyn(const float* logits, const float* teacher, long ldl, const long* labels,
+                               const float* row_weight, const float* row_kl, int R, int V, float temp, float kl_scale,
+                               float grad_scale, const float* grad_scale_dev, int* nonfinite, void* dlogits_bf16, long ldd,
+                               float* scalars, hipStream_t stream);
 /* ALBEF.rank_answer's selections (src/modeling/models/albef_model.py:171-228; eval loop task_trainer.py:159-204).
  * feddat_softmax_gather_rows: out[r, j] = softmax(logits[r * row_stride + 0 .. V))[ids[j * id_stride]]  -- the probability of
  *   every candidate answer's first token after [BOS] (albef_model.py:183-186: F.softmax(logits, 1).index_select(1, answer_ids[:, 1])).

@@ -166,3 +166,66 @@ def test_a_nonfinite_loss_skips_the_step():
     eng.train_step(b)
     assert not eng.nonfinite_groups() and eng.head["art"].state.tolist() == [2, 2]
     assert not torch.equal(before["task_layer.art.clf_fc1.weight"], eng.state_dict()["task_layer.art.clf_fc1.weight"])
+
+
+# ---------------------------------------------------------------------------------------------------------------- ALBEF
+def _albef(**kw):
+    from feddat_amd import albef_engine
+    from oracle import albef_oracle as A
+    from tests.test_albef_gpu import SMALL, _small_engine
+    d = A.AlbefDims(**SMALL)
+    P = A.make_params(d)
+    eng = _small_engine(albef_engine, P, 3, 6, 12, 5, operands="f16", **kw)
+    batches = [A.synthetic_batch(3, d, 510 + s, q_len=12, a_len=5, k=[2, 1, 3], ragged=True) for s in range(5)]
+    return eng, [{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in batches]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_albef_dynamic_scale_is_bit_identical_without_overflow_and_skips_like_the_vilt_engine(use_graph):
+    """AlbefDatEngine(operands="f16"): the same device-side scaler (feddat_lm_loss_fwd_bwd_dyn, the checked reduce, predicated
+    AdamW, feddat_dat_step_finish without a head).  No overflow -> bit-identical with the static scale; flag B -> adapter_0's
+    sub-step alone is skipped; flag A -> nothing of the batch is applied; counters and scale follow."""
+    out = {}
+    for dyn in (False, True):
+        eng, batches = _albef(dynamic_loss_scale=dyn)
+        eng.begin_local_update(steps_per_epoch=5)
+        for b in batches[:3]:
+            eng.train_step(b, use_graph=use_graph)
+        torch.cuda.synchronize()
+        out[dyn] = {k: v.clone() for k, v in eng.state_dict().items()}
+    for k in out[False]:
+        assert torch.equal(out[False][k], out[True][k]), k
+    eng, batches = _albef()
+    assert eng.scaler_state()["dynamic"]
+    eng.begin_local_update(steps_per_epoch=5)
+    eng.train_step(batches[0], use_graph=use_graph)
+    a0, a1 = eng.ad[0].p.clone(), eng.ad[1].p.clone()
+    eng.ovf_flags[0] = 1                                     # sub-step B (adapter_0's pass) "overflowed"
+    eng.train_step(batches[1], use_graph=use_graph)
+    assert torch.equal(a0, eng.ad[0].p) and not torch.equal(a1, eng.ad[1].p)
+    assert eng.ad[1].state.tolist() == [3, 2] and eng.ad[0].state.tolist() == [4, 1] and eng.scaler_state()["scale"] == 8192.0
+    a0, a1 = eng.ad[0].p.clone(), eng.ad[1].p.clone()
+    eng.ovf_flags[1] = 1                                     # sub-step A: the batch is void
+    eng.train_step(batches[2], use_graph=use_graph)
+    assert torch.equal(a0, eng.ad[0].p) and torch.equal(a1, eng.ad[1].p)
+    assert eng.ad[1].state.tolist() == [3, 2] and eng.ad[0].state.tolist() == [4, 1] and eng.scaler_state()["scale"] == 4096.0
+    eng.train_step(batches[3], use_graph=use_graph)
+    assert not torch.equal(a0, eng.ad[0].p) and not torch.equal(a1, eng.ad[1].p)
+    st = eng.scaler_state()
+    assert st["skipped_substeps"] == 3 and st["skipped_batches"] == 2 and eng.ovf_flags.tolist() == [0, 0]
+    eng.assert_finite()
+
+
+def test_albef_a_scale_too_large_backs_off():
+    eng, batches = _albef(loss_scale=2.0 ** 24)       # (this model's gradients overflow fp16 down to a scale of ~2^17)
+    eng.begin_local_update(steps_per_epoch=16)
+    skipped = []
+    prev = 0
+    for s in range(16):
+        eng.train_step(batches[s % len(batches)])
+        st = eng.scaler_state()
+        skipped.append(st["skipped_substeps"] - prev)
+        prev = st["skipped_substeps"]
+        assert not eng.nonfinite_groups()
+    print("ALBEF: skipped sub-steps per batch", skipped, "final scale", st["scale"])
+    assert skipped[0] == 2 and sum(1 for x in skipped if x == 0) >= 3 and st["scale"] < 2.0 ** 22
