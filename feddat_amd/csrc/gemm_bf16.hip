@@ -1382,85 +1382,71 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(GemmArgs g, c
 // second kernel (the split-K pair cost 13-15 us per product in the step, 2 graph nodes; this form 6-8 us, 1 node).
 // N / 16 blocks (48 for N = 768, 192 for N = 3072) keep the weight stream spread over the chip.
 constexpr int SKF_NW = 16, SKF_MAXSL = 3;
+// (round 6) a block = 16 output columns x ONE 16-row tile (blockIdx.y): with all (<= 64) rows per block a launch had N / 16 = 48
+// workgroups at N = 768, each streaming the whole 64 x K A panel (393 KB at K = 3072) through one CU: 20 us for the two
+// K = 3072 products of the top layer.  Four times the workgroups, a quarter of the A bytes each; the per-element summation
+// order (slices per wave, then waves in order) is unchanged: bit-identical results.
 __global__ __launch_bounds__(SKF_NW * 64) void gemm_skinny_fused_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float red[SKF_NW - 1][64][16];
+    __shared__ __attribute__((aligned(16))) float red[SKF_NW - 1][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fg = lane >> 4, i16 = lane & 15;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16, mt = blockIdx.y;
     const int nslice = g.K / 64;                       // 64-deep k slices, dealt round-robin to the waves
     const bf16* wrow = g.B + (size_t)(n0 + i16) * g.ldb + fg * 8;
-    const bf16* arow[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) arow[mt] = g.A + (size_t)min(mt * 16 + i16, g.M - 1) * g.lda + fg * 8;
-    f32x4 acc[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16* arow = g.A + (size_t)min(mt * 16 + i16, g.M - 1) * g.lda + fg * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // a wave's slices (<= SKF_MAXSL for K <= 3072; the loop covers longer K): ALL their loads are issued before the first MFMA
     // -- these products are one chain of dependent load batches, so the batches must overlap, not follow each other
     for (int sl0 = wave; sl0 < nslice; sl0 += SKF_NW * SKF_MAXSL) {
-        bf16x8 w0[SKF_MAXSL], w1[SKF_MAXSL], a0[SKF_MAXSL][4], a1[SKF_MAXSL][4];
+        bf16x8 w0[SKF_MAXSL], w1[SKF_MAXSL], a0[SKF_MAXSL], a1[SKF_MAXSL];
 #pragma unroll
         for (int u = 0; u < SKF_MAXSL; ++u) {
             const int k = min(sl0 + u * SKF_NW, nslice - 1) * 64;           // (clamped: the surplus loads are not used)
             w0[u] = *reinterpret_cast<const bf16x8*>(wrow + k);
             w1[u] = *reinterpret_cast<const bf16x8*>(wrow + k + 32);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                a0[u][mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k);
-                a1[u][mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + k + 32);
-            }
+            a0[u] = *reinterpret_cast<const bf16x8*>(arow + k);
+            a1[u] = *reinterpret_cast<const bf16x8*>(arow + k + 32);
         }
 #pragma unroll
         for (int u = 0; u < SKF_MAXSL; ++u) {
             if (sl0 + u * SKF_NW >= nslice) break;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                acc[mt] = mfma16x32(w0[u], a0[u][mt], acc[mt]);
-                acc[mt] = mfma16x32(w1[u], a1[u][mt], acc[mt]);
-            }
+            acc = mfma16x32(w0[u], a0[u], acc);
+            acc = mfma16x32(w1[u], a1[u], acc);
         }
     }
-    if (wave > 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(&red[wave - 1][lane][4 * mt]) = acc[mt];
-    }
+    if (wave > 0) *reinterpret_cast<f32x4*>(&red[wave - 1][lane][0]) = acc;
     __syncthreads();
     if (wave != 0) return;
     const int nw = min(SKF_NW, nslice);
 #pragma unroll 1
-    for (int w = 1; w < nw; ++w)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = acc[mt] + *reinterpret_cast<const f32x4*>(&red[w - 1][lane][4 * mt]);
+    for (int w = 1; w < nw; ++w) acc = acc + *reinterpret_cast<const f32x4*>(&red[w - 1][lane][0]);
     // lane: n = n0 + 4 fg + (0..3), m = 16 mt + i16
     const int n = n0 + 4 * fg;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = mt * 16 + i16;
-        if (m >= g.M) continue;
-        const f32x4 v = acc[mt] + b4;
-        switch (g.epi) {
-            case FEDDAT_EPI_BF16:
-                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(v);
-                break;
-            case FEDDAT_EPI_RESID_F32:
-                *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) =
-                    v + *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n);
-                break;
-            case FEDDAT_EPI_GELU:
-                if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(v);
-                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(gelu4_pk(v));
-                break;
-            case FEDDAT_EPI_MUL_DGELU: {
-                const bf16x4 u = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)m * g.ldaux + n);
-                *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) =
-                    cvt4(v * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]}));
-                break;
-            }
-            default:
-                *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v;
+    const int m = mt * 16 + i16;
+    if (m >= g.M) return;
+    const f32x4 v = acc + b4;
+    switch (g.epi) {
+        case FEDDAT_EPI_BF16:
+            *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(v);
+            break;
+        case FEDDAT_EPI_RESID_F32:
+            *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) =
+                v + *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n);
+            break;
+        case FEDDAT_EPI_GELU:
+            if (g.out2_bf16) *reinterpret_cast<bf16x4*>(g.out2_bf16 + (size_t)m * g.ldo2 + n) = cvt4(v);
+            *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) = cvt4(gelu4_pk(v));
+            break;
+        case FEDDAT_EPI_MUL_DGELU: {
+            const bf16x4 u = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)m * g.ldaux + n);
+            *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.ldo16 + n) =
+                cvt4(v * gelu_grad4_pk(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]}));
+            break;
         }
+        default:
+            *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo32 + n) = v;
     }
 }
 
@@ -1502,7 +1488,7 @@ extern "C" int feddat_gemm_bf16_nt_skinny(const void* A, int lda, const void* B,
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldr = ldr; g.ldaux = ldaux;
     g.ldo32 = ldo32; g.ldo16 = ldo16; g.ldo2 = ldo2; g.epi = epi;
     if (!(fd_debug_flags() & 128)) {       // one launch: K split over the waves of a block (debug flag 128: the split-K pair)
-        hipLaunchKernelGGL(gemm_skinny_fused_kernel, dim3(N / 16), dim3(SKF_NW * 64), 0, stream, g);
+        hipLaunchKernelGGL(gemm_skinny_fused_kernel, dim3(N / 16, (M + 15) / 16), dim3(SKF_NW * 64), 0, stream, g);
         FD_LAUNCH_RET();
     }
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(N / 64, ksplit), dim3(256), 0, stream, g, workspace, K / ksplit);
