@@ -343,6 +343,9 @@ class ViltDatEngine:
         # True: the last layer's attention computes the ONE query per (sample, head) the pooler consumes (token 0) and its
         # rank-1 backward (feddat_attn_cls_fwd / _bwd); False: the dense kernels on all S queries (184 of 185 never read)
         self.cls_attention = True
+        # True: with the token-0-only attention the last layer's QKV product computes K | V for every row and Q for the 2B token-0
+        # rows only, and QKV^T contracts dK | dV densely + the token-0 rows' dQ as a skinny product (a third of both products)
+        self.top_q_cls = batch * 2 <= 64
         self.sched = dict(warmup=1, total=2)
         self.opt_adapters = (0, 1)
         self.task = self.tasks[0]
@@ -581,6 +584,12 @@ class ViltDatEngine:
             L.layernorm_fwd_fp8(a["h_in"], W["ln1g"], W["ln1b"], self.ln_eps, R2, H, self.x8[:R2], self.xs[:R2],
                                 stats=a["st1"])
             L.gemm_fp8_nt(self.x8[:R2], self.xs[:R2], W["wqkv8"], W["sqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
+        elif self.cls_attention and self.top_q_cls:
+            # (round 6) token 0 is the only QUERY of this layer that anything reads (step algebra item 6): K | V for every row
+            # (N = 1536: two exact rounds of tiles at configs[1]), Q for the 2B token-0 rows as one skinny product
+            L.gemm_bf16_nt(x16, W["wqkv"][H:], L.EPI_BF16, bias=W["bqkv"][H:], out_bf16=a["qkv"][:, H:])
+            L.gemm_bf16_nt(self._cls_rows(x16, nb), W["wqkv"][:H], L.EPI_BF16, bias=W["bqkv"][:H],
+                           out_bf16=self._cls_rows(a["qkv"], nb)[:, :H], skinny_workspace=self._skinny_ws())
         else:
             L.gemm_bf16_nt(x16, W["wqkv"], L.EPI_BF16, bias=W["bqkv"], out_bf16=a["qkv"])
         (L.attn_cls_fwd if self.cls_attention else L.attn_fwd)(a["qkv"], a["ctx"], a["lse"], nb, self.S, self.heads,
@@ -599,7 +608,7 @@ class ViltDatEngine:
         if getattr(self, "_skws", None) is None:
             nb, H, I = 2 * self.B, self.H, self.I
             n = max(L.gemm_skinny_workspace_elems(nb, I, H), L.gemm_skinny_workspace_elems(nb, H, I),
-                    L.gemm_skinny_workspace_elems(nb, H, H)) if nb <= 64 else 0
+                    L.gemm_skinny_workspace_elems(nb, H, H), L.gemm_skinny_workspace_elems(nb, H, 3 * H)) if nb <= 64 else 0
             self._skws = torch.empty(max(n, 1), device=self.dev) if n else False
         return self._skws if self._skws is not False else None
 
@@ -800,7 +809,15 @@ class ViltDatEngine:
         else:
             L.scatter_cls_rows(t["dctx"], None, self.dctx, nb, self.S, H)
             L.attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, nb, self.S, self.heads, key_mask=mask)
-        L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
+        if self.cls_attention and self.top_q_cls and nb <= 64:
+            # dQ is non-zero on the token-0 rows only: the dense product contracts dK | dV alone (K = 1536: the zero third of
+            # the contraction is not read or multiplied -- bit-identical on those rows), and the 2B token-0 rows are
+            # overwritten by the full contraction as one skinny product
+            L.gemm_bf16_nt(self.dqkv[:, H:], W["wqkvT"][:, H:], L.EPI_BF16, out_bf16=self.dx16)
+            L.gemm_bf16_nt(self._cls_rows(self.dqkv, nb), W["wqkvT"], L.EPI_BF16, out_bf16=self._cls_rows(self.dx16, nb),
+                           skinny_workspace=self._skinny_ws())
+        else:
+            L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
         L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
 
     def _layer_struct(self, i: int):
@@ -909,7 +926,7 @@ class ViltDatEngine:
         # launch list is unchanged (all mutable state -- weights, moments, counters -- lives in device buffers)
         sig = (task, total, self.sched["warmup"], self.opt_adapters, self.lr, self.wd, self.eps, self.use_layer_calls, self.fp8,
                self.fp8_ffn_chain, self.fused_tail, self.cls_attention, self.operands, self.loss_scale, self.fp8_mx_dqkv,
-               self._dyn(), self.scale_growth_interval)        # host-side switches that change the launch list are part of the signature
+               self._dyn(), self.scale_growth_interval, self.top_q_cls)        # host-side switches that change the launch list are part of the signature
         if getattr(self, "_graph_sig", None) != sig:
             self.graph = None
             self._graph_sig = sig
