@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
                                                         long dres_stride, int rows, int H, float* __restrict__ out32,
                                                         long out_stride, bf16* __restrict__ out16,
                                                         unsigned char* __restrict__ out8 = nullptr,
-                                                        float* __restrict__ out8_scale = nullptr) {
+                                                        float* __restrict__ out8_scale = nullptr, const int dres_every = 0) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -130,8 +130,11 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[c][e] - m1 - xh[c][e] * m2);
-            if (dres) {
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(dres + (size_t)row * dres_stride + i * 4);
+            // dres_every = E > 0: the residual gradient is non-zero on rows 0, E, 2 E, ... only and comes COMPACT (row r / E of
+            // dres): the top layer's, whose gradient lives on token 0 of every sample (wave-uniform condition)
+            if (dres && (dres_every == 0 || row % dres_every == 0)) {
+                const size_t rr = dres_every ? (size_t)(row / dres_every) : (size_t)row;
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(dres + rr * dres_stride + i * 4);
                 o = o + r4;
             }
             if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)row * out_stride + i * 4) = o;
@@ -266,6 +269,23 @@ extern "C" int feddat_layernorm_bwd_dx(const void* dy_bf16, const float* dy_f32,
                        (bf16*)out_bf16)
     if (H <= 768) LN_BWD(3); else if (H <= 1536) LN_BWD(6); else LN_BWD(8);
 #undef LN_BWD
+    FD_LAUNCH_RET();
+}
+
+extern "C" int feddat_layernorm_bwd_dx_sparse(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x,
+                                              long x_stride, const float* stats, const float* gamma, const float* dres,
+                                              long dres_stride, int dres_every, int rows, int H, float* out_f32,
+                                              long out_stride, void* out_bf16, hipStream_t stream) {
+    FD_CHECK_ARG((dy_bf16 != nullptr) != (dy_f32 != nullptr));
+    FD_CHECK_ARG(x && stats && gamma && dres && dres_every > 0 && rows > 0 && H > 0 && H % 4 == 0 && H <= 2048);
+    FD_CHECK_ARG(dy_stride % 4 == 0 && x_stride % 4 == 0 && dres_stride % 4 == 0);
+    FD_CHECK_ARG((out_f32 && out_stride % 4 == 0) || out_bf16);
+#define LN_BWDS(MC)                                                                                               \
+    hipLaunchKernelGGL(ln_bwd_dx_kernel<MC>, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)dy_bf16, dy_f32, \
+                       dy_stride, x, x_stride, stats, gamma, dres, dres_stride, rows, H, out_f32, out_stride,          \
+                       (bf16*)out_bf16, (unsigned char*)nullptr, (float*)nullptr, dres_every)
+    if (H <= 768) LN_BWDS(3); else if (H <= 1536) LN_BWDS(6); else LN_BWDS(8);
+#undef LN_BWDS
     FD_LAUNCH_RET();
 }
 

@@ -802,8 +802,8 @@ class ViltDatEngine:
         L.layernorm_bwd_dx(t["h2"], t["st2"], W["ln2g"], nb, H, dy_bf16=t["dx2"], dres=t["dh3"], out_f32=t["dh2"],
                            out_bf16=t["dh216"])
         L.gemm_bf16_nt(t["dh216"], W["woT"], L.EPI_F32, out_f32=t["dctx"], skinny_workspace=ws)
-        # scatter the token-0 rows into the dense operands of the attention / LN1 backward
-        L.scatter_cls_rows(t["dh2"], cur, None, nb, self.S, H)
+        # the token-0 rows' residual gradient t["dh2"] reaches the LN1 backward below compact (dres_every = S); only the dense
+        # attention path needs its own operand scattered into a dense buffer
         if self.cls_attention:       # rank-1 backward straight from the fp32 token-0 gradient rows
             L.attn_cls_bwd(a["qkv"], a["ctx"], a["lse"], t["dctx"], self.dqkv, nb, self.S, self.heads, key_mask=mask)
         else:
@@ -818,7 +818,7 @@ class ViltDatEngine:
                            skinny_workspace=self._skinny_ws())
         else:
             L.gemm_bf16_nt(self.dqkv, W["wqkvT"], L.EPI_BF16, out_bf16=self.dx16)
-        L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=cur, out_f32=oth)
+        L.layernorm_bwd_dx(a["h_in"], a["st1"], W["ln1g"], R2, H, dy_bf16=self.dx16, dres=t["dh2"], dres_every=self.S, out_f32=oth)
 
     def _layer_struct(self, i: int):
         """ctypes views of layer i's frozen weights and static activation buffers for the composite entry points."""

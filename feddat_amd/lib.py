@@ -119,6 +119,7 @@ _SIGS = {
     "feddat_dropout": [vp, vp, vp, vp, vp, i64, f32, u32, u32, vp, vp],
     "feddat_layernorm_fwd": [vp, i64, vp, vp, f32, i32, i32, vp, vp, vp, vp],
     "feddat_layernorm_bwd_dx": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp],
+    "feddat_layernorm_bwd_dx_sparse": [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp],
     "feddat_layernorm_bwd_full": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp],
     "feddat_adapter_fwd": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp],
     "feddat_adapter_fwd_ln": [vp, vp, i32, i32, i32, C.POINTER(AdapterSeg), i32, vp, vp, f32, vp, vp, vp, vp],
@@ -505,8 +506,17 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, x_stride=None, y_bf16=None, y
 
 
 def layernorm_bwd_dx(x, stats, gamma, rows, H, *, dy_bf16=None, dy_f32=None, dy_stride=None, x_stride=None,
-                     dres=None, dres_stride=None, out_f32=None, out_stride=None, out_bf16=None):
+                     dres=None, dres_stride=None, out_f32=None, out_stride=None, out_bf16=None, dres_every=0):
+    """dres_every = E > 0: dres is compact, its row r / E belongs to output row r for r % E == 0 (feddat_layernorm_bwd_dx_sparse)."""
     _dev(x)
+    if dres_every:
+        _dev(dres)
+        _chk(load().feddat_layernorm_bwd_dx_sparse(_p(dy_bf16), _p(dy_f32), H if dy_stride is None else dy_stride, _p(x),
+                                                   H if x_stride is None else x_stride, _p(stats), _p(gamma), _p(dres),
+                                                   H if dres_stride is None else dres_stride, int(dres_every), rows, H,
+                                                   _p(out_f32), H if out_stride is None else out_stride, _p(out_bf16), _stream()),
+             "feddat_layernorm_bwd_dx_sparse")
+        return
     _chk(load().feddat_layernorm_bwd_dx(_p(dy_bf16), _p(dy_f32), H if dy_stride is None else dy_stride, _p(x),
                                         H if x_stride is None else x_stride, _p(stats), _p(gamma), _p(dres),
                                         H if dres_stride is None else dres_stride, rows, H, _p(out_f32),

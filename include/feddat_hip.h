@@ -218,6 +218,12 @@ int feddat_layernorm_fwd(const float* x, long x_stride, const float* gamma, cons
 int feddat_layernorm_bwd_dx(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x, long x_stride,
                             const float* stats, const float* gamma, const float* dres, long dres_stride, int rows,
                             int H, float* out_f32, long out_stride, void* out_bf16, hipStream_t stream);
+/* ABI 8: the same with a SPARSE residual gradient -- non-zero on rows 0, E, 2 E, ... only (E = dres_every > 0), given compact:
+ * row r / E of dres (row stride dres_stride) is added to output row r when r % E == 0.  The top ViLT layer's residual gradient
+ * lives on token 0 of every sample (E = S): no scatter into a dense [rows, H] buffer, no read of its zeros. */
+int feddat_layernorm_bwd_dx_sparse(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x, long x_stride,
+                                   const float* stats, const float* gamma, const float* dres, long dres_stride, int dres_every,
+                                   int rows, int H, float* out_f32, long out_stride, void* out_bf16, hipStream_t stream);
 /* The same, its result additionally leaving as e4m3 rows + per-row scale (amax / 448): configs[4], the A operand of the
  * fp8 dX product that follows (attention-output^T after layernorm_after's backward). */
 int feddat_layernorm_bwd_dx_fp8(const void* dy_bf16, const float* dy_f32, long dy_stride, const float* x, long x_stride,
