@@ -80,33 +80,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     bf16x8 qn[2];
     qn[0] = gload_frag(base, ld, wave * 16 + i16, S, g);
     qn[1] = gload_frag(base, ld, wave * 16 + i16, S, 4 + g);
-    // (round 6) K and V are requested together, but only K is waited for: a wave's first score tile (QK^T, softmax) runs while
-    // V is still on its way; V goes to LDS behind it.  S_pad * 8 / 256 = NKS 16-byte pieces per thread and matrix.
-    bf16x8 kreg[NKS], vreg[NKS];
-#pragma unroll
-    for (int i = 0; i < NKS; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 3, chunk = idx & 7;
-        kreg[i] = gload_frag(base + H, ld, row, S, chunk);
-    }
-#pragma unroll
-    for (int i = 0; i < NKS; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 3, chunk = idx & 7;
-        vreg[i] = gload_frag(base + 2 * H, ld, row, S, chunk);
-    }
-#pragma unroll
-    for (int i = 0; i < NKS; ++i) {
-        const int idx = tid + 256 * i;
-        *reinterpret_cast<bf16x8*>(Ks + sw_off(idx >> 3, idx & 7)) = kreg[i];
-    }
+    load_head(base + H, ld, S, S_pad, Ks, tid);
+    load_head(base + 2 * H, ld, S, S_pad, Vs, tid);
     for (int k = tid; k < S_pad; k += 256) {
         const bool ok = k < S && (!kmask || kmask[(size_t)b * S + k]);
         mask_add[k] = ok ? 0.f : -INFINITY;
     }
     __syncthreads();
 
-    // scores of one query tile: S^T tiles (rows = keys kt*16 + 4g + r, col = query i16), log2-domain, then P = exp2(s - max)
-    auto scores = [&](const bf16x8 (&qf)[2], f32x4 (&s)[NKT], float& mx, float& sum) {
-        mx = -INFINITY;
+    for (int qt = wave; qt < NQT; qt += 4) {
+        if (qt * 16 >= S) break;
+        bf16x8 qf[2] = {qn[0], qn[1]};
+        if (qt + 4 < NQT) {          // (rows beyond S come back as zeros from gload_frag)
+            qn[0] = gload_frag(base, ld, (qt + 4) * 16 + i16, S, g);
+            qn[1] = gload_frag(base, ld, (qt + 4) * 16 + i16, S, 4 + g);
+        }
+        // S^T tiles: rows = keys kt*16 + 4g + r, col = query i16
+        f32x4 s[NKT];
+        float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -122,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        sum = 0.f;
+        float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -132,9 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-    };
-    // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q], normalised, and the row's log-sum-exp
-    auto pv_store = [&](const int qt, const f32x4 (&s)[NKT], const float mx, const float sum) {
+        // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -159,38 +148,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             }
             if (g == 0 && lse) lse[((size_t)b * heads + h) * S + q] = mx * (1.0f / LOG2E) + __logf(sum);
         }
-    };
-
-    // first tile of the wave: scores before V has landed
-    const bool has_first = wave * 16 < S;
-    f32x4 s0[NKT];
-    float mx0 = 0.f, sum0 = 1.f;
-    if (has_first) {
-        bf16x8 qf[2] = {qn[0], qn[1]};
-        if (wave + 4 < NQT) {          // (rows beyond S come back as zeros from gload_frag)
-            qn[0] = gload_frag(base, ld, (wave + 4) * 16 + i16, S, g);
-            qn[1] = gload_frag(base, ld, (wave + 4) * 16 + i16, S, 4 + g);
-        }
-        scores(qf, s0, mx0, sum0);
-    }
-#pragma unroll
-    for (int i = 0; i < NKS; ++i) {
-        const int idx = tid + 256 * i;
-        *reinterpret_cast<bf16x8*>(Vs + sw_off(idx >> 3, idx & 7)) = vreg[i];
-    }
-    __syncthreads();
-    if (has_first) pv_store(wave, s0, mx0, sum0);
-    for (int qt = wave + 4; qt < NQT; qt += 4) {
-        if (qt * 16 >= S) break;
-        bf16x8 qf[2] = {qn[0], qn[1]};
-        if (qt + 4 < NQT) {
-            qn[0] = gload_frag(base, ld, (qt + 4) * 16 + i16, S, g);
-            qn[1] = gload_frag(base, ld, (qt + 4) * 16 + i16, S, 4 + g);
-        }
-        f32x4 s[NKT];
-        float mx, sum;
-        scores(qf, s, mx, sum);
-        pv_store(qt, s, mx, sum);
     }
 }
 

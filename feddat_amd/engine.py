@@ -344,8 +344,11 @@ class ViltDatEngine:
         # rank-1 backward (feddat_attn_cls_fwd / _bwd); False: the dense kernels on all S queries (184 of 185 never read)
         self.cls_attention = True
         # True: with the token-0-only attention the last layer's QKV product computes K | V for every row and Q for the 2B token-0
-        # rows only, and QKV^T contracts dK | dV densely + the token-0 rows' dQ as a skinny product (a third of both products)
-        self.top_q_cls = batch * 2 <= 64
+        # rows only, and QKV^T contracts dK | dV densely + the token-0 rows' dQ as a skinny product (a third of both products:
+        # -0.03 ms/step, ratio 0.996).  OFF by default: equally accurate, but not bit-identical on the 2B token-0 rows, and at 80
+        # steps the AdamW trajectory is chaotic enough that this moves the draw of the round-length parity tests (DESIGN.md
+        # section 5, "draws"): the default keeps round 5's arithmetic, whose draws on both reference rounds are pinned.
+        self.top_q_cls = False
         self.sched = dict(warmup=1, total=2)
         self.opt_adapters = (0, 1)
         self.task = self.tasks[0]
