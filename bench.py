@@ -519,7 +519,7 @@ def bench_albef(args, world, rank, dev, dist):
                                    f"batch={B}/client, {args.res}x{args.res}, 25-token questions, one 4-token answer each, "
                                    f"BERT dropout {args.albef_dropout}" + (" (0 = the parity configuration, SURVEY 8d)"
                                                                             if args.albef_dropout == 0 else "") +
-                                   f", {'fp16 MFMA operands (static loss scale 2^14)' if eng.operands == 'f16' else 'bf16 MFMA operands (the ALBEF engine default: 7.6e-4 on the reference 40-step full-size round, fp16: 3.2e-4)'}",
+                                   f", {'fp16 MFMA operands (the engine default; dynamic loss scale, GradScaler semantics on the device, initial 2^14; 3.2e-4 / 2.6e-4 on the reference 40-step full-size rounds)' if eng.operands == 'f16' else 'bf16 MFMA operands (7.6e-4 / 8.4e-4 on the reference 40-step full-size rounds; the default is fp16)'}",
                        "clients": world, "hip_graph": use_graph, "hetero_steps": bool(args.hetero), "collective": coll,
                        "last_loss_0": round(loss, 4)},
             "samples_per_sec_per_gpu": round(sps / world, 2),
@@ -593,9 +593,9 @@ def main():
     ap.add_argument("--operands", default=None, choices=["bf16", "f16"],
                     help="16-bit MFMA operand format of the frozen products, attention and adapters: IEEE half with a 2^14 loss "
                          "scale (default: the reference's own GPU arithmetic is fp16 autocast, and the format that meets the "
-                         "north-star parity bar at round length) or bf16 -- same MFMA instruction rate, same bytes; --workload albef "
-                         "defaults to bf16 (its parity is inside the bar at the tested round lengths either way; fp16: 5x tighter, +2 percent)")
-    args_fixup = lambda a: setattr(a, "operands", a.operands or ("bf16" if a.workload == "albef" else "f16"))  # noqa: E731
+                         "north-star parity bar at round length) or bf16 -- same MFMA instruction rate, same bytes; both workloads "
+                         "default to fp16 (ALBEF in bf16: inside the bar at the tested round lengths with a fifth to spare, -1.5 percent)")
+    args_fixup = lambda a: setattr(a, "operands", a.operands or "f16")  # noqa: E731
     ap.add_argument("--hetero", action="store_true",
                     help="N > 1, SURVEY.md 8d config 3: rank r runs K * {40,50,60,70,80}[r mod 5] / 80 steps (heterogeneous "
                          "len(loader)) on answers drawn from its own Dirichlet(0.5) label prior; the imbalance is absorbed at the "

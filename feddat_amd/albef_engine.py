@@ -42,16 +42,17 @@ class AlbefDatEngine:
                  vit_depth: int = 12, enc_layers: int = 12, fusion_layer: int = 6, dec_layers: int = 6, image: int = 384,
                  vocab: int = 30522, lr: float = 1e-4, weight_decay: float = 1e-2, adam_eps: float = 1e-8, pad_id: int = 0,
                  max_pos: int = 512, dropout: float = 0.0, seed: int = 0, stack_text: bool = False,
-                 operands: str = "bf16", loss_scale: Optional[float] = None, dynamic_loss_scale: Optional[bool] = None,
+                 operands: str = "f16", loss_scale: Optional[float] = None, dynamic_loss_scale: Optional[bool] = None,
                  scale_growth_interval: int = 2000):
         """operands="f16": every 16-bit MFMA operand in IEEE half (libfeddat_hip_f16.so) with a power-of-two loss scale on
         dL/dlogits (feddat_lm_loss_fwd_bwd's grad_scale, default 2^14) that leaves through feddat_wgrad_seg.grad_unscale -- the
         ViLT engine's scheme (engine.ViltDatEngine), with the same device-side dynamic scaler (dynamic_loss_scale, default on for
-        "f16").  The default operand format here is bf16 -- in this class, in
-        train.main (--encoder_name albef_no_distill without --mixed_precision) and in bench.py --workload albef alike: against the
-        reference's own full-size 40-step round (tests/golden/g11b_albef_full_round40.npz) bf16 operands land at 7.6e-4 on the
-        worst adapter element (mean ratio 0.024), inside north_star's 1e-3; fp16 operands at 3.2e-4 (0.005) for ~2 % of the step
-        (tests/test_sizes_gpu.py::test_albef_full_size_round_of_40_steps_vs_reference_golden asserts both)."""
+        "f16").  The default operand format is fp16 -- in this class, in train.main (--encoder_name albef_no_distill without
+        --mixed_precision) and in bench.py --workload albef alike, the same as the ViLT engine's and the reference's own setting
+        (accelerate_config.yaml:8): against the reference's own full-size 40-step rounds (tests/golden/g11b_albef_full_round40.npz
+        and ..._seed8800.npz) fp16 operands land at 3.2e-4 / 2.6e-4 on the worst adapter element (mean ratio 0.005 / 0.003), bf16
+        operands at 7.6e-4 / 8.4e-4 (0.024 / 0.028): both inside north_star's 1e-3, bf16 with a fifth of it to spare, for 1.5 % of
+        the step (tests/test_sizes_gpu.py::test_albef_full_size_round_of_40_steps_vs_reference_golden asserts all four)."""
         if operands not in L.OPERAND_DTYPE:
             raise L.FeddatHipError(f"operands must be 'bf16' or 'f16', got {operands!r}")
         self.operands, self.op_dtype = operands, L.OPERAND_DTYPE[operands]

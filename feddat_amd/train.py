@@ -319,10 +319,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help="ALBEF only: override depths for quick runs, e.g. vit_depth=2,enc_layers=3,fusion_layer=1,dec_layers=2")
     p.add_argument("--no_hip_graph", dest="hip_graph", action="store_false")
     p.add_argument("--mixed_precision", default=None, choices=["fp16", "bf16"],
-                   help="16-bit MFMA operand format of the engine, named like accelerate's setting.  Default: fp16 for ViLT (the "
+                   help="16-bit MFMA operand format of the engine, named like accelerate's setting.  Default: fp16 for both encoders (the "
                         "reference's accelerate_config.yaml:8; dynamic loss scale with GradScaler semantics on the device) -- the format "
-                        "that meets the 1e-3 round-length bar at 80 steps --, bf16 for ALBEF (7.6e-4 after the reference's own "
-                        "full-size 40-step round, tests/golden/g11b; fp16 there: 3.2e-4, static 2^14 loss scale)")
+                        "that meets the 1e-3 round-length bar at 80 steps for ViLT and leaves two thirds of it after the reference's own "
+                        "full-size 40-step ALBEF rounds (tests/golden/g11b*: 3.2e-4 / 2.6e-4; bf16 there: 7.6e-4 / 8.4e-4)")
     p.add_argument("--exchange", default="rccl_cabi", choices=["rccl_cabi", "torch"],
                    help="the round's FedAvg collective: rccl_cabi = feddat_fedavg_allreduce on a communicator made through "
                         "the C ABI (RCCL bound by dlopen; also taken with ONE rank, where it is the identity); torch = "
@@ -346,8 +346,8 @@ def main(argv=None):
         raise L.FeddatHipError("only --optimizer_mode dat is on the MI355X hot path (SURVEY.md section 2, row 13)")
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
     log = logging.getLogger("feddat_amd")
-    if args.mixed_precision is None:       # one default per engine, the same as bench.py's and the engines' own
-        args.mixed_precision = "bf16" if "albef" in args.encoder_name else "fp16"
+    if args.mixed_precision is None:       # one default, the same as bench.py's and the engines' own
+        args.mixed_precision = "fp16"
     from . import weights
     # a checkpoint that was asked for must exist (local path; no network): never a silent random initialisation
     pretrained = weights.resolve(args.pretrained_model_name)

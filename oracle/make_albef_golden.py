@@ -361,7 +361,7 @@ def golden_round(out, steps=40):
           "mean |dW|", float(np.mean([rec[k] for k in rec if k.startswith("dmean::")])))
 
 
-def golden_round_full(out, steps=40, batch=4, snaps=(20, 40)):
+def golden_round_full(out, steps=40, batch=4, snaps=(20, 40), seed0=7700):
     """G11b: a local round at realistic length on the reference at FULL size (ViT-B/16 at 384 = 577 tokens, BERT-base 12 + 6
     layers, vocab 30522; B = 4, 25-token questions, one 4-token answer each = SURVEY 8d config 4's shapes; dropout 0 = its
     parity configuration): `steps` train_steps of ALBEFContinualLearner + TaskTrainer.train_step (albef_model.py:69-145,
@@ -373,9 +373,10 @@ def golden_round_full(out, steps=40, batch=4, snaps=(20, 40)):
     for n, p in model.named_parameters():
         if "adapter" in n:
             p.requires_grad = True
-    batches = [A.synthetic_batch(batch, d, 7700 + s) for s in range(steps)]
+    batches = [A.synthetic_batch(batch, d, seed0 + s) for s in range(steps)]       # --seed0 N: an independent round, own file
     init = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    rec = {"steps": np.array(steps, np.int64), "batch": np.array(batch, np.int64), "snaps": np.array(snaps, np.int64)}
+    rec = {"steps": np.array(steps, np.int64), "batch": np.array(batch, np.int64), "snaps": np.array(snaps, np.int64),
+           "seed0": np.array(seed0, np.int64)}
 
     def cap(step, m):
         n = step + 1
@@ -389,7 +390,7 @@ def golden_round_full(out, steps=40, batch=4, snaps=(20, 40)):
                 rec[f"s{n}::dnorm::" + k], rec[f"s{n}::dmean::" + k] = np_(dw.norm()), np_(dw.abs().mean())
                 rec[f"s{n}::dmax::" + k], rec[f"s{n}::dsamp::" + k] = np_(dw.abs().max()), np_(dw[idx])
     rec["losses"] = np.array(ref_local_update(model, batches, lr=1e-4, num_epochs=15, capture=cap), np.float32)
-    np.savez_compressed(os.path.join(out, f"g11b_albef_full_round{steps}.npz"), **rec)
+    np.savez_compressed(os.path.join(out, f"g11b_albef_full_round{steps}" + ("" if seed0 == 7700 else f"_seed{seed0}") + ".npz"), **rec)
     print("G11b losses first/last", rec["losses"][:3], rec["losses"][-3:])
 
 
@@ -476,7 +477,7 @@ if __name__ == "__main__":
         golden_round(out)
         sys.exit(0)
     if "--only-g11b" in sys.argv:          # full size, 40 steps: ~1 CPU-hour
-        golden_round_full(out)
+        golden_round_full(out, seed0=int(sys.argv[sys.argv.index("--seed0") + 1]) if "--seed0" in sys.argv else 7700)
         sys.exit(0)
     golden_small(out)
     golden_round(out)

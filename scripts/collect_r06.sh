@@ -12,7 +12,7 @@ python tools/step_breakdown.py --detail > gpurun_out/r06/step_breakdown.txt 2>&1
 bash tools/collect_profiles.sh r06 > gpurun_out/r06/collect.log 2>&1
 python tools/trace_gaps.py $(find gpurun_out/prof_r06/trace -name step_kernel_trace.csv | head -1) > gpurun_out/r06/step_timeline.txt 2>&1
 python bench.py --workload albef > gpurun_out/r06/bench_albef.json 2> gpurun_out/r06/bench_albef.err
-python bench.py --workload albef --operands f16 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/r06/bench_albef_f16.json
+python bench.py --workload albef --operands bf16 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/r06/bench_albef_bf16.json
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r06/albef_trace -o step --output-format csv -- python $R/bench.py --workload albef --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/r06/albef_trace.log 2>&1)
 for f in "" "--fp8"; do python bench.py --batch 64 $f --no-cpu-baseline --no-roofline --steps 100 --warmup 10 2>/dev/null | tail -1; done > gpurun_out/r06/bench_b64.json
 ls -la gpurun_out/r06 gpurun_out/prof_r06 | head -40
