@@ -14,5 +14,9 @@ python tools/trace_gaps.py $(find gpurun_out/prof_r06/trace -name step_kernel_tr
 python bench.py --workload albef > gpurun_out/r06/bench_albef.json 2> gpurun_out/r06/bench_albef.err
 python bench.py --workload albef --operands bf16 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/r06/bench_albef_bf16.json
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r06/albef_trace -o step --output-format csv -- python $R/bench.py --workload albef --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/r06/albef_trace.log 2>&1)
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  name=$(echo "$set" | awk '{print tolower($1)}')
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/prof_r06/albef_pmc_$name -o p --output-format csv -- python $R/bench.py --workload albef --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/r06/albef_pmc_$name.log 2>&1)
+done
 for f in "" "--fp8"; do python bench.py --batch 64 $f --no-cpu-baseline --no-roofline --steps 100 --warmup 10 2>/dev/null | tail -1; done > gpurun_out/r06/bench_b64.json
 ls -la gpurun_out/r06 gpurun_out/prof_r06 | head -40
